@@ -1,0 +1,399 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by IMPORTING the reference's model.py (never copied).
+
+Run only in the build container, where /root/reference exists:
+    python tools/make_goldens.py [--skip-big]
+It instantiates the reference's own stackedBRNN / DeepSpeech / L1Loss_mask
+(/root/reference/Speech_enhancement_by_AAS/model.py), loads deterministic weights from the
+portable PRNG (aas_enhancement_amd/prng.py), and runs the training steps restated from
+trainer_AAS.py:131-194, trainer_DCE.py:116-127, trainer_FSEGAN.py:128-182 and
+AM_training/train.py:297-349 with the substitutions listed in SURVEY.md 8(c)
+(.data[0]->.item(), no .cuda(), bool mask, O=nFeat, warp-ctc -> F.ctc_loss(log_softmax),
+A left in train mode, DeepSpeech(nFreq=F) built directly).
+Outputs: tests/golden/*.npz (data only: inputs, expected outputs, seeds).
+"""
+import argparse
+import os
+import sys
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/Speech_enhancement_by_AAS")
+import model as REF  # noqa: E402  (the reference's model.py)
+
+from aas_enhancement_amd import prng  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+LABELS = "_'abcdefghijklmnopqrstuvwxyz "  # 29 symbols, blank '_' at 0 (Common/labels.json)
+torch.set_num_threads(8)
+
+
+def load_weights(mod, seed, conv_std=None):
+    sd = mod.state_dict()
+    w = prng.fill_state_dict(sd, seed, conv_std=conv_std)
+    for k, v in w.items():
+        sd[k].copy_(torch.from_numpy(v))
+    return w
+
+
+def make_batch(N, Fdim, lens, seed, label_lens=None, lab_seed=None):
+    """_collate_fn layout (loader_functions.py:47-73): sorted desc by T, zero padded."""
+    T = max(lens)
+    x = np.zeros((N, Fdim, T), np.float32)
+    mask = np.zeros((N, 1, T), np.uint8)
+    pct = np.zeros(N, np.float32)
+    for n in range(N):
+        x[n, :, :lens[n]] = prng.uniform(seed + 17 * n, (Fdim, lens[n]), 0.0, 6.0)
+        mask[n, :, lens[n]:] = 1
+        pct[n] = lens[n] / float(T)
+    out = dict(inputs=x, mask=mask, pct=pct)
+    if label_lens is not None:
+        tg = []
+        for n in range(N):
+            tg.extend(prng.randint(lab_seed + n, (label_lens[n],), 1, 28).tolist())
+        out["targets"] = np.asarray(tg, np.int32)
+        out["target_sizes"] = np.asarray(label_lens, np.int32)
+    return out
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def ctc_sum(prob, targets, sizes, target_sizes):
+    return F.ctc_loss(F.log_softmax(prob, 2), targets.long(), sizes.long(), target_sizes.long(),
+                      blank=0, reduction="sum")
+
+
+def gnorm(model):  # trainer_AAS.py:353-361
+    g = 0
+    for p in model.parameters():
+        g = g + torch.pow(p.grad, 2).sum()
+    return float(torch.pow(g, 0.5))
+
+
+def aas_iteration(G, D, A, og, od, oa, ny, cl, cfg, kt, it, diff):
+    """trainer_AAS.py:131-194, line by line, on reference modules."""
+    G.zero_grad(); D.zero_grad(); A.zero_grad()
+    inputs, targets, pct, target_sizes = t(ny["inputs"]), t(ny["targets"]), t(ny["pct"]).clone(), t(ny["target_sizes"])
+    mask = t(ny["mask"]).bool()
+    N = inputs.size(0)
+    enhanced = G(inputs)
+    enhanced_D = enhanced.detach()
+    ae_ny_G = D(enhanced)
+    l_adv_ny_G, _ = diff(ae_ny_G, enhanced, mask)
+    l_adv_ny_G = l_adv_ny_G * cfg["w_adversarial"]
+    l_adv_ny_G_data = l_adv_ny_G.item()
+    l_adv_ny_G.backward(retain_graph=True)
+    g_adv = gnorm(G)
+    D.zero_grad()
+    ae_ny_D = D(enhanced_D)
+    l_adv_ny_D, _ = diff(ae_ny_D, enhanced_D, mask)
+    l_adv_ny_D = l_adv_ny_D * (-kt) * cfg["w_adversarial"]
+    l_adv_ny_D.backward()
+    prob = A(enhanced)
+    prob = prob.transpose(0, 1)
+    T = prob.size(0)
+    sizes = pct.mul_(int(T)).int()
+    l_CTC = cfg["w_acoustic"] * ctc_sum(prob, targets, sizes, target_sizes) / N
+    l_ctc_data = l_CTC.item()
+    l_CTC.backward()
+    g_ctc_adv = gnorm(G)
+    cinputs, cmask = t(cl["inputs"]), t(cl["mask"]).bool()
+    ae_cl = D(cinputs)
+    l_adv_cl, _ = diff(ae_cl, cinputs, cmask)
+    l_adv_cl = cfg["w_adversarial"] * l_adv_cl
+    l_adv_cl.backward()
+    l_adv_cl_data = l_adv_cl.item()
+    grads = {}
+    for nm, m in (("G", G), ("D", D), ("A", A)):
+        for k, p in m.named_parameters():
+            grads[nm + "." + k] = p.grad.detach().clone().numpy()
+    og.step(); od.step()
+    if it > cfg["allow_ASR_update_iter"]:
+        oa.step()
+    bal = cfg["gamma"] * l_adv_cl_data - l_adv_ny_G_data
+    kt = kt + cfg["lambda_k"] * bal
+    kt = max(min(1, kt), 0)
+    conv = l_adv_cl_data + abs(bal)
+    sc = dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, g_adv=g_adv,
+              g_ctc_adv=g_ctc_adv, kt=kt, conv_measure=conv)
+    return kt, sc, grads, enhanced.detach().numpy(), ae_ny_G.detach().numpy(), prob.detach().numpy(), sizes.numpy()
+
+
+def build_aas(Fdim, H, HA, M, nA, seed):
+    G = REF.stackedBRNN(I=Fdim, O=Fdim, H=H, L=4)
+    D = REF.stackedBRNN(I=Fdim, O=Fdim, H=H, L=4)
+    A = REF.DeepSpeech(rnn_type=nn.GRU, labels=LABELS, rnn_hidden_size=HA, rnn_layers=nA,
+                       kernel_sz=11, stride=2, map=M, cnn_layers=2, nFreq=Fdim)
+    load_weights(G, seed + 1)
+    load_weights(D, seed + 2)
+    load_weights(A, seed + 3, conv_std=0.1)
+    return G, D, A
+
+
+def adam(m, lr, amsgrad=True):
+    return torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999), amsgrad=amsgrad)
+
+
+def f1_tiny():
+    """F1: full tensors at tiny size; ragged lengths; 3 iterations."""
+    Fdim, H, HA, M = 8, 16, 12, 8
+    G, D, A = build_aas(Fdim, H, HA, M, 5, seed=1000)
+    init = {}
+    for nm, m in (("G", G), ("D", D), ("A", A)):
+        for k, v in m.state_dict().items():
+            init[nm + "." + k] = v.clone().numpy()
+    cfg = dict(w_adversarial=1.0, w_acoustic=1.0, gamma=0.5, lambda_k=0.001, allow_ASR_update_iter=0)
+    lr = 1e-3  # larger than the 1e-5 default so 3 Adam steps move the params measurably
+    og, od, oa = adam(G, lr), adam(D, lr), adam(A, lr)
+    diff = REF.L1Loss_mask()
+    out = dict(cfg_lr=lr, **{"cfg_" + k: v for k, v in cfg.items()})
+    out.update({"init." + k: v for k, v in init.items()})
+    kt = 0.3  # non-zero so the D-step contributes on iteration 0
+    out["kt0"] = kt
+    for it in range(3):
+        ny = make_batch(3, Fdim, [60, 50, 38], 2000 + 100 * it, [4, 3, 2], 3000 + 10 * it)
+        cl = make_batch(3, Fdim, [60, 47, 41], 4000 + 100 * it)
+        kt, sc, grads, enh, ae, prob, sizes = aas_iteration(G, D, A, og, od, oa, ny, cl, cfg, kt, it, diff)
+        for k, v in ny.items():
+            out["it%d.ny.%s" % (it, k)] = v
+        for k, v in cl.items():
+            out["it%d.cl.%s" % (it, k)] = v
+        for k, v in sc.items():
+            out["it%d.%s" % (it, k)] = np.float64(v)
+        out["it%d.enhanced" % it] = enh
+        out["it%d.ae_ny_G" % it] = ae
+        out["it%d.logits_tnc" % it] = prob
+        out["it%d.sizes" % it] = sizes
+        if it == 0:
+            out.update({"it0.grad." + k: v for k, v in grads.items()})
+    for nm, m in (("G", G), ("D", D), ("A", A)):
+        for k, v in m.state_dict().items():
+            out["final." + nm + "." + k] = v.clone().numpy()
+    np.savez_compressed(os.path.join(OUT, "f1_aas_tiny.npz"), **out)
+    print("F1", {k: out[k] for k in out if k.startswith("it2.") and np.ndim(out[k]) == 0})
+
+
+def sample_idx(seed, shape, n):
+    tot = int(np.prod(shape))
+    return prng.randint(seed, (n,), 0, tot - 1)
+
+
+def f2_dce():
+    """F2: config 1 (N=4,F=80,T=200,H=128, reference-equivalent 4 layers), 5 DCE steps."""
+    Fdim, H, N, T = 80, 128, 4, 200
+    G = REF.stackedBRNN(I=Fdim, O=Fdim, H=H, L=4)
+    load_weights(G, 5001)
+    og = adam(G, 1e-4)
+    diff = REF.L1Loss_mask()
+    out = dict(weight_seed=5001, lr=1e-4, N=N, F=Fdim, T=T, H=H)
+    losses, gns, sums, samples = [], [], [], []
+    idx = sample_idx(77, (N, Fdim, T), 64)
+    for it in range(5):
+        x = prng.uniform(6000 + it, (N, Fdim, T), 0.0, 6.0)
+        c = prng.uniform(7000 + it, (N, Fdim, T), 0.0, 6.0)
+        mask = torch.zeros(N, 1, T, dtype=torch.bool)
+        o = G(t(x))
+        loss, nel = diff(o, t(c), mask)
+        G.zero_grad()
+        loss.backward()
+        gns.append(gnorm(G))
+        og.step()
+        losses.append(loss.item())
+        sums.append(float(o.detach().double().sum()))
+        samples.append(o.detach().numpy().reshape(-1)[idx])
+    out.update(losses=np.asarray(losses), g_norms=np.asarray(gns), out_sums=np.asarray(sums),
+               sample_idx=idx, out_samples=np.stack(samples), nElement=int(nel),
+               input_seed0=6000, clean_seed0=7000)
+    np.savez_compressed(os.path.join(OUT, "f2_dce_config1.npz"), **out)
+    print("F2 losses", losses)
+
+
+def f3_config2():
+    """F3: config 2 (N=30,T=200,F=80,E/D 4x500, A 2conv+5x1000 GRU): scalars + samples, 2 iterations."""
+    Fdim, H, HA, M, N, T, L = 80, 500, 1000, 128, 30, 200, 20
+    G, D, A = build_aas(Fdim, H, HA, M, 5, seed=9000)
+    cfg = dict(w_adversarial=1.0, w_acoustic=1.0, gamma=0.5, lambda_k=0.001, allow_ASR_update_iter=0)
+    og, od, oa = adam(G, 1e-5), adam(D, 1e-5), adam(A, 1e-5)
+    diff = REF.L1Loss_mask()
+    out = dict(weight_seed=9000, lr=1e-5, N=N, F=Fdim, T=T, H=H, HA=HA, M=M, L=L, kt0=0.0,
+               noisy_seed=123, clean_seed=124, label_seed=125)
+    kt = 0.0
+    for it in range(2):
+        ny = dict(inputs=prng.uniform(123 + 1000 * it, (N, Fdim, T), 0.0, 6.0), mask=np.zeros((N, 1, T), np.uint8),
+                  pct=np.ones(N, np.float32),
+                  targets=prng.randint(125 + 1000 * it, (N * L,), 1, 28).astype(np.int32),
+                  target_sizes=np.full(N, L, np.int32))
+        cl = dict(inputs=prng.uniform(124 + 1000 * it, (N, Fdim, T), 0.0, 6.0), mask=np.zeros((N, 1, T), np.uint8))
+        kt, sc, grads, enh, ae, prob, sizes = aas_iteration(G, D, A, og, od, oa, ny, cl, cfg, kt, it, diff)
+        for k, v in sc.items():
+            out["it%d.%s" % (it, k)] = np.float64(v)
+        ie = sample_idx(31 + it, enh.shape, 256)
+        il = sample_idx(41 + it, prob.shape, 256)
+        out["it%d.enh_idx" % it] = ie
+        out["it%d.enh_samples" % it] = enh.reshape(-1)[ie]
+        out["it%d.logit_idx" % it] = il
+        out["it%d.logit_samples" % it] = prob.reshape(-1)[il]
+        out["it%d.enh_sum" % it] = float(np.float64(enh.astype(np.float64).sum()))
+        out["it%d.logit_abs_sum" % it] = float(np.abs(prob.astype(np.float64)).sum())
+        if it == 0:
+            for k in ("G.rnn1.rnn.weight_hh_l0", "G.first_linear.weight", "D.rnn4.rnn.weight_ih_l0_reverse",
+                      "A.conv.0.weight", "A.rnns.2.rnn.weight_hh_l0", "A.fc.0.module.1.weight"):
+                g = grads[k]
+                ig = sample_idx(51, g.shape, 64)
+                out["it0.gradsample_idx." + k] = ig
+                out["it0.gradsample." + k] = g.reshape(-1)[ig]
+                out["it0.gradnorm." + k] = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        print("F3 it", it, sc, flush=True)
+    np.savez_compressed(os.path.join(OUT, "f3_aas_config2.npz"), **out)
+
+
+def f4_ops():
+    """F4: per-op vectors from the reference's own BRNN / BatchRNN / DeepSpeech.conv / L1Loss_mask."""
+    out = {}
+    torch.manual_seed(0)
+    # LSTM BRNN fwd+bwd (model.py:88-105)
+    for tag, (T, N, H) in dict(s=(7, 2, 5), m=(23, 5, 24)).items():
+        for kind, cls in (("lstm", nn.LSTM), ("gru", nn.GRU)):
+            m = REF.BRNN(H, H, rnn_type=cls, bidirectional=True)
+            load_weights(m, 1 + T + (0 if kind == "lstm" else 50))
+            x = t(prng.normal(11 + T, (T, N, H))).requires_grad_(True)
+            y = m(x)
+            gy = t(prng.normal(12 + T, (T, N, H)))
+            y.backward(gy)
+            p = "brnn_%s_%s." % (kind, tag)
+            out[p + "x"], out[p + "y"], out[p + "gy"], out[p + "gx"] = x.detach().numpy(), y.detach().numpy(), gy.numpy(), x.grad.numpy()
+            for k, v in m.named_parameters():
+                out[p + "w." + k] = v.detach().numpy()
+                out[p + "gw." + k] = v.grad.numpy()
+    # BatchRNN with SequenceWise BN, GRU, in != hidden (model.py:66-86)
+    m = REF.BatchRNN(6, 9, rnn_type=nn.GRU, bidirectional=True, batch_norm=True)
+    load_weights(m, 301)
+    x = t(prng.normal(302, (11, 3, 6), 0.5, 2.0)).requires_grad_(True)
+    y = m(x)
+    gy = t(prng.normal(303, (11, 3, 9)))
+    y.backward(gy)
+    p = "batchrnn."
+    out[p + "x"], out[p + "y"], out[p + "gy"], out[p + "gx"] = x.detach().numpy(), y.detach().numpy(), gy.numpy(), x.grad.numpy()
+    for k, v in m.state_dict().items():
+        out[p + "sd." + k] = v.numpy().copy()
+    for k, v in m.named_parameters():
+        out[p + "gw." + k] = v.grad.numpy()
+    # DeepSpeech conv front-end: conv(k11,s2)+BN+LeakyReLU(slope=map), conv(k11,s1)+BN+LReLU (model.py:288-301)
+    A = REF.DeepSpeech(rnn_type=nn.GRU, labels=LABELS, rnn_hidden_size=6, rnn_layers=2, map=8, nFreq=10)
+    load_weights(A, 401, conv_std=0.1)
+    x = t(prng.uniform(402, (3, 10, 50), 0.0, 6.0)).requires_grad_(True)
+    y = A.conv(x)
+    gy = t(prng.normal(403, tuple(y.shape)))
+    y.backward(gy)
+    p = "dsconv."
+    out[p + "x"], out[p + "y"], out[p + "gy"], out[p + "gx"] = x.detach().numpy(), y.detach().numpy(), gy.numpy(), x.grad.numpy()
+    for k, v in A.conv.state_dict().items():
+        out[p + "sd." + k] = v.numpy().copy()
+    for k, v in A.conv.named_parameters():
+        out[p + "gw." + k] = v.grad.numpy()
+    # L1Loss_mask with padding: shows the mask is NOT applied (model.py:23-31)
+    a = t(prng.normal(501, (3, 4, 9))).requires_grad_(True)
+    b = t(prng.normal(502, (3, 4, 9))).requires_grad_(True)
+    mask = torch.zeros(3, 1, 9, dtype=torch.bool)
+    mask[1, :, 6:] = True
+    mask[2, :, 4:] = True
+    loss, nel = REF.L1Loss_mask()(a, b, mask)
+    loss.backward()
+    out["l1.a"], out["l1.b"], out["l1.mask"] = a.detach().numpy(), b.detach().numpy(), mask.numpy().astype(np.uint8)
+    out["l1.loss"], out["l1.nElement"], out["l1.ga"], out["l1.gb"] = loss.item(), int(nel), a.grad.numpy(), b.grad.numpy()
+    # stackedBRNN.forward_paired (model.py:233-238)
+    Dp = REF.stackedBRNN(I=12, O=6, H=10, L=4)
+    load_weights(Dp, 601)
+    xa, xb = t(prng.normal(602, (2, 6, 13))), t(prng.normal(603, (2, 6, 13)))
+    out["paired.a"], out["paired.b"], out["paired.y"] = xa.numpy(), xb.numpy(), Dp.forward_paired(xa, xb).detach().numpy()
+    for k, v in Dp.state_dict().items():
+        out["paired.sd." + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "f4_ops.npz"), **out)
+    print("F4 keys", len(out))
+
+
+def f5_fsegan_am():
+    """F5: FSEGAN (intended + as-written) and AM steps at tiny size."""
+    out = {}
+    Fdim, H = 8, 12
+    for variant in ("intended", "as_written"):
+        G = REF.stackedBRNN(I=Fdim, O=Fdim, H=H, L=4)
+        D = REF.stackedBRNN(I=2 * Fdim, O=Fdim, H=H, L=4)
+        load_weights(G, 7001)
+        load_weights(D, 7002)
+        og, od = adam(G, 1e-3), adam(D, 1e-3)
+        diff = REF.L1Loss_mask()
+        kt, w = 0.2, 0.01
+        for it in range(2):
+            b = make_batch(3, Fdim, [30, 26, 19], 7100 + it)
+            mixture, mask = t(b["inputs"]), t(b["mask"]).bool()
+            cl = make_batch(3, Fdim, [30, 26, 19], 7200 + it)["inputs"]
+            cleans = t(cl)
+            G.zero_grad(); D.zero_grad()
+            enhanced = G(mixture)
+            enhanced_D = enhanced.detach()
+            ae = D.forward_paired(enhanced, mixture)
+            l_g, _ = diff(ae, enhanced, mask)
+            l_g = l_g * w
+            l_g_data = l_g.item()
+            l_g.backward(retain_graph=True)
+            D.zero_grad()
+            ae_d = D.forward_paired(enhanced_D, mixture)
+            l_d, _ = diff(ae_d, enhanced_D, mask)
+            (l_d * (-kt) * w).backward()
+            dce, _ = diff(enhanced, cleans, mask)
+            if variant == "intended":
+                dce.backward()
+            ae_cl = D.forward_paired(cleans, mixture)
+            l_cl, _ = diff(ae_cl, cleans, mask)
+            l_cl = w * l_cl
+            l_cl.backward()
+            l_cl_data = l_cl.item()
+            gn = gnorm(G)
+            og.step(); od.step()
+            bal = 0.5 * l_cl_data - l_g_data
+            kt = max(min(1, kt + 0.001 * bal), 0)
+            p = "fsegan_%s.it%d." % (variant, it)
+            out[p + "l_adv_ny_G"], out[p + "l_adv_cl"], out[p + "dce"], out[p + "kt"], out[p + "g_norm"] = l_g_data, l_cl_data, dce.item(), kt, gn
+        for nm, m in (("G", G), ("D", D)):
+            for k, v in m.state_dict().items():
+                out["fsegan_%s.final.%s.%s" % (variant, nm, k)] = v.numpy().copy()
+    # AM step (AM_training/train.py:297-349), plain Adam
+    A = REF.DeepSpeech(rnn_type=nn.GRU, labels=LABELS, rnn_hidden_size=12, rnn_layers=3, map=8, nFreq=Fdim)
+    load_weights(A, 8001, conv_std=0.1)
+    opt = torch.optim.Adam(A.parameters(), lr=1e-3)
+    for it in range(2):
+        b = make_batch(3, Fdim, [60, 50, 38], 8100 + it, [4, 3, 2], 8200 + it)
+        o = A(t(b["inputs"])).transpose(0, 1)
+        sizes = t(b["pct"]).clone().mul_(int(o.size(0))).int()
+        loss = ctc_sum(o, t(b["targets"]), sizes, t(b["target_sizes"])) / 3
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        out["am.it%d.loss" % it] = loss.item()
+        out["am.it%d.logits" % it] = o.detach().numpy()
+    for k, v in A.state_dict().items():
+        out["am.final." + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "f5_fsegan_am.npz"), **out)
+    print("F5", {k: v for k, v in out.items() if np.ndim(v) == 0})
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-big", action="store_true", help="skip F3 (config 2, minutes of CPU)")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    f1_tiny()
+    f4_ops()
+    f5_fsegan_am()
+    f2_dce()
+    if not a.skip_big:
+        f3_config2()
