@@ -1,0 +1,89 @@
+"""ctypes binding of libaas_hip.so (the C ABI declared in include/aas_hip.h).
+
+PyTorch is plumbing here: it owns device memory (``tensor.data_ptr()``) and the HIP stream
+(``torch.cuda.current_stream().cuda_stream``); every compute op of the hot path is a call into the
+HIP library.  There is NO fallback: if the library is missing or a call fails, a RuntimeError is
+raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaas_hip.so")
+
+_lib = None
+
+c_int, c_i64, c_f32, c_vp, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "aas_version": [],
+    "aas_last_error": [],
+    "aas_device_cus": [],
+    "aas_gemm_f32": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
+                     c_int, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_i64],
+    "aas_transpose_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64],
+    "aas_swap01_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int],
+    "aas_add3_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64],
+    "aas_axpby_f32": [c_vp, c_vp, c_vp, c_f32, c_f32, c_i64],
+    "aas_colsum_f32": [c_vp, c_vp, c_i64, c_int, c_i64, c_vp, c_int],
+    "aas_sqsum_f32": [c_vp, c_vp, c_i64, c_vp],
+    "aas_rnn_sync_bytes": [],
+    "aas_lstm_fwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "aas_lstm_bwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "aas_gru_fwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "aas_gru_bwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "aas_bn_fwd": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp],
+    "aas_bn_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_vp],
+    "aas_col2im_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int],
+    "aas_l1_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp],
+    "aas_l1_bwd": [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_int],
+    "aas_ctc_get_workspace_size": [c_vp, c_vp, c_int, c_int, c_int, ctypes.POINTER(c_sz)],
+    "aas_compute_ctc_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int],
+    "aas_ctc_loss_async": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_f32],
+    "aas_adam_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_f32],
+    "aas_lmfb_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+}
+_RESTYPES = {"aas_last_error": ctypes.c_char_p, "aas_rnn_sync_bytes": c_sz}
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises loudly when the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "aas_enhancement_amd: HIP library %s is missing - build it with "
+                "`python -m aas_enhancement_amd.build` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, c_int)
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().aas_last_error()
+        raise RuntimeError("libaas_hip %s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a CUDA float tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("aas_enhancement_amd ops run on the MI355X only: got a %s tensor (no CPU fallback)" % t.device)

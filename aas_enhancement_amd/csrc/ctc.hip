@@ -1,0 +1,198 @@
+// CTC loss + gradient wrt pre-softmax activations (replaces warpctc_pytorch.CTCLoss, a third-party
+// C++/CUDA op the reference calls at Speech_enhancement_by_AAS/trainer_AAS.py:168,349 and
+// AM_training/train.py:319).  One workgroup per utterance; threads span the S = 2L+1 states of the
+// blank-extended label sequence; alpha is kept in global scratch for the beta/gradient sweep;
+// per-class occupancies are accumulated in LDS in linear space (normalised by the utterance
+// likelihood, so they are <= 1).  Latency-bound: T' sequential steps per sweep.
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float lse2(float a, float b) {
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    const float m = fmaxf(a, b);
+    return m + log1pf(__expf(-fabsf(a - b)));
+}
+
+__global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ acts, float* __restrict__ grads,
+                                                  const int* __restrict__ labels, const int* __restrict__ lab_off,
+                                                  const int* __restrict__ lab_lens, const int* __restrict__ act_lens,
+                                                  int C, int N, int Tmax, int Smax, float* __restrict__ costs,
+                                                  float* __restrict__ ws, int blank, float gscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* ext = reinterpret_cast<int*>(smem);
+    float* a0 = reinterpret_cast<float*>(smem) + Smax;
+    float* a1 = a0 + Smax;
+    float* occ = a1 + Smax;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int L = lab_lens[n];
+    int Tn = act_lens[n];
+    if (Tn > Tmax) Tn = Tmax;
+    const int S = 2 * L + 1;
+    float* alpha = ws + (int64_t)n * ((int64_t)Tmax * Smax + Tmax);
+    float* lse = alpha + (int64_t)Tmax * Smax;
+    const int off = lab_off[n];
+    auto act = [&](int t, int c) { return acts[((int64_t)t * N + n) * C + c]; };
+
+    for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? labels[off + (s >> 1)] : blank;
+    for (int t = tid; t < Tn; t += 256) {
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, act(t, c));
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += __expf(act(t, c) - m);
+        lse[t] = m + __logf(sum);
+    }
+    __syncthreads();
+    bool feasible = (Tn >= 1) && (S <= Smax);
+    float ll = -INFINITY;
+    if (feasible) {
+        // ---- alpha sweep ----
+        for (int s = tid; s < S; s += 256) {
+            float a = -INFINITY;
+            if (s < 2) a = act(0, ext[s]) - lse[0];
+            a0[s] = a;
+            alpha[s] = a;
+        }
+        __syncthreads();
+        for (int t = 1; t < Tn; ++t) {
+            const float* prev = (t & 1) ? a0 : a1;
+            float* cur = (t & 1) ? a1 : a0;
+            const float l_t = lse[t];
+            for (int s = tid; s < S; s += 256) {
+                float x = prev[s];
+                if (s >= 1) x = lse2(x, prev[s - 1]);
+                const int e = ext[s];
+                if (s >= 2 && e != blank && e != ext[s - 2]) x = lse2(x, prev[s - 2]);
+                if (x != -INFINITY) x += act(t, e) - l_t;
+                cur[s] = x;
+                alpha[(int64_t)t * Smax + s] = x;
+            }
+            __syncthreads();
+        }
+        const float* last = alpha + (int64_t)(Tn - 1) * Smax;
+        ll = last[S - 1];
+        if (S > 1) ll = lse2(ll, last[S - 2]);
+        __syncthreads();
+        feasible = (ll != -INFINITY);
+    }
+    if (tid == 0) costs[n] = feasible ? -ll : INFINITY;
+    if (!grads) return;
+    if (!feasible) {
+        for (int i = tid; i < Tmax * C; i += 256) grads[((int64_t)(i / C) * N + n) * C + (i % C)] = 0.f;
+        return;
+    }
+    // ---- beta sweep fused with the gradient ----
+    {
+        const int t = Tn - 1;
+        for (int s = tid; s < S; s += 256) a0[s] = (s >= S - 2) ? act(t, ext[s]) - lse[t] : -INFINITY;
+    }
+    __syncthreads();
+    int flip = 0;
+    for (int t = Tn - 1; t >= 0; --t) {
+        const float* bcur = flip ? a1 : a0;
+        float* bnext = flip ? a0 : a1;
+        for (int k = tid; k < C; k += 256) occ[k] = 0.f;
+        __syncthreads();
+        const float l_t = lse[t];
+        for (int s = tid; s < S; s += 256) {
+            const float al = alpha[(int64_t)t * Smax + s], be = bcur[s];
+            if (al != -INFINITY && be != -INFINITY) {
+                const int e = ext[s];
+                atomicAdd(&occ[e], __expf(al + be - (act(t, e) - l_t) - ll));
+            }
+        }
+        if (t > 0) {
+            const float l_p = lse[t - 1];
+            for (int s = tid; s < S; s += 256) {
+                float x = bcur[s];
+                if (s + 1 < S) x = lse2(x, bcur[s + 1]);
+                const int e = ext[s];
+                if (s + 2 < S && ext[s + 2] != blank && ext[s + 2] != e) x = lse2(x, bcur[s + 2]);
+                if (x != -INFINITY) x += act(t - 1, e) - l_p;
+                bnext[s] = x;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < C; k += 256)
+            grads[((int64_t)t * N + n) * C + k] = gscale * (__expf(act(t, k) - l_t) - occ[k]);
+        __syncthreads();
+        flip ^= 1;
+    }
+    for (int i = tid; i < (Tmax - Tn) * C; i += 256) grads[((int64_t)(Tn + i / C) * N + n) * C + (i % C)] = 0.f;
+}
+
+size_t ws_floats(int minibatch, int max_T, int smax) { return (size_t)minibatch * ((size_t)max_T * smax + max_T); }
+
+}  // namespace
+
+extern "C" int aas_ctc_loss_async(aasStream_t stream, const float* activations, float* gradients, const int* d_labels,
+                                  const int* d_label_offsets, const int* d_label_lens, const int* d_act_lens,
+                                  int alphabet, int minibatch, int max_T, int max_label_len, float* costs,
+                                  void* workspace, int blank, float grad_scale) {
+    AAS_CHECK(activations && d_labels && d_label_offsets && d_label_lens && d_act_lens && costs && workspace,
+              "aas_ctc_loss_async: null pointer");
+    AAS_CHECK(alphabet > 0 && minibatch > 0 && max_T > 0 && max_label_len >= 0 && blank >= 0 && blank < alphabet,
+              "aas_ctc_loss_async: bad sizes");
+    const int smax = 2 * max_label_len + 1;
+    const size_t lds = sizeof(float) * ((size_t)3 * smax + alphabet);
+    AAS_CHECK(lds <= 64 * 1024, "aas_ctc_loss_async: label length %d too long for the LDS state arrays", max_label_len);
+    hipLaunchKernelGGL(ctc_kernel, dim3(minibatch), dim3(256), lds, (hipStream_t)stream, activations, gradients, d_labels,
+                       d_label_offsets, d_label_lens, d_act_lens, alphabet, minibatch, max_T, smax, costs,
+                       (float*)workspace, blank, grad_scale);
+    AAS_LAUNCH_CHECK("aas_ctc_loss_async");
+    return 0;
+}
+
+// workspace layout for the warp-ctc-shaped synchronous entry point:
+//   [float scratch | costs N | labels sumL | offsets N | label_lens N | act_lens N]
+extern "C" int aas_ctc_get_workspace_size(const int* h_label_lens, const int* h_act_lens, int alphabet, int minibatch,
+                                          int max_T, size_t* bytes) {
+    AAS_CHECK(h_label_lens && h_act_lens && bytes && minibatch > 0 && alphabet > 0 && max_T > 0,
+              "aas_ctc_get_workspace_size: bad args");
+    int maxl = 0;
+    size_t suml = 0;
+    for (int i = 0; i < minibatch; ++i) {
+        AAS_CHECK(h_label_lens[i] >= 0 && h_act_lens[i] >= 0, "aas_ctc_get_workspace_size: negative length");
+        if (h_label_lens[i] > maxl) maxl = h_label_lens[i];
+        suml += h_label_lens[i];
+    }
+    *bytes = sizeof(float) * (ws_floats(minibatch, max_T, 2 * maxl + 1) + minibatch) + sizeof(int) * (suml + 3 * (size_t)minibatch) + 64;
+    return 0;
+}
+
+extern "C" int aas_compute_ctc_loss(aasStream_t stream, const float* activations, float* gradients,
+                                    const int* h_flat_labels, const int* h_label_lens, const int* h_act_lens,
+                                    int alphabet, int minibatch, int max_T, float* h_costs, void* workspace,
+                                    int blank) {
+    AAS_CHECK(activations && h_flat_labels && h_label_lens && h_act_lens && h_costs && workspace,
+              "aas_compute_ctc_loss: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int maxl = 0;
+    size_t suml = 0;
+    std::vector<int> offs(minibatch);
+    for (int i = 0; i < minibatch; ++i) {
+        offs[i] = (int)suml;
+        suml += h_label_lens[i];
+        if (h_label_lens[i] > maxl) maxl = h_label_lens[i];
+    }
+    float* wsf = (float*)workspace;
+    float* d_costs = wsf + ws_floats(minibatch, max_T, 2 * maxl + 1);
+    int* d_lab = (int*)(d_costs + minibatch);
+    int* d_off = d_lab + suml;
+    int* d_ll = d_off + minibatch;
+    int* d_al = d_ll + minibatch;
+    if (suml) AAS_HIP(hipMemcpyAsync(d_lab, h_flat_labels, sizeof(int) * suml, hipMemcpyHostToDevice, s));
+    AAS_HIP(hipMemcpyAsync(d_off, offs.data(), sizeof(int) * minibatch, hipMemcpyHostToDevice, s));
+    AAS_HIP(hipMemcpyAsync(d_ll, h_label_lens, sizeof(int) * minibatch, hipMemcpyHostToDevice, s));
+    AAS_HIP(hipMemcpyAsync(d_al, h_act_lens, sizeof(int) * minibatch, hipMemcpyHostToDevice, s));
+    AAS_HIP(hipStreamSynchronize(s));  // offs is a stack vector: the copies must have consumed it
+    int rc = aas_ctc_loss_async(stream, activations, gradients, d_lab, d_off, d_ll, d_al, alphabet, minibatch, max_T,
+                                maxl, d_costs, workspace, blank, 1.0f);
+    if (rc) return rc;
+    AAS_HIP(hipMemcpyAsync(h_costs, d_costs, sizeof(float) * minibatch, hipMemcpyDeviceToHost, s));
+    AAS_HIP(hipStreamSynchronize(s));
+    return 0;
+}

@@ -1,0 +1,277 @@
+// HBM-bound elementwise / layout / reduction kernels (gfx950): 16-byte vector accesses, 64-wide
+// wave reductions, grid-stride loops capped at ~8 blocks per CU.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXB = 2048;
+
+// ---- tiled transpose: out[b, c, r] = in[b, r, c] ------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        int R, int C, int64_t isb, int64_t isr, int64_t osb,
+                                                        int64_t osc) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    const float* ip = in + (int64_t)b * isb;
+    float* op = out + (int64_t)b * osb;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int r = r0 + ty + i * 4, c = c0 + tx;
+        if (r < R && c < C) tile[ty + i * 4][tx] = ip[(int64_t)r * isr + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int c = c0 + ty + i * 4, r = r0 + tx;
+        if (r < R && c < C) op[(int64_t)c * osc + r] = tile[tx][ty + i * 4];
+    }
+}
+
+__global__ __launch_bounds__(256) void add3_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                   const float* __restrict__ b, const float* __restrict__ c,
+                                                   int64_t n4, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n4; i += stride) {
+        f32x4 va = reinterpret_cast<const f32x4*>(a)[i];
+        f32x4 vb = reinterpret_cast<const f32x4*>(b)[i];
+        f32x4 v = va + vb;
+        if (c) v += reinterpret_cast<const f32x4*>(c)[i];
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+    // tail (n not a multiple of 4)
+    int64_t t = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) out[t] = a[t] + b[t] + (c ? c[t] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha,
+                                                    float beta, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        float v = alpha * x[i];
+        if (beta != 0.f) v += beta * y[i];
+        y[i] = v;
+    }
+}
+
+// out[c] += sum over a chunk of rows; grid (col blocks of 64, row chunks)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld,
+                                                     float* __restrict__ out, int rows_per_block) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    float s = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + w; r < r1; r += 4) s += x[r * ld + c];
+    part[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < C) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void sqsum_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ acc) {
+    __shared__ double part[4];
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float s = 0.f;
+    for (; i < n; i += stride) { float v = x[i]; s += v * v; }
+    double d = wave_sum_d((double)s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     int64_t n, double* __restrict__ acc) {
+    __shared__ double part[4];
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float s = 0.f;
+    for (; i < n; i += stride) s += fabsf(a[i] - b[i]);
+    double d = wave_sum_d((double)s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     int64_t n, float scale, float* __restrict__ ga,
+                                                     float* __restrict__ gb, int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        float d = a[i] - b[i];
+        float g = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);  // torch.abs backward: sign(d), 0 at 0
+        if (ga) ga[i] = accumulate ? ga[i] + g : g;
+        if (gb) gb[i] = accumulate ? gb[i] - g : -g;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ vmax, int64_t n, float b1, float b2, float eps,
+                                                   float step_size, float bc2_sqrt, int amsgrad, float gscale) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        float gi = g[i] * gscale;
+        float mo = m[i];
+        float mi = mo + (1.f - b1) * (gi - mo);  // torch: exp_avg.lerp_(grad, 1-beta1)
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        float vv = vi;
+        if (amsgrad) {
+            vv = fmaxf(vmax[i], vi);
+            vmax[i] = vv;
+        }
+        float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+// dx[n,t,f] = sum_kk dcol[n, (t-kk)/s, kk, f]
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int N,
+                                                     int T, int T1, int F, int KW, int s) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tot = (int64_t)N * T * F;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < tot; i += stride) {
+        int f = (int)(i % F);
+        int t = (int)((i / F) % T);
+        int n = (int)(i / ((int64_t)F * T));
+        float acc = 0.f;
+        for (int kk = 0; kk < KW; ++kk) {
+            int tt = t - kk;
+            if (tt < 0) break;
+            if (tt % s) continue;
+            int t1 = tt / s;
+            if (t1 < T1) acc += dcol[(((int64_t)n * T1 + t1) * KW + kk) * F + f];
+        }
+        dx[i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void swap01_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int B,
+                                                     int C) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tot = (int64_t)A * B * C;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < tot; i += stride) {
+        const int c = (int)(i % C);
+        const int b = (int)((i / C) % B);
+        const int a = (int)(i / ((int64_t)C * B));
+        out[((int64_t)b * A + a) * C + c] = in[i];
+    }
+}
+
+inline int grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > MAXB ? MAXB : b));
+}
+
+}  // namespace
+
+extern "C" int aas_transpose_f32(aasStream_t stream, const float* in, float* out, int B, int R, int C, int64_t isb,
+                                 int64_t isr, int64_t osb, int64_t osc) {
+    AAS_CHECK(in && out && B > 0 && R > 0 && C > 0, "aas_transpose_f32: bad args");
+    AAS_CHECK(B <= 65535 && cdiv(R, 64) <= 65535, "aas_transpose_f32: grid too large");
+    dim3 grid(cdiv(C, 64), cdiv(R, 64), B);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, R, C, isb, isr, osb, osc);
+    AAS_LAUNCH_CHECK("aas_transpose_f32");
+    return 0;
+}
+
+extern "C" int aas_swap01_f32(aasStream_t stream, const float* in, float* out, int A, int B, int C) {
+    AAS_CHECK(in && out && A > 0 && B > 0 && C > 0, "aas_swap01_f32: bad args");
+    hipLaunchKernelGGL(swap01_kernel, dim3(grid_for((int64_t)A * B * C)), dim3(256), 0, (hipStream_t)stream, in, out, A, B, C);
+    AAS_LAUNCH_CHECK("aas_swap01_f32");
+    return 0;
+}
+
+extern "C" int aas_add3_f32(aasStream_t stream, float* out, const float* a, const float* b, const float* c, int64_t n) {
+    AAS_CHECK(out && a && b && n >= 0, "aas_add3_f32: bad args");
+    if (n == 0) return 0;
+    bool al = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+                reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+    int64_t n4 = al ? n / 4 : 0;
+    int g = grid_for(n4 > 0 ? n4 : n);
+    if (!al) {  // unaligned: scalar path = tail handling over everything, needs enough threads
+        AAS_CHECK(false, "aas_add3_f32: pointers must be 16-byte aligned");
+    }
+    hipLaunchKernelGGL(add3_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, out, a, b, c, n4, n);
+    AAS_LAUNCH_CHECK("aas_add3_f32");
+    return 0;
+}
+
+extern "C" int aas_axpby_f32(aasStream_t stream, float* y, const float* x, float alpha, float beta, int64_t n) {
+    AAS_CHECK(y && x && n >= 0, "aas_axpby_f32: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, beta, n);
+    AAS_LAUNCH_CHECK("aas_axpby_f32");
+    return 0;
+}
+
+extern "C" int aas_colsum_f32(aasStream_t stream, const float* x, int64_t R, int C, int64_t ld, float* out,
+                              int accumulate) {
+    AAS_CHECK(x && out && R >= 0 && C > 0, "aas_colsum_f32: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) AAS_HIP(hipMemsetAsync(out, 0, sizeof(float) * C, s));
+    if (R == 0) return 0;
+    int rpb = 256;
+    dim3 grid(cdiv(C, 64), cdiv(R, rpb));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, x, R, C, ld, out, rpb);
+    AAS_LAUNCH_CHECK("aas_colsum_f32");
+    return 0;
+}
+
+extern "C" int aas_sqsum_f32(aasStream_t stream, const float* x, int64_t n, double* acc) {
+    AAS_CHECK(x && acc && n >= 0, "aas_sqsum_f32: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sqsum_kernel, dim3(grid_for(n) > 512 ? 512 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, acc);
+    AAS_LAUNCH_CHECK("aas_sqsum_f32");
+    return 0;
+}
+
+extern "C" int aas_l1_fwd(aasStream_t stream, const float* a, const float* b, int64_t n, double* loss_sum) {
+    AAS_CHECK(a && b && loss_sum && n >= 0, "aas_l1_fwd: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(l1_fwd_kernel, dim3(grid_for(n) > 512 ? 512 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, loss_sum);
+    AAS_LAUNCH_CHECK("aas_l1_fwd");
+    return 0;
+}
+
+extern "C" int aas_l1_bwd(aasStream_t stream, const float* a, const float* b, int64_t n, float scale, float* ga,
+                          float* gb, int accumulate) {
+    AAS_CHECK(a && b && n >= 0, "aas_l1_bwd: bad args");
+    if (n == 0 || (!ga && !gb)) return 0;
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, scale, ga, gb, accumulate);
+    AAS_LAUNCH_CHECK("aas_l1_bwd");
+    return 0;
+}
+
+extern "C" int aas_adam_f32(aasStream_t stream, float* p, const float* g, float* m, float* v, float* vmax, int64_t n,
+                            float lr, float beta1, float beta2, float eps, int step, int amsgrad, float grad_scale) {
+    AAS_CHECK(p && g && m && v && (vmax || !amsgrad) && n >= 0 && step >= 1, "aas_adam_f32: bad args");
+    if (n == 0) return 0;
+    double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    float step_size = (float)(lr / bc1);
+    float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n, beta1,
+                       beta2, eps, step_size, bc2_sqrt, amsgrad, grad_scale);
+    AAS_LAUNCH_CHECK("aas_adam_f32");
+    return 0;
+}
+
+extern "C" int aas_col2im_f32(aasStream_t stream, const float* dcol, float* dx, int N, int T, int T1, int F, int KW,
+                              int stride) {
+    AAS_CHECK(dcol && dx && N > 0 && T > 0 && T1 > 0 && F > 0 && KW > 0 && stride > 0, "aas_col2im_f32: bad args");
+    int64_t tot = (int64_t)N * T * F;
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(tot)), dim3(256), 0, (hipStream_t)stream, dcol, dx, N, T, T1, F, KW, stride);
+    AAS_LAUNCH_CHECK("aas_col2im_f32");
+    return 0;
+}

@@ -1,0 +1,258 @@
+// fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32): 128x128x16 block tile, 4 waves (2x2),
+// each wave 64x64 = 2x2 MFMA tiles; operands staged k-major in LDS (conflict-free ds_read_b32),
+// register-prefetch double buffering.  Exact fp32 (k-ordered fma chain).
+// Replaces the cuBLAS/cuDNN GEMMs below nn.LSTM/nn.GRU/nn.Conv1d/nn.Linear
+// (reference Speech_enhancement_by_AAS/model.py:73-74,94-95,216-217,289,297,317).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
+
+struct GemmP {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* addend;
+    int M, N, K;
+    int64_t lda, ldb, ldc, ldd;
+    int accumulate;
+    int batch;
+    int64_t sA, sB, sC;
+    int kdivA;
+    int64_t kouterA;
+    int kdivB;
+    int64_t kouterB;
+    int splitk;
+};
+
+__device__ __forceinline__ int64_t krow_addr(int r, int kdiv, int64_t kouter, int64_t ld) {
+    return kdiv > 0 ? (int64_t)(r / kdiv) * kouter + (int64_t)(r % kdiv) * ld : (int64_t)r * ld;
+}
+
+// k-contiguous operand: tile [128 rows][16 k]; two float4 per thread.
+template <bool VEC>
+__device__ __forceinline__ void load_kcontig(const float* __restrict__ base, int64_t ld, int row0, int rmax,
+                                             int k0, int kend, int tid, f32x4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int idx = tid + i * 256;
+        int row = idx >> 2, kq = idx & 3;
+        int gr = row0 + row, gk = k0 + kq * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < rmax) {
+            const float* p = base + (int64_t)gr * ld + gk;
+            if (VEC) {
+                if (gk < kend) v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+                if (gk + 0 < kend) v.x = p[0];
+                if (gk + 1 < kend) v.y = p[1];
+                if (gk + 2 < kend) v.z = p[2];
+                if (gk + 3 < kend) v.w = p[3];
+            }
+        }
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void store_kcontig(float (*S)[LDT], int tid, const f32x4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int idx = tid + i * 256;
+        int row = idx >> 2, kq = idx & 3;
+        S[kq * 4 + 0][row] = r[i].x;
+        S[kq * 4 + 1][row] = r[i].y;
+        S[kq * 4 + 2][row] = r[i].z;
+        S[kq * 4 + 3][row] = r[i].w;
+    }
+}
+// row-contiguous operand ([K, cols], cols contiguous): tile [16 k][128 cols]
+template <bool VEC>
+__device__ __forceinline__ void load_rcontig(const float* __restrict__ base, int64_t ld, int kdiv, int64_t kouter,
+                                             int c0, int cmax, int k0, int kend, int tid, f32x4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int idx = tid + i * 256;
+        int kr = idx >> 5, cq = idx & 31;
+        int gk = k0 + kr, gc = c0 + cq * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gk < kend) {
+            const float* p = base + krow_addr(gk, kdiv, kouter, ld) + gc;
+            if (VEC) {
+                if (gc < cmax) v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+                if (gc + 0 < cmax) v.x = p[0];
+                if (gc + 1 < cmax) v.y = p[1];
+                if (gc + 2 < cmax) v.z = p[2];
+                if (gc + 3 < cmax) v.w = p[3];
+            }
+        }
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void store_rcontig(float (*S)[LDT], int tid, const f32x4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int idx = tid + i * 256;
+        int kr = idx >> 5, cq = idx & 31;
+        *reinterpret_cast<f32x4*>(&S[kr][cq * 4]) = r[i];
+    }
+}
+
+template <bool A_KC, bool B_KC, bool VECA, bool VECB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int z = blockIdx.z;
+    const float* A = p.A;
+    const float* B = p.B;
+    float* C = p.C;
+    const float* addend = p.addend;
+    int kbeg = 0, kend = p.K;
+    if (p.splitk > 1) {
+        int ktiles = (p.K + BK - 1) / BK;
+        int per = (ktiles + p.splitk - 1) / p.splitk;
+        kbeg = z * per * BK;
+        kend = min(p.K, (z + 1) * per * BK);
+        if (kbeg >= kend) return;
+    } else if (p.batch > 1) {
+        A += (int64_t)z * p.sA;
+        B += (int64_t)z * p.sB;
+        C += (int64_t)z * p.sC;
+        if (addend) addend += (int64_t)z * p.sC;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+        if (A_KC) load_kcontig<VECA>(A, p.lda, m0, p.M, k0, kend, tid, ra);
+        else load_rcontig<VECA>(A, p.lda, p.kdivA, p.kouterA, m0, p.M, k0, kend, tid, ra);
+        if (B_KC) load_kcontig<VECB>(B, p.ldb, n0, p.N, k0, kend, tid, rb);
+        else load_rcontig<VECB>(B, p.ldb, p.kdivB, p.kouterB, n0, p.N, k0, kend, tid, rb);
+    };
+    auto sstore = [&](int buf) {
+        if (A_KC) store_kcontig(As[buf], tid, ra); else store_rcontig(As[buf], tid, ra);
+        if (B_KC) store_kcontig(Bs[buf], tid, rb); else store_rcontig(Bs[buf], tid, rb);
+    };
+    gload(kbeg);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = (k0 + BK) < kend;
+        if (more) gload(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a0 = As[buf][kk + lh][wm * 64 + l31];
+            float a1 = As[buf][kk + lh][wm * 64 + 32 + l31];
+            float b0 = Bs[buf][kk + lh][wn * 64 + l31];
+            float b1 = Bs[buf][kk + lh][wn * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool first = (p.splitk <= 1) || (z == 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            int n = n0 + wn * 64 + nt * 32 + l31;
+            if (n >= p.N) continue;
+            float bv = (p.bias && first) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[mt][nt][r] + bv;
+                if (addend && first) v += addend[(int64_t)m * p.ldd + n];
+                float* cp = C + (int64_t)m * p.ldc + n;
+                if (p.splitk > 1) atomicAdd(cp, v);
+                else if (p.accumulate) *cp += v;
+                else *cp = v;
+            }
+        }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <bool A_KC, bool B_KC>
+void launch(const GemmP& p, bool va, bool vb, dim3 grid, hipStream_t s) {
+    if (va && vb) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, true>), grid, dim3(256), 0, s, p);
+    else if (va) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, false>), grid, dim3(256), 0, s, p);
+    else if (vb) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, false>), grid, dim3(256), 0, s, p);
+}
+
+}  // namespace
+
+extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, const float* A, int64_t lda,
+                            const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                            const float* addend, int64_t ldd, int accumulate, int batch, int64_t strideA,
+                            int64_t strideB, int64_t strideC, int kdivA, int64_t kouterA, int kdivB,
+                            int64_t kouterB) {
+    AAS_CHECK(mode >= 0 && mode <= 2, "aas_gemm_f32: bad mode %d", mode);
+    AAS_CHECK(M >= 0 && N >= 0 && K >= 0 && batch >= 1, "aas_gemm_f32: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    AAS_CHECK(A && B && C, "aas_gemm_f32: null operand");
+    AAS_CHECK(!(batch > 1 && mode == AAS_GEMM_TN), "aas_gemm_f32: batch>1 unsupported for TN");
+    if (M == 0 || N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.addend = addend;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldd = ldd;
+    p.accumulate = accumulate; p.batch = batch; p.sA = strideA; p.sB = strideB; p.sC = strideC;
+    p.kdivA = kdivA; p.kouterA = kouterA; p.kdivB = kdivB; p.kouterB = kouterB;
+    p.splitk = 1;
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
+    // split-K (atomic epilogue) when the MxN grid cannot fill the 256 CUs and K is deep
+    int blocks = grid.x * grid.y;
+    if (batch == 1 && blocks < 192 && K >= 1024) {
+        int want = (256 + blocks - 1) / blocks;
+        int maxs = K / 256;
+        int sk = want < maxs ? want : maxs;
+        if (sk > 16) sk = 16;
+        if (sk > 1) {
+            p.splitk = sk;
+            grid.z = sk;
+            if (!accumulate) {
+                if (ldc == N) {
+                    AAS_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s));
+                } else {
+                    AAS_HIP(hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s));
+                }
+            }
+        }
+    }
+    bool va, vb;
+    if (mode == AAS_GEMM_TN) {
+        va = al16(A) && lda % 4 == 0 && M % 4 == 0 && (kdivA == 0 || kouterA % 4 == 0);
+        vb = al16(B) && ldb % 4 == 0 && N % 4 == 0 && (kdivB == 0 || kouterB % 4 == 0);
+        launch<false, false>(p, va, vb, grid, s);
+    } else {
+        va = al16(A) && lda % 4 == 0 && K % 4 == 0 && strideA % 4 == 0;
+        if (mode == AAS_GEMM_NT) {
+            vb = al16(B) && ldb % 4 == 0 && K % 4 == 0 && strideB % 4 == 0;
+            launch<true, true>(p, va, vb, grid, s);
+        } else {
+            vb = al16(B) && ldb % 4 == 0 && N % 4 == 0 && strideB % 4 == 0;
+            launch<true, false>(p, va, vb, grid, s);
+        }
+    }
+    AAS_LAUNCH_CHECK("aas_gemm_f32");
+    return 0;
+}

@@ -1,0 +1,60 @@
+"""Entry point with the reference's CLI (Speech_enhancement_by_AAS/main.py:8-89):
+    python -m aas_enhancement_amd.main --trainer AAS --DB_name librispeech --ASR_path pkg.pth.tar ...
+"""
+import json
+import os
+
+import torch
+
+from .config import get_config
+
+
+def main(config):
+    from .data_loader import DataLoader
+    if config.trainer == "minimize_DCE":
+        from .trainer_DCE import Trainer
+        paired = True
+    elif config.trainer == "acoustic_supervision":
+        from .trainer_AAS import Trainer  # AAS with w_adversarial = 0 (trainer_acoustic.py:120-142)
+        config.w_adversarial = 0
+        paired = False
+    elif config.trainer == "AAS":
+        from .trainer_AAS import Trainer
+        paired = False
+    elif config.trainer == "FSEGAN":
+        from .trainer_FSEGAN import Trainer
+        paired = True
+    else:
+        raise ValueError("unknown trainer %r" % config.trainer)
+    if config.gpu >= 0:
+        torch.cuda.manual_seed(config.random_seed)
+        torch.cuda.set_device(config.gpu)
+    sfx = "_paired" if paired else ""
+    if config.DB_name == "librispeech":
+        config.tr_ny_manifest = "data/libri_tr_ny%s.csv" % sfx
+        config.trsub_manifest = "data/libri_trsub_ny%s.csv" % sfx
+        config.val_manifest = "data/libri_val%s.csv" % sfx
+        config.tr_cl_manifest = "data/libri_tr_cl.csv"
+    elif config.DB_name == "chime":
+        config.tr_ny_manifest = "data/chime_%s_tr_ny%s.csv" % (config.simul_real, sfx)
+        config.trsub_manifest = "data/chime_%s_trsub_ny%s.csv" % (config.simul_real, sfx)
+        config.val_manifest = "data/chime_real_val%s.csv" % sfx
+        config.val2_manifest = "data/chime_simul_val%s.csv" % sfx  # (the reference has a typo here, main.py:50,55)
+        config.tr_cl_manifest = "data/chime_tr_org.csv"
+    with open(config.labels_path) as label_file:
+        labels = str("".join(json.load(label_file)))
+    data_loader = DataLoader(batch_size=config.batch_size, paired=paired, tr_cl_manifest=config.tr_cl_manifest,
+                             tr_ny_manifest=config.tr_ny_manifest, trsub_manifest=config.trsub_manifest,
+                             val_manifest=config.val_manifest, val2_manifest=config.val2_manifest, labels=labels)
+    os.makedirs("logs/" + str(config.expnum), exist_ok=True)
+    trainer = Trainer(config, data_loader)
+    torch.manual_seed(config.random_seed)
+    if config.mode == "train":
+        trainer.train()
+    else:
+        raise NotImplementedError("mode %r: the reference trainers define neither test() nor visualize()" % config.mode)
+
+
+if __name__ == "__main__":
+    config, unparsed = get_config()
+    main(config)

@@ -1,0 +1,455 @@
+"""Layer-level forward/backward ops of the AAS hot path, each a thin host wrapper over the C ABI of
+libaas_hip.so, plus the ``torch.autograd.Function`` shells that let the reference-compatible
+modules (model.py) participate in autograd.  All tensors are fp32 CUDA (HIP) tensors.
+
+Layouts used internally:  sequences [T,N,H] row-major ("TNH"); conv front-end
+channels-last [N,T,C]; the module boundary keeps the reference's [N,C,T].
+"""
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, require_cuda, stream
+
+NT, NN, TN = 0, 1, 2
+
+_scratch = {}
+
+
+def _sync_buf(dev):
+    """zero-initialised arrival-counter scratch for the persistent RNN kernels (per device+stream)."""
+    key = ("sync", dev, torch.cuda.current_stream().cuda_stream)
+    b = _scratch.get(key)
+    if b is None:
+        b = torch.zeros(int(lib().aas_rnn_sync_bytes()), dtype=torch.uint8, device=dev)
+        _scratch[key] = b
+    return b
+
+
+def rnn_timeout_flag(dev=None):
+    """True if any persistent RNN launch on this device hit its bounded-spin timeout."""
+    bad = False
+    for k, b in _scratch.items():
+        if k[0] == "sync":
+            bad = bad or bool(b.view(torch.int32)[1024].item())
+    return bad
+
+
+def _wsd(dev, n):
+    key = ("wsd", dev, torch.cuda.current_stream().cuda_stream)
+    b = _scratch.get(key)
+    if b is None or b.numel() < n:
+        b = torch.empty(max(n, 4096), dtype=torch.float64, device=dev)
+        _scratch[key] = b
+    return b
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------- GEMM
+def gemm(mode, M, N, K, A, lda, B, ldb, C, ldc, bias=None, addend=None, ldd=0, accumulate=False,
+         batch=1, sA=0, sB=0, sC=0, kdivA=0, kouterA=0, kdivB=0, kouterB=0, a_off=0, b_off=0, c_off=0):
+    """Raw GEMM on device pointers; *_off are element offsets into A/B/C."""
+    check(lib().aas_gemm_f32(stream(), mode, M, N, K, A.data_ptr() + 4 * a_off, lda, B.data_ptr() + 4 * b_off, ldb,
+                             C.data_ptr() + 4 * c_off, ldc, ptr(bias), ptr(addend), ldd, int(accumulate),
+                             batch, sA, sB, sC, kdivA, kouterA, kdivB, kouterB), "aas_gemm_f32")
+
+
+def linear_fwd(x2d, W, bias=None):
+    """y[R,N] = x[R,K] W[N,K]^T + b"""
+    R, K = x2d.shape
+    Nn = W.shape[0]
+    y = torch.empty((R, Nn), device=x2d.device, dtype=torch.float32)
+    gemm(NT, R, Nn, K, x2d, K, W, K, y, Nn, bias=bias)
+    return y
+
+
+def linear_bwd(x2d, W, dy, need_dx=True, need_db=False):
+    R, K = x2d.shape
+    Nn = W.shape[0]
+    dW = torch.empty((Nn, K), device=x2d.device, dtype=torch.float32)
+    gemm(TN, Nn, K, R, dy, Nn, x2d, K, dW, K)
+    dx = None
+    if need_dx:
+        dx = torch.empty((R, K), device=x2d.device, dtype=torch.float32)
+        gemm(NN, R, K, Nn, dy, Nn, W, K, dx, K)
+    db = colsum(dy, R, Nn) if need_db else None
+    return dx, dW, db
+
+
+def colsum(x2d, R, C):
+    out = torch.empty((C,), device=x2d.device, dtype=torch.float32)
+    check(lib().aas_colsum_f32(stream(), ptr(x2d), R, C, C, ptr(out), 0), "aas_colsum_f32")
+    return out
+
+
+def transpose(inp, out, B, R, C, isb, isr, osb, osc):
+    check(lib().aas_transpose_f32(stream(), ptr(inp), ptr(out), B, R, C, isb, isr, osb, osc), "aas_transpose_f32")
+    return out
+
+
+def add3(a, b, c=None):
+    out = torch.empty_like(a)
+    check(lib().aas_add3_f32(stream(), ptr(out), ptr(a), ptr(b), ptr(c), a.numel()), "aas_add3_f32")
+    return out
+
+
+def axpby_(y, x, alpha, beta):
+    check(lib().aas_axpby_f32(stream(), ptr(y), ptr(x), float(alpha), float(beta), y.numel()), "aas_axpby_f32")
+    return y
+
+
+# ---- layout helpers (each is its own inverse pair) -------------------------------------------
+def nct_to_tnc(x):  # [N,C,T] -> [T,N,C]
+    N, C, T = x.shape
+    out = torch.empty((T, N, C), device=x.device, dtype=torch.float32)
+    return transpose(x, out, N, C, T, C * T, T, C, N * C)
+
+
+def tnc_to_nct(x):  # [T,N,C] -> [N,C,T]
+    T, N, C = x.shape
+    out = torch.empty((N, C, T), device=x.device, dtype=torch.float32)
+    return transpose(x, out, N, T, C, C, N * C, C * T, T)
+
+
+def nct_to_ntc(x):  # [N,C,T] -> [N,T,C]
+    N, C, T = x.shape
+    out = torch.empty((N, T, C), device=x.device, dtype=torch.float32)
+    return transpose(x, out, N, C, T, C * T, T, T * C, C)
+
+
+def ntc_to_nct(x):  # [N,T,C] -> [N,C,T]
+    N, T, C = x.shape
+    out = torch.empty((N, C, T), device=x.device, dtype=torch.float32)
+    return transpose(x, out, N, T, C, T * C, C, C * T, T)
+
+
+def swap01(x):  # [A,B,C] -> [B,A,C]
+    A, B, C = x.shape
+    out = torch.empty((B, A, C), device=x.device, dtype=torch.float32)
+    check(lib().aas_swap01_f32(stream(), ptr(x), ptr(out), A, B, C), "aas_swap01_f32")
+    return out
+
+
+class _Layout(torch.autograd.Function):
+    """Differentiable layout change; backward applies the inverse permutation."""
+    FWD = {"nct_tnc": nct_to_tnc, "tnc_nct": tnc_to_nct, "nct_ntc": nct_to_ntc, "ntc_nct": ntc_to_nct, "swap01": swap01}
+    INV = {"nct_tnc": "tnc_nct", "tnc_nct": "nct_tnc", "nct_ntc": "ntc_nct", "ntc_nct": "nct_ntc", "swap01": "swap01"}
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        require_cuda(x)
+        ctx.kind = kind
+        return _Layout.FWD[kind](_c(x))
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Layout.FWD[_Layout.INV[ctx.kind]](_c(g)), None
+
+
+def layout(x, kind):
+    return _Layout.apply(x, kind)
+
+
+# --------------------------------------------------------------------------------------- linear
+class _LinearRows(torch.autograd.Function):
+    """y[..., N] = x[..., K] W[N,K]^T (+ b) on the flattened leading dims."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        require_cuda(x, W)
+        x = _c(x)
+        W2 = _c(W).view(W.shape[0], -1)
+        x2 = x.view(-1, x.shape[-1])
+        y = linear_fwd(x2, W2, _c(b) if b is not None else None)
+        ctx.save_for_backward(x2, W2)
+        ctx.wshape = W.shape
+        ctx.has_b = b is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], W2.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, W2 = ctx.saved_tensors
+        gy2 = _c(gy).view(-1, W2.shape[0])
+        dx, dW, db = linear_bwd(x2, W2, gy2, need_dx=ctx.needs_input_grad[0], need_db=ctx.has_b)
+        return (dx.view(ctx.xshape) if dx is not None else None), dW.view(ctx.wshape), db
+
+
+def linear_rows(x, W, b=None):
+    return _LinearRows.apply(x, W, b)
+
+
+# --------------------------------------------------------------------------------------- RNN layers
+def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
+    """x [T,N,I] -> (pre, hout[2,T,N,H], gact, cst)."""
+    T, N, I = x.shape
+    G = 4 if kind == "lstm" else 3
+    H = w_hh.shape[1]
+    dev = x.device
+    pre = torch.empty((T, N, 2, G * H), device=dev, dtype=torch.float32)
+    x2 = x.view(T * N, I)
+    gemm(NT, T * N, G * H, I, x2, I, w_ih, I, pre, 2 * G * H)
+    gemm(NT, T * N, G * H, I, x2, I, w_ih_r, I, pre, 2 * G * H, c_off=G * H)
+    hout = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
+    gact = torch.empty((2, T, N, 4 * H), device=dev, dtype=torch.float32)
+    sync = _sync_buf(dev)
+    if kind == "lstm":
+        cst = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
+        check(lib().aas_lstm_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(cst),
+                                 ptr(sync)), "aas_lstm_fwd")
+    else:
+        cst = None
+        check(lib().aas_gru_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync)),
+              "aas_gru_fwd")
+    return hout, gact, cst
+
+
+def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residual, need_dx=True):
+    T, N, I = x.shape
+    G = 4 if kind == "lstm" else 3
+    H = w_hh.shape[1]
+    GH = G * H
+    dev = x.device
+    dy = _c(dy)
+    sync = _sync_buf(dev)
+    dgx = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
+    if kind == "lstm":
+        check(lib().aas_lstm_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), ptr(dgx),
+                                 ptr(sync)), "aas_lstm_bwd")
+        dgh = dgx
+    else:
+        dgh = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
+        check(lib().aas_gru_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(dgx),
+                                ptr(dgh), ptr(sync)), "aas_gru_bwd")
+    x2 = x.view(T * N, I)
+    R = T * N
+    dW_ih = torch.empty((GH, I), device=dev, dtype=torch.float32)
+    dW_ih_r = torch.empty((GH, I), device=dev, dtype=torch.float32)
+    gemm(TN, GH, I, R, dgx, 2 * GH, x2, I, dW_ih, I)
+    gemm(TN, GH, I, R, dgx, 2 * GH, x2, I, dW_ih_r, I, a_off=GH)
+    dW_hh = torch.empty((GH, H), device=dev, dtype=torch.float32)
+    dW_hh_r = torch.empty((GH, H), device=dev, dtype=torch.float32)
+    if T > 1:
+        Rm = (T - 1) * N
+        # forward direction: sum_{t>=1} dg[t,:,0,:]^T h_f[t-1]
+        gemm(TN, GH, H, Rm, dgh, 2 * GH, hout, H, dW_hh, H, a_off=N * 2 * GH)
+        # reverse direction: sum_{t<=T-2} dg[t,:,1,:]^T h_r[t+1]
+        gemm(TN, GH, H, Rm, dgh, 2 * GH, hout, H, dW_hh_r, H, a_off=GH, b_off=T * N * H + N * H)
+    else:
+        dW_hh.zero_()
+        dW_hh_r.zero_()
+    dx = None
+    if need_dx:
+        dx = torch.empty((T, N, I), device=dev, dtype=torch.float32)
+        gemm(NN, R, I, GH, dgx, 2 * GH, w_ih, I, dx, I, addend=dy if residual else None, ldd=I)
+        gemm(NN, R, I, GH, dgx, 2 * GH, w_ih_r, I, dx, I, accumulate=True, a_off=GH)
+    return dx, dW_ih, dW_hh, dW_ih_r, dW_hh_r
+
+
+class _BiRNNLayer(torch.autograd.Function):
+    """y = h_fwd + h_rev (+ x if residual)  for a bias-free bidirectional LSTM/GRU layer
+    (reference model.py:80-86,101-105 and the residual adds at :223-226)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual):
+        require_cuda(x, w_ih, w_hh)
+        x = _c(x)
+        w_ih, w_hh, w_ih_r, w_hh_r = _c(w_ih), _c(w_hh), _c(w_ih_r), _c(w_hh_r)
+        hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r)
+        y = add3(hout[0], hout[1], x if residual else None)
+        ctx.kind, ctx.residual = kind, residual
+        ctx.save_for_backward(x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst if cst is not None else hout)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst = ctx.saved_tensors
+        dx, a, b, c, d = _birnn_bwd(ctx.kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, ctx.residual,
+                                    need_dx=ctx.needs_input_grad[0])
+        return dx, a, b, c, d, None, None
+
+
+def birnn_layer(x, w_ih, w_hh, w_ih_r, w_hh_r, kind="lstm", residual=False):
+    return _BiRNNLayer.apply(x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual)
+
+
+# --------------------------------------------------------------------------------------- batch norm
+class _BatchNormRows(torch.autograd.Function):
+    """Train-mode BatchNorm over the rows of x[..., C] (+ fused LeakyReLU(slope)); updates running stats."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope):
+        require_cuda(x, gamma)
+        x = _c(x)
+        C = x.shape[-1]
+        R = x.numel() // C
+        y = torch.empty_like(x)
+        stats = torch.empty((4, C), device=x.device, dtype=torch.float32)
+        wsd = _wsd(x.device, 2 * C)
+        check(lib().aas_bn_fwd(stream(), ptr(x), ptr(y), R, C, ptr(gamma), ptr(beta), float(eps), float(slope),
+                               ptr(stats), ptr(running_mean), ptr(running_var), float(momentum), ptr(wsd)), "aas_bn_fwd")
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        dy = _c(dy)
+        C = x.shape[-1]
+        R = x.numel() // C
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        wsd = _wsd(x.device, 2 * C)
+        check(lib().aas_bn_bwd(stream(), ptr(x), ptr(dy), ptr(dx), R, C, ptr(gamma), ptr(beta), float(ctx.slope),
+                               ptr(stats), ptr(dgamma), ptr(dbeta), 0, ptr(wsd)), "aas_bn_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batchnorm_rows(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, slope=1.0):
+    return _BatchNormRows.apply(x, gamma, beta, running_mean, running_var, eps, momentum, slope)
+
+
+# --------------------------------------------------------------------------------------- conv1d (k>1)
+def _w_to_kf(W):  # [M,F,KW] -> [M,KW*F]
+    M, F, KW = W.shape
+    out = torch.empty((M, KW * F), device=W.device, dtype=torch.float32)
+    return transpose(W, out, M, F, KW, F * KW, KW, KW * F, F)
+
+
+def _kf_to_w(W2, F, KW):  # [M,KW*F] -> [M,F,KW]
+    M = W2.shape[0]
+    out = torch.empty((M, F, KW), device=W2.device, dtype=torch.float32)
+    return transpose(W2, out, M, KW, F, KW * F, F, F * KW, KW)
+
+
+class _Conv1dCL(torch.autograd.Function):
+    """Temporal conv (no padding) on channels-last x[N,T,F] with PyTorch-layout weight [M,F,KW]:
+    implicit-im2col batched GEMM (a row of the im2col matrix is KW consecutive frames of x)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, stride):
+        require_cuda(x, W)
+        x = _c(x)
+        N, T, F = x.shape
+        M, _, KW = W.shape
+        T1 = (T - KW) // stride + 1
+        if T1 < 1:
+            raise RuntimeError("conv1d: input of %d frames is shorter than the kernel (%d)" % (T, KW))
+        W2 = _w_to_kf(_c(W))
+        y = torch.empty((N, T1, M), device=x.device, dtype=torch.float32)
+        gemm(NT, T1, M, KW * F, x, stride * F, W2, KW * F, y, M, bias=_c(b) if b is not None else None,
+             batch=N, sA=T * F, sB=0, sC=T1 * M)
+        ctx.save_for_backward(x, W2)
+        ctx.dims = (N, T, F, M, KW, T1, stride)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W2 = ctx.saved_tensors
+        N, T, F, M, KW, T1, stride = ctx.dims
+        dy = _c(dy)
+        dW2 = torch.empty((M, KW * F), device=x.device, dtype=torch.float32)
+        gemm(TN, M, KW * F, N * T1, dy, M, x, stride * F, dW2, KW * F, kdivB=T1, kouterB=T * F)
+        dW = _kf_to_w(dW2, F, KW)
+        db = colsum(dy.view(N * T1, M), N * T1, M) if ctx.has_b else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcol = torch.empty((N * T1, KW * F), device=x.device, dtype=torch.float32)
+            gemm(NN, N * T1, KW * F, M, dy, M, W2, KW * F, dcol, KW * F)
+            dx = torch.empty((N, T, F), device=x.device, dtype=torch.float32)
+            check(lib().aas_col2im_f32(stream(), ptr(dcol), ptr(dx), N, T, T1, F, KW, stride), "aas_col2im_f32")
+        return dx, dW, db, None
+
+
+def conv1d_cl(x, W, b, stride):
+    return _Conv1dCL.apply(x, W, b, stride)
+
+
+# --------------------------------------------------------------------------------------- losses
+class _L1Sum(torch.autograd.Function):
+    """sum |a - b| over all elements (fp64 device accumulation), differentiable wrt both."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        require_cuda(a, b)
+        a, b = _c(a), _c(b)
+        acc = torch.zeros((1,), device=a.device, dtype=torch.float64)
+        check(lib().aas_l1_fwd(stream(), ptr(a), ptr(b), a.numel(), ptr(acc)), "aas_l1_fwd")
+        ctx.save_for_backward(a, b)
+        return acc.to(torch.float32).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        # the upstream scalar lives on the device; read it once (it is the loss weight / nElement)
+        scale = float(g)
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        check(lib().aas_l1_bwd(stream(), ptr(a), ptr(b), a.numel(), scale, ptr(ga), ptr(gb), 0), "aas_l1_bwd")
+        return ga, gb
+
+
+def l1_sum(a, b):
+    return _L1Sum.apply(a, b)
+
+
+class _CTC(torch.autograd.Function):
+    """sum_n -log p(l_n | softmax(acts[:len_n, n])); gradient wrt pre-softmax acts (warp-ctc semantics)."""
+
+    @staticmethod
+    def forward(ctx, acts, labels, act_lens, label_lens, blank):
+        require_cuda(acts)
+        acts = _c(acts)
+        T, N, C = acts.shape
+        dev = acts.device
+        lab_lens_h = label_lens.to("cpu", torch.int32)
+        max_l = int(lab_lens_h.max().item()) if N > 0 else 0
+        offs_h = torch.zeros(N, dtype=torch.int32)
+        if N > 1:
+            offs_h[1:] = torch.cumsum(lab_lens_h, 0)[:-1].to(torch.int32)
+        meta = torch.cat([labels.to("cpu", torch.int32).view(-1), offs_h, lab_lens_h,
+                          act_lens.to("cpu", torch.int32)]).to(dev, non_blocking=True)
+        nl = labels.numel()
+        d_lab, d_off, d_ll, d_al = meta[:nl], meta[nl:nl + N], meta[nl + N:nl + 2 * N], meta[nl + 2 * N:]
+        smax = 2 * max_l + 1
+        ws = torch.empty((N * (T * smax + T),), device=dev, dtype=torch.float32)
+        costs = torch.empty((N,), device=dev, dtype=torch.float32)
+        grads = torch.empty_like(acts)
+        lp = ptr(d_lab) if nl > 0 else ptr(meta)
+        check(lib().aas_ctc_loss_async(stream(), ptr(acts), ptr(grads), lp, ptr(d_off), ptr(d_ll), ptr(d_al), C, N, T,
+                                       max_l, ptr(costs), ptr(ws), int(blank), 1.0), "aas_ctc_loss_async")
+        ctx.save_for_backward(grads)
+        ctx.costs = costs
+        total = torch.zeros((1,), device=dev, dtype=torch.float64)
+        # reduce the N costs with the colsum kernel (R = N rows, C = 1 column)
+        out = torch.empty((1,), device=dev, dtype=torch.float32)
+        check(lib().aas_colsum_f32(stream(), ptr(costs), N, 1, 1, ptr(out), 0), "aas_colsum_f32")
+        del total
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (grads,) = ctx.saved_tensors
+        scale = float(g.reshape(-1)[0])
+        if scale != 1.0:
+            axpby_(grads, grads, scale, 0.0)
+        return grads, None, None, None, None
+
+
+def ctc_sum(acts, labels, act_lens, label_lens, blank=0):
+    return _CTC.apply(acts, labels, act_lens, label_lens, blank)
+
+
+# --------------------------------------------------------------------------------------- reductions / optimiser
+def sqsum_into(acc, t):
+    check(lib().aas_sqsum_f32(stream(), ptr(t), t.numel(), ptr(acc)), "aas_sqsum_f32")
+
+
+def adam_step(p, g, m, v, vmax, lr, beta1, beta2, eps, step, amsgrad=True, grad_scale=1.0):
+    check(lib().aas_adam_f32(stream(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), float(lr), float(beta1),
+                             float(beta2), float(eps), int(step), int(amsgrad), float(grad_scale)), "aas_adam_f32")

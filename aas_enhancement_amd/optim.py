@@ -1,0 +1,32 @@
+"""Adam / Adam-amsgrad with the element-wise update fused into one HIP kernel per parameter tensor.
+
+Replaces ``torch.optim.Adam(..., amsgrad=True)`` at Speech_enhancement_by_AAS/trainer_AAS.py:127-129
+(and plain Adam at AM_training/train.py:246-247).  torch 2.x update rule.
+"""
+import torch
+
+from . import ops
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, amsgrad=False):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, amsgrad=amsgrad))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                    if group["amsgrad"]:
+                        st["max_exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                ops.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], st.get("max_exp_avg_sq"), group["lr"], b1, b2,
+                              group["eps"], st["step"], group["amsgrad"], grad_scale)

@@ -1,0 +1,283 @@
+"""AAS trainer on the MI355X HIP path - same API as the reference's
+Speech_enhancement_by_AAS/trainer_AAS.py (Trainer.__init__/build_model/train/zero_grad_all/
+get_gradient_norm/greedy_decoding_and_AAS; hot loop :131-194).
+
+``train_step`` is the loop body of ``train()`` (:131-194) factored out so that bench.py and the
+parity tests can drive exactly the code ``main.py --trainer AAS`` runs.
+
+Schedules (results identical, SURVEY.md 3.1 / 8a "verified algebraic identities"):
+  * ``schedule='as_executed'``: the reference's literal order - D forward x3, E backward x2.
+  * ``schedule='fused'`` (default): D(enhanced) is evaluated once; the D-step parameter gradients
+    are (-kt) x the G-step's D-parameter gradients that the reference computes and then discards at
+    :152, so no second D forward/backward is run.
+"""
+import os
+import random
+from glob import glob
+from shutil import copyfile
+
+import torch
+
+from . import ops
+from .ctc import CTCLoss
+from .decoder import GreedyDecoder
+from .model import DeepSpeech, L1Loss_mask, stackedBRNN, supported_rnns
+from .optim import Adam
+from .utils import AverageMeter, _get_variable_nograd, _get_variable_volatile, attach_n_valid
+
+
+class Trainer(object):
+    def __init__(self, config, data_loader=None, models=None):
+        self.config = config
+        self.data_loader = data_loader
+        self.lr, self.beta1, self.beta2 = config.lr, config.beta1, config.beta2
+        self.optimizer = getattr(config, "optimizer", "adam")
+        self.batch_size = config.batch_size
+        self.schedule = getattr(config, "schedule", "fused")
+        self.diffLoss = L1Loss_mask()
+        self.valmin_iter = 0
+        self.model_dir = "logs/" + str(config.expnum)
+        self.savename_G = self.savename_D = self.savename_ASR = ""
+        self.kt = 0  # BEGAN proportional controller state (:47)
+        self.lb = config.lambda_k
+        self.gamma = config.gamma
+        self.conv_measure = 0
+        for m in ("ctc_tr", "ctc_tr_local", "ctc_val", "adv_ny_tr", "adv_ny_val", "wer_tr", "wer_val", "cer_tr", "cer_val"):
+            setattr(self, m, AverageMeter())
+        self.CTCLoss = CTCLoss()
+        self.decoder = GreedyDecoder(data_loader.labels) if data_loader is not None and getattr(data_loader, "labels", None) else None
+        if models is not None:
+            self.G, self.D, self.ASR = models
+        else:
+            self.build_model()
+        self.G.loss_stop = 100000
+        if config.gpu >= 0:
+            self.G.cuda(); self.D.cuda(); self.ASR.cuda()
+        if len(getattr(config, "load_path", "")) > 0:
+            self.load_model()
+        self.logFile = None
+        if config.mode == "train" and getattr(config, "write_log", True):
+            os.makedirs(self.model_dir, exist_ok=True)
+            self.logFile = open(self.model_dir + "/log.txt", "w")
+        self._opts = None
+        self._gn_acc = None
+
+    def zero_grad_all(self):
+        self.G.zero_grad(); self.D.zero_grad(); self.ASR.zero_grad()
+
+    def build_model(self):
+        print("initialize enhancement & discriminator model")
+        c = self.config
+        self.G = stackedBRNN(I=c.nFeat, H=c.rnn_size, L=c.rnn_layers, rnn_type=supported_rnns[c.rnn_type])
+        self.D = stackedBRNN(I=c.nFeat, H=c.rnn_size, L=c.rnn_layers, rnn_type=supported_rnns[c.rnn_type])
+        print("load pre-trained ASR model")
+        package_ASR = torch.load(c.ASR_path, map_location=lambda storage, loc: storage)
+        self.ASR = DeepSpeech.load_model_package(package_ASR)
+
+    def load_model(self):
+        print("[*] Load models from {}...".format(self.config.load_path))
+        postfix = "_valmin"
+        paths = sorted(glob(os.path.join(self.config.load_path, "G{}*.pth".format(postfix))))
+        if len(paths) == 0:
+            raise AssertionError("checkpoint not avilable")
+        idxes = [int(os.path.basename(p.split(".")[0].split("_")[-1])) for p in paths]
+        if self.config.start_iter <= 0:
+            self.config.start_iter = max(idxes)
+        self.G.load_state_dict(torch.load("{}/G{}_{}.pth".format(self.config.load_path, postfix, self.config.start_iter),
+                                          map_location=lambda storage, loc: storage))
+        print("[*] Model loaded")
+
+    # ------------------------------------------------------------------------------------------
+    def make_optimizers(self):
+        c = self.config
+        mk = lambda m: Adam(m.parameters(), lr=c.lr, betas=(self.beta1, self.beta2), amsgrad=True)
+        self._opts = (mk(self.G), mk(self.ASR), mk(self.D))
+        return self._opts
+
+    def get_gradient_norm(self, model):
+        """sqrt(sum_p sum grad^2) (:353-361) - one fp64 device accumulator, one kernel per tensor."""
+        dev = next(model.parameters()).device
+        acc = torch.zeros((1,), device=dev, dtype=torch.float64)
+        for p in model.parameters():
+            if p.grad is not None:
+                ops.sqsum_into(acc, p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+        return acc.sqrt().to(torch.float32)
+
+    def _prep(self, data_list):
+        inputs, targets, pct, target_sizes, mask = data_list[0], data_list[1], data_list[2], data_list[3], data_list[4]
+        attach_n_valid(mask) if not mask.is_cuda else None
+        return (_get_variable_nograd(inputs), targets, pct, target_sizes, _get_variable_nograd(mask))
+
+    def train_step(self, data_list, data_list_cl, iter, log_norms=True):
+        """One iteration of :131-194.  Returns the host scalars the reference logs."""
+        if self._opts is None:
+            self.make_optimizers()
+        optimizer_g, optimizer_asr, optimizer_d = self._opts
+        c = self.config
+        self.zero_grad_all()
+        inputs, targets, input_percentages, target_sizes, mask = self._prep(data_list)
+        N = inputs.size(0)
+        enhanced = self.G(inputs)
+        g_adv = g_ctc_adv = None
+        if self.schedule == "as_executed":
+            enhanced_D = enhanced.detach()
+            ae_ny_G = self.D(enhanced)
+            l_adv_ny_G, _ = self.diffLoss(ae_ny_G, enhanced, mask)
+            l_adv_ny_G = l_adv_ny_G * c.w_adversarial
+            l_adv_ny_G.backward(retain_graph=True)
+            if log_norms:
+                g_adv = self.get_gradient_norm(self.G)
+            self.D.zero_grad()
+            ae_ny_D = self.D(enhanced_D)
+            l_adv_ny_D, _ = self.diffLoss(ae_ny_D, enhanced_D, mask)
+            l_adv_ny_D = l_adv_ny_D * (-self.kt) * c.w_adversarial
+            l_adv_ny_D.backward()
+            del l_adv_ny_D
+        else:
+            # E is back-propagated ONCE: both losses are taken on a detached leaf of `enhanced`, their
+            # gradients wrt it add up (linear), then a single backward runs through E.  On logging
+            # iterations g_adv needs E's adversarial-only gradients, so E is back-propagated per loss.
+            leaf = enhanced.detach().requires_grad_(True)
+            ae_ny_G = self.D(leaf)
+            l_adv_ny_G, _ = self.diffLoss(ae_ny_G, leaf, mask)
+            l_adv_ny_G = l_adv_ny_G * c.w_adversarial
+            l_adv_ny_G.backward()
+            if log_norms:
+                enhanced.backward(leaf.grad, retain_graph=True)
+                g_adv = self.get_gradient_norm(self.G)
+                leaf.grad = None
+            # D-step == (-kt) x the D-parameter gradients of the G-step (identical forward values)
+            for p in self.D.parameters():
+                if p.grad is not None:
+                    ops.axpby_(p.grad, p.grad, -float(self.kt), 0.0)
+        # CTC loss (:163-172)
+        a_in = enhanced if self.schedule == "as_executed" else leaf
+        prob = self.ASR(a_in)
+        prob = prob.transpose(0, 1)
+        T = prob.size(0)
+        sizes = input_percentages.clone().mul_(int(T)).int()
+        l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes) / N
+        l_CTC.backward()
+        if self.schedule != "as_executed":
+            enhanced.backward(leaf.grad)
+        if log_norms:
+            g_ctc_adv = self.get_gradient_norm(self.G)
+        # clean data (:174-182)
+        cl_inputs, cl_mask = data_list_cl[0], data_list_cl[4]
+        attach_n_valid(cl_mask) if not cl_mask.is_cuda else None
+        cl_inputs, cl_mask = _get_variable_nograd(cl_inputs), _get_variable_nograd(cl_mask)
+        ae_cl = self.D(cl_inputs)
+        l_adv_cl, _ = self.diffLoss(ae_cl, cl_inputs, cl_mask)
+        l_adv_cl = c.w_adversarial * l_adv_cl
+        l_adv_cl.backward()
+        # update (:184-188)
+        optimizer_g.step()
+        optimizer_d.step()
+        if iter > c.allow_ASR_update_iter:
+            optimizer_asr.step()
+        # one packed device->host read for the three scalars the controller / log need
+        packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), l_CTC.detach().reshape(())]).tolist()
+        l_adv_ny_G_data, l_adv_cl_data, l_ctc_data = packed
+        self.ctc_tr_local.update(l_ctc_data, N)
+        # Proportional Control Theory (:190-194)
+        g_d_balance = self.gamma * l_adv_cl_data - l_adv_ny_G_data
+        self.kt += self.lb * g_d_balance
+        self.kt = max(min(1, self.kt), 0)
+        conv_measure = l_adv_cl_data + abs(g_d_balance)
+        return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, kt=self.kt,
+                    conv_measure=conv_measure, g_adv=g_adv, g_ctc_adv=g_ctc_adv, enhanced=enhanced, prob=prob)
+
+    def train(self):
+        from tqdm import trange
+        c = self.config
+        self.make_optimizers()
+        for iter in trange(c.start_iter, c.max_iter):
+            logging = (iter + 1) % c.log_iter == 0
+            data_list = self.data_loader.next(cl_ny="ny", type="train")
+            data_list_cl = self.data_loader.next(cl_ny="cl", type="train")
+            r = self.train_step(data_list, data_list_cl, iter, log_norms=logging)
+            if logging:
+                lines = [
+                    "[{}/{}] (train) CTC: {:.7f}, ADV_cl: {:.7f}, ADV_ny: {:.7f}".format(iter, c.max_iter, self.ctc_tr_local.avg, r["l_adv_cl"], r["l_adv_ny_G"]),
+                    "[{}/{}] (train) conv_measure: {:.4f}, kt: {:.4f} ".format(iter, c.max_iter, r["conv_measure"], self.kt),
+                    "[{}/{}] (train) gradient norm, adv: {:.4f}, adv + ctc : {:.4f}".format(iter, c.max_iter, float(r["g_adv"]), float(r["g_ctc_adv"])),
+                ]
+                for s in lines:
+                    print(s)
+                    if self.logFile:
+                        self.logFile.write(s + "\n")
+                if self.logFile:
+                    self.logFile.flush()
+                self.ctc_tr_local.reset()
+            if (iter + 1) % c.save_iter == 0:
+                self.validate_and_checkpoint(iter)
+
+    # ---- validation + checkpoint lifecycle (:215-297) -----------------------------------------
+    def validate_and_checkpoint(self, iter):
+        c = self.config
+        self.G.eval()
+        for name, dl, ctc_m, adv_m, wer_m, cer_m in (("training subset", "trsub", self.ctc_tr, self.adv_ny_tr, self.wer_tr, self.cer_tr),
+                                                     ("validation", "val", self.ctc_val, self.adv_ny_val, self.wer_val, self.cer_val)):
+            for m in (ctc_m, adv_m, wer_m, cer_m):
+                m.reset()
+            for _ in range(self.data_loader.num_batches(dl)):
+                d = self.data_loader.next(cl_ny="ny", type=dl)
+                with torch.no_grad():
+                    ctc, adv_ny, nElement, wer, cer, nWord, nChar = self.greedy_decoding_and_AAS(d[0], d[1], d[2], d[3], d[4])
+                ctc_m.update(float(ctc), d[0].size(0)); adv_m.update(float(adv_ny), nElement)
+                wer_m.update(wer, nWord); cer_m.update(cer, nChar)
+            s = "[{}/{}] ({}) CTC: {:.7f}, WER: {:.7f}, CER: {:.7f}".format(iter, c.max_iter, name, ctc_m.avg, wer_m.avg * 100, cer_m.avg * 100)
+            print(s)
+            if self.logFile:
+                self.logFile.write(s + "\n"); self.logFile.flush()
+        self.G.train()
+        os.makedirs(self.model_dir, exist_ok=True)
+        if len(self.savename_G) > 0 and os.path.exists(self.savename_G):
+            os.remove(self.savename_G)
+        self.savename_G = "{}/G_{}.pth".format(self.model_dir, iter)
+        torch.save(self.G.state_dict(), self.savename_G)
+        if len(self.savename_ASR) > 0 and os.path.exists(self.savename_ASR):
+            os.remove(self.savename_ASR)
+        self.savename_ASR = "{}/ASR_{}.pth".format(self.model_dir, iter)
+        torch.save(self.ASR.state_dict(), self.savename_ASR)
+        if self.G.loss_stop > self.wer_val.avg:
+            self.G.loss_stop = self.wer_val.avg
+            for tag, cur in (("G", self.savename_G), ("ASR", self.savename_ASR)):
+                prev = "{}/{}_valmin_{}.pth".format(self.model_dir, tag, self.valmin_iter)
+                if os.path.exists(prev):
+                    os.remove(prev)
+                print("save model for this checkpoint")
+                copyfile(cur, "{}/{}_valmin_{}.pth".format(self.model_dir, tag, iter))
+            self.valmin_iter = iter
+
+    def greedy_decoding_and_AAS(self, inputs, targets, input_percentages, target_sizes, mask, transcript_prob=0.001):
+        """:301-351 (keeps the reference's ``cer = ce/total_word`` quirk at :338)."""
+        inputs = _get_variable_volatile(inputs)
+        attach_n_valid(mask) if not mask.is_cuda else None
+        mask = _get_variable_volatile(mask)
+        N = inputs.size(0)
+        split_targets, offset = [], 0
+        for size in target_sizes:
+            split_targets.append(targets[offset:offset + int(size)])
+            offset += int(size)
+        enhanced = self.G(inputs)
+        prob = self.ASR(enhanced).transpose(0, 1)
+        T = prob.size(0)
+        sizes = input_percentages.clone().mul_(int(T)).int()
+        decoded_output, _ = self.decoder.decode(prob.detach(), sizes)
+        target_strings = self.decoder.convert_to_strings(split_targets)
+        we = ce = total_word = total_char = 0
+        for x in range(len(target_strings)):
+            decoding, reference = decoded_output[x][0], target_strings[x][0]
+            nChar, nWord = len(reference), len(reference.split())
+            we_i, ce_i = self.decoder.wer(decoding, reference), self.decoder.cer(decoding, reference)
+            we += we_i; ce += ce_i; total_word += nWord; total_char += nChar
+            if random.uniform(0, 1) < transcript_prob:
+                print("reference = " + reference); print("decoding = " + decoding)
+        wer = we / max(total_word, 1)
+        cer = ce / max(total_word, 1)
+        ae_ny = self.D(enhanced)
+        l_adv_ny, nElement = self.diffLoss(ae_ny, enhanced, mask)
+        l_adv_ny = l_adv_ny * self.config.w_adversarial
+        l_CTC = self.config.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes) / N
+        return l_CTC, l_adv_ny, nElement, wer, cer, total_word, total_char

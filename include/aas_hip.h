@@ -1,0 +1,161 @@
+/*
+ * aas_hip.h - C ABI of libaas_hip.so: the MI355X (gfx950) hot path of the AAS training step.
+ *
+ * The reference (lifelongeek/AAS_enhancement) is pure Python on PyTorch; the native code its
+ * hot path executes lives in third-party libraries reached through PyTorch / warp-ctc bindings.
+ * Each entry point below names the reference call site (file:line under /root/reference) whose
+ * native implementation it replaces.  Plain pointers and sizes only: no torch types.  All
+ * pointers are DEVICE pointers unless the parameter name starts with `h_`.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  Every function enqueues work on `stream`
+ * and returns immediately (exceptions: the two functions documented as synchronous).
+ *
+ * Return value: 0 on success, non-zero on error; aas_last_error() returns a message for the
+ * calling thread's last failure (shape / alignment / capacity / HIP launch errors).
+ * Buffers are owned by the caller for the duration of the enqueued work.
+ */
+#ifndef AAS_HIP_H
+#define AAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* aasStream_t;
+
+int aas_version(void);
+const char* aas_last_error(void);
+/* number of CUs of the current device (persistent recurrent kernels size their grids from it) */
+int aas_device_cus(void);
+
+/* ---------------------------------------------------------------- dense linear algebra --------
+ * fp32 MFMA GEMM  C = op(A) op(B) [+ bias broadcast over rows] [+ addend] [+ C if accumulate].
+ * Replaces the cuDNN/cuBLAS GEMMs under nn.LSTM / nn.GRU input projections (model.py:73-74,94-95),
+ * nn.Conv1d k=1 (model.py:216-217), nn.Conv1d k=11 as implicit-im2col GEMM (model.py:289,297),
+ * nn.Linear (model.py:317) and all their backward (dgrad / wgrad) products.
+ *   mode 0 (NT): A[M,K] lda, B[N,K] ldb      (y = x W^T)
+ *   mode 1 (NN): A[M,K] lda, B[K,N] ldb      (dx = dy W)
+ *   mode 2 (TN): A[K,M] lda, B[K,N] ldb      (dW = dy^T x), reduction row r addressed two-level:
+ *                row(r) = (r / kdiv) * kouter + (r % kdiv) * ld   when kdiv > 0 (per operand)
+ * batch > 1: independent problems at A + b*strideA, B + b*strideB, C + b*strideC (NT/NN only).
+ */
+#define AAS_GEMM_NT 0
+#define AAS_GEMM_NN 1
+#define AAS_GEMM_TN 2
+int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K,
+                 const float* A, int64_t lda, const float* B, int64_t ldb,
+                 float* C, int64_t ldc,
+                 const float* bias, const float* addend, int64_t ldd, int accumulate,
+                 int batch, int64_t strideA, int64_t strideB, int64_t strideC,
+                 int kdivA, int64_t kouterA, int kdivB, int64_t kouterB);
+
+/* ---------------------------------------------------------------- layout / elementwise --------
+ * out[b, c, r] = in[b, r, c]  with element strides (in: isb, isr, c contiguous; out: osb, osc, r
+ * contiguous).  Replaces the .transpose() chains at model.py:222,227,328,331. */
+int aas_transpose_f32(aasStream_t stream, const float* in, float* out, int B, int R, int C,
+                      int64_t isb, int64_t isr, int64_t osb, int64_t osc);
+/* out[b, a, :] = in[a, b, :]  ([A,B,C] -> [B,A,C], C contiguous): N,T,C <-> T,N,C (model.py:328,331) */
+int aas_swap01_f32(aasStream_t stream, const float* in, float* out, int A, int B, int C);
+/* out = a + b (+ c if c != NULL), n elements.  Direction sum + residual (model.py:85,104,223-226). */
+int aas_add3_f32(aasStream_t stream, float* out, const float* a, const float* b, const float* c, int64_t n);
+/* y = alpha * x + beta * y  (gradient scaling / accumulation; y may alias x) */
+int aas_axpby_f32(aasStream_t stream, float* y, const float* x, float alpha, float beta, int64_t n);
+/* out[c] (+)= sum_r x[r, c]   (bias gradients) */
+int aas_colsum_f32(aasStream_t stream, const float* x, int64_t R, int C, int64_t ld, float* out, int accumulate);
+/* acc[0] += sum x^2 (fp64 accumulator on device). trainer_AAS.py:353-361 get_gradient_norm. */
+int aas_sqsum_f32(aasStream_t stream, const float* x, int64_t n, double* acc);
+
+/* ---------------------------------------------------------------- recurrent layers ------------
+ * Bidirectional, bias-free LSTM layer recurrence (cuDNN RNN under model.py:94-95,102).
+ *   pre   [T,N,2,4H]  input projections x W_ih^T for both directions (d=0 forward, d=1 reverse),
+ *                     gate order i,f,g,o (PyTorch)
+ *   w_hh, w_hh_rev  [4H,H] each (weight_hh_l0, weight_hh_l0_reverse)
+ *   hout  [2,T,N,H]   h_t per direction (time index = position in the sequence, both directions)
+ *   gact  [2,T,N,4H]  post-nonlinearity gates (saved for backward);  cst [2,T,N,H] cell states
+ *   sync  >= aas_rnn_sync_bytes() bytes of zero-initialisable device scratch (zeroed by the call)
+ * Persistent kernel: one workgroup per (unit slice, batch group, direction); W_hh slices stay
+ * in registers for all T steps; h_t is exchanged through L2 with write-through stores and an
+ * agent-scope arrival counter per (batch group, direction).
+ */
+size_t aas_rnn_sync_bytes(void);
+int aas_lstm_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh,
+                 const float* w_hh_rev, float* hout, float* gact, float* cst, void* sync);
+/* BPTT.  dy [T,N,H] is the gradient wrt (h_fwd + h_bwd) (shared by both directions);
+ * dgates [T,N,2,4H] receives d(loss)/d(pre) (same layout as pre). */
+int aas_lstm_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh,
+                 const float* w_hh_rev, const float* gact, const float* cst, float* dgates, void* sync);
+
+/* Bidirectional bias-free GRU (cuDNN RNN under model.py:73-74,83), gate order r,z,n:
+ *   pre [T,N,2,3H]; w_hh, w_hh_rev [3H,H]; hout [2,T,N,H];
+ *   gact [2,T,N,4H] saves r, z, n and hn = (W_hn h_{t-1}) for backward. */
+int aas_gru_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh,
+                const float* w_hh_rev, float* hout, float* gact, void* sync);
+/* dgx [T,N,2,3H] = d/d(pre) (for dW_ih, dx); dgh [T,N,2,3H] = d/d(W_hh h) (for dW_hh). */
+int aas_gru_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh,
+                const float* w_hh_rev, const float* hout, const float* gact, float* dgx, float* dgh, void* sync);
+
+/* ---------------------------------------------------------------- batch norm (train mode) -----
+ * Rows-by-channels BatchNorm with batch statistics (nn.BatchNorm1d in train mode: model.py:72,82
+ * via SequenceWise :44-49, :290,298, :316; the reference never calls ASR.eval()).
+ * x,y [R,C] (ld = C).  stats [4,C] fp32: mean, invstd, (bwd) sum_dy, sum_dy_xhat.
+ * slope != 1 fuses LeakyReLU(negative_slope = slope) after the affine (model.py:291,299: slope=map).
+ * running_mean/var (may be NULL) are updated with `momentum` and the unbiased variance.
+ * wsd: >= 2*C doubles of scratch. */
+int aas_bn_fwd(aasStream_t stream, const float* x, float* y, int64_t R, int C,
+               const float* gamma, const float* beta, float eps, float slope,
+               float* stats, float* running_mean, float* running_var, float momentum, double* wsd);
+int aas_bn_bwd(aasStream_t stream, const float* x, const float* dy, float* dx, int64_t R, int C,
+               const float* gamma, const float* beta, float slope, float* stats,
+               float* dgamma, float* dbeta, int accumulate, double* wsd);
+
+/* conv1d backward-data helper: dx[n,t,f] = sum_{kk} dcol[n,(t-kk)/s,kk,f] over valid (t-kk)%s==0.
+ * dcol [N,T1,KW,F] (from the NN GEMM dOut x W2), dx [N,T,F] channels-last.  model.py:289,297. */
+int aas_col2im_f32(aasStream_t stream, const float* dcol, float* dx, int N, int T, int T1, int F, int KW, int stride);
+
+/* ---------------------------------------------------------------- losses ----------------------
+ * L1Loss_mask (model.py:19-31): loss_sum[0] (+)= sum |a-b| over ALL elements (mask not applied,
+ * as in the reference); the caller divides by nElement = #unmasked (n,t). fp64 accumulator. */
+int aas_l1_fwd(aasStream_t stream, const float* a, const float* b, int64_t n, double* loss_sum);
+/* ga = scale*sign(a-b) (if ga), gb = -scale*sign(a-b) (if gb); `accumulate` adds into them. */
+int aas_l1_bwd(aasStream_t stream, const float* a, const float* b, int64_t n, float scale,
+               float* ga, float* gb, int accumulate);
+
+/* CTC (warpctc_pytorch.CTCLoss; call site trainer_AAS.py:168).  Mirrors warp-ctc's C ABI
+ * (get_workspace_size / compute_ctc_loss): activations [T,N,C] pre-softmax, gradients [T,N,C]
+ * (may be NULL), labels/lengths on the HOST (int32), blank index `blank`.
+ * aas_compute_ctc_loss is SYNCHRONOUS like warp-ctc's gpu path: h_costs[N] is on the host.
+ * aas_ctc_loss_async keeps everything on the device: d_labels (flat), d_label_offsets[N],
+ * d_label_lens[N], d_act_lens[N], costs[N] device; max_label_len bounds S = 2L+1. */
+int aas_ctc_get_workspace_size(const int* h_label_lens, const int* h_act_lens, int alphabet, int minibatch,
+                               int max_T, size_t* bytes);
+int aas_compute_ctc_loss(aasStream_t stream, const float* activations, float* gradients,
+                         const int* h_flat_labels, const int* h_label_lens, const int* h_act_lens,
+                         int alphabet, int minibatch, int max_T, float* h_costs, void* workspace, int blank);
+int aas_ctc_loss_async(aasStream_t stream, const float* activations, float* gradients,
+                       const int* d_labels, const int* d_label_offsets, const int* d_label_lens,
+                       const int* d_act_lens, int alphabet, int minibatch, int max_T, int max_label_len,
+                       float* costs, void* workspace, int blank, float grad_scale);
+
+/* ---------------------------------------------------------------- optimiser -------------------
+ * torch.optim.Adam(amsgrad=True/False) element-wise update (trainer_AAS.py:127-129,185-188;
+ * AM_training/train.py:246-247), torch 2.x semantics:
+ *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; vmax = max(vmax, v);
+ *   p -= (lr/(1-b1^t)) * m / (sqrt(vmax)/sqrt(1-b2^t) + eps)          (vmax = v if !amsgrad) */
+int aas_adam_f32(aasStream_t stream, float* p, const float* g, float* m, float* v, float* vmax,
+                 int64_t n, float lr, float beta1, float beta2, float eps, int step, int amsgrad,
+                 float grad_scale);
+
+/* ---------------------------------------------------------------- features --------------------
+ * log-Mel filterbank: wave [N,S] -> out [N,n_mels,T] with T = 1 + S/hop; hamming(periodic) window
+ * of `win` samples, centre=True reflect padding, |DFT|^2 -> mel -> log1p.  Tables from
+ * aas_lmfb_tables: dft [win, 2*nbins] (cos | -sin, window folded in), melT [nbins, n_mels].
+ * (AM_training/train.py:39-42,55-60,199; model.py:194-198.) */
+int aas_lmfb_fwd(aasStream_t stream, const float* wave, int N, int S, int win, int hop, int n_mels,
+                 const float* dft, const float* melT, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AAS_HIP_H */

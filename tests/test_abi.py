@@ -1,0 +1,102 @@
+"""CPU (-m "not gpu"): the C-ABI library builds/loads here and exports every symbol include/aas_hip.h declares;
+the host logic that needs no GPU (collate layouts, decoder, config, error paths)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "aas_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(aas_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from aas_enhancement_amd import _lib, build
+    build.build(verbose=False)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), n
+        assert n in _lib.SIGNATURES, "binding missing for " + n
+    assert set(_lib.SIGNATURES) == set(names)
+    assert _lib.lib().aas_version() == 1
+    assert _lib.lib().aas_rnn_sync_bytes() >= 4096
+
+
+def test_no_cpu_fallback():
+    from aas_enhancement_amd import ops
+    from aas_enhancement_amd.model import L1Loss_mask, stackedBRNN
+    G = stackedBRNN(I=4, H=8, L=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        G(torch.zeros(1, 4, 5))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L1Loss_mask()(torch.zeros(1, 4, 5), torch.zeros(1, 4, 5), torch.zeros(1, 1, 5, dtype=torch.uint8))
+
+
+def test_argument_validation_without_gpu():
+    from aas_enhancement_amd import _lib
+    L = _lib.lib()
+    assert L.aas_gemm_f32(None, 7, 1, 1, 1, None, 1, None, 1, None, 1, None, None, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0) != 0
+    assert b"bad mode" in L.aas_last_error()
+    sz = ctypes.c_size_t(0)
+    ll, al = np.array([4, 3], np.int32), np.array([15, 12], np.int32)
+    assert L.aas_ctc_get_workspace_size(ll.ctypes.data, al.ctypes.data, 29, 2, 15, ctypes.byref(sz)) == 0
+    assert sz.value >= 4 * 2 * (15 * 9 + 15)
+
+
+def test_state_dict_keys_match_reference_goldens():
+    import torch.nn as nn
+    from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
+    from tests.helpers import LABELS, load, sub
+    z = load("f1_aas_tiny.npz")
+    G = stackedBRNN(I=8, H=16, L=4)
+    A = DeepSpeech(nn.GRU, LABELS, 12, 5, True, 11, 2, 8, 2, nFreq=8)
+    assert list(G.state_dict().keys()) == list(sub(z, "init.G.").keys())
+    assert list(A.state_dict().keys()) == list(sub(z, "init.A.").keys())
+    for k, v in A.state_dict().items():
+        assert tuple(v.shape) == tuple(z["init.A." + k].shape), k
+    pkg = DeepSpeech.serialize(A)
+    B = DeepSpeech.load_model_package(pkg)
+    assert B.nFreq == 8 and B.rnn_size == 12 and len(B.rnns) == 5
+
+
+def test_collate_layouts():
+    from aas_enhancement_amd.loader_functions import _collate_fn, _collate_fn_paired
+    feats = [torch.randn(8, t) for t in (5, 9, 7)]
+    out = _collate_fn([(f, [1, 2][: i + 1]) for i, f in enumerate(feats)])
+    inputs, targets, pct, tsz, mask = out
+    assert inputs.shape == (3, 8, 9) and mask.shape == (3, 1, 9) and mask.dtype == torch.uint8
+    assert [int(m.sum()) for m in mask] == [0, 2, 4] and mask.n_valid == 21
+    assert torch.allclose(pct, torch.tensor([1.0, 7 / 9.0, 5 / 9.0]))
+    assert targets.dtype == torch.int32 and tsz.tolist() == [2, 2, 1]
+    p = _collate_fn_paired([(f, [3], f * 2) for f in feats])
+    assert len(p) == 6 and torch.equal(p[1][0], feats[1] * 2) and p[2].n_valid == 21
+
+
+def test_greedy_decoder_and_wer():
+    from aas_enhancement_amd.decoder import GreedyDecoder
+    from tests.helpers import LABELS
+    d = GreedyDecoder(LABELS)
+    T, C = 8, len(LABELS)
+    path = [2, 2, 0, 2, 28, 3, 3, 0]  # a a _ a ' ' b b _  -> "aa b"
+    probs = torch.full((T, 1, C), -5.0)
+    for t, k in enumerate(path):
+        probs[t, 0, k] = 5.0
+    out, _ = d.decode(probs, torch.tensor([T]))
+    assert out[0][0] == "aa b"
+    assert d.wer("the cat sat", "the cat sit") == 1 and d.cer("abc", "axc") == 1
+
+
+def test_config_flags_match_reference_defaults():
+    from aas_enhancement_amd.config import get_config
+    c, _ = get_config([])
+    assert (c.trainer, c.batch_size, c.nFeat, c.rnn_size, c.rnn_layers, c.lr, c.beta1, c.gamma, c.lambda_k, c.max_iter) == \
+        ("AAS", 20, 40, 500, 4, 1e-5, 0.5, 0.5, 0.001, 30000000)

@@ -1,0 +1,281 @@
+"""GPU parity tests (-m gpu): every HIP op, through the C ABI, against the CPU oracle / goldens.
+Tolerances: fp32 kernels vs fp32 CPU reference; relative = max|a-b| / max|ref|."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from tests.helpers import load, load_sd, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from aas_enhancement_amd import ops as o
+    return o
+
+
+def R(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def test_native_library_loaded():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from aas_enhancement_amd import _lib
+    L = _lib.lib()
+    assert L.aas_version() == 1 and L.aas_device_cus() >= 64
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (128, 128, 16), (130, 70, 50), (600, 500, 500), (333, 29, 1000), (257, 129, 33)])
+def test_gemm_modes(ops, M, N, K):
+    a, b, bias, add = R(M, K, seed=1), R(N, K, seed=2), R(N, seed=3), R(M, N, seed=4)
+    A, B = a.cuda(), b.cuda()
+    c = torch.empty(M, N, device="cuda")
+    ops.gemm(ops.NT, M, N, K, A, K, B, K, c, N, bias=bias.cuda(), addend=add.cuda(), ldd=N)
+    ref = a.double() @ b.double().t() + bias.double() + add.double()
+    assert rel_err(c, ref) < 2e-6 * max(1, K ** 0.5)
+    bt = b.t().contiguous().cuda()  # [K,N]
+    ops.gemm(ops.NN, M, N, K, A, K, bt, N, c, N)
+    assert rel_err(c, a.double() @ b.double().t()) < 2e-6 * max(1, K ** 0.5)
+    at = a.t().contiguous().cuda()  # [K,M]
+    c.fill_(1.0)
+    ops.gemm(ops.TN, M, N, K, at, M, bt, N, c, N, accumulate=True)
+    assert rel_err(c, a.double() @ b.double().t() + 1.0) < 2e-6 * max(1, K ** 0.5)
+
+
+def test_gemm_splitk_batch_twolevel(ops):
+    # deep-K small-MN -> split-K atomics path
+    K, M, N = 6000, 200, 120
+    at, bt = R(K, M, seed=5), R(K, N, seed=6)
+    c = torch.empty(M, N, device="cuda")
+    ops.gemm(ops.TN, M, N, K, at.cuda(), M, bt.cuda(), N, c, N)
+    assert rel_err(c, at.double().t() @ bt.double()) < 2e-5
+    # batched NT with strided rows (implicit im2col): x [Nb,T,F], rows t1 -> x[n, t1*s : t1*s+KW, :]
+    Nb, T, Fd, KW, s, Mch = 3, 50, 10, 11, 2, 8
+    x, w = R(Nb, T, Fd, seed=7), R(Mch, KW * Fd, seed=8)
+    T1 = (T - KW) // s + 1
+    y = torch.empty(Nb, T1, Mch, device="cuda")
+    ops.gemm(ops.NT, T1, Mch, KW * Fd, x.cuda(), s * Fd, w.cuda(), KW * Fd, y, Mch, batch=Nb, sA=T * Fd, sB=0, sC=T1 * Mch)
+    col = torch.stack([x[:, t * s:t * s + KW, :].reshape(Nb, -1) for t in range(T1)], 1)
+    assert rel_err(y, col.double() @ w.double().t()) < 1e-5
+    # two-level reduction rows on B (conv wgrad)
+    dy = R(Nb * T1, Mch, seed=9)
+    dw = torch.empty(Mch, KW * Fd, device="cuda")
+    ops.gemm(ops.TN, Mch, KW * Fd, Nb * T1, dy.cuda(), Mch, x.cuda(), s * Fd, dw, KW * Fd, kdivB=T1, kouterB=T * Fd)
+    assert rel_err(dw, dy.double().t() @ col.reshape(Nb * T1, -1).double()) < 1e-5
+
+
+def test_layout_and_elementwise(ops):
+    x = R(5, 7, 13, seed=1)
+    X = x.cuda()
+    assert torch.equal(ops.nct_to_tnc(X).cpu(), x.permute(2, 0, 1).contiguous())
+    assert torch.equal(ops.tnc_to_nct(X).cpu(), x.permute(1, 2, 0).contiguous())
+    assert torch.equal(ops.nct_to_ntc(X).cpu(), x.permute(0, 2, 1).contiguous())
+    assert torch.equal(ops.ntc_to_nct(X).cpu(), x.permute(0, 2, 1).contiguous())
+    assert torch.equal(ops.swap01(X).cpu(), x.permute(1, 0, 2).contiguous())
+    big = R(70, 130, 65, seed=2)
+    assert torch.equal(ops.nct_to_tnc(big.cuda()).cpu(), big.permute(2, 0, 1).contiguous())
+    a, b, c = R(1001, seed=3), R(1001, seed=4), R(1001, seed=5)
+    assert torch.allclose(ops.add3(a.cuda(), b.cuda(), c.cuda()).cpu(), a + b + c)
+    assert torch.allclose(ops.add3(a.cuda(), b.cuda()).cpu(), a + b)
+    m = R(777, 93, seed=6)
+    assert rel_err(ops.colsum(m.cuda(), 777, 93), m.double().sum(0)) < 1e-6
+    acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ops.sqsum_into(acc, m.cuda())
+    assert float(acc) == pytest.approx(float((m.double() ** 2).sum()), rel=1e-6)
+    y = b.cuda()
+    ops.axpby_(y, a.cuda(), 2.0, -0.5)
+    assert torch.allclose(y.cpu(), 2 * a - 0.5 * b, atol=1e-6)
+
+
+def test_l1_loss_golden(ops):
+    from aas_enhancement_amd.model import L1Loss_mask
+    z = load("f4_ops.npz")
+    a = torch.from_numpy(z["l1.a"]).cuda().requires_grad_(True)
+    b = torch.from_numpy(z["l1.b"]).cuda().requires_grad_(True)
+    loss, nel = L1Loss_mask()(a, b, torch.from_numpy(z["l1.mask"]).cuda())
+    loss.backward()
+    assert nel == int(z["l1.nElement"])
+    assert float(loss) == pytest.approx(float(z["l1.loss"]), rel=1e-6)
+    assert rel_err(a.grad, z["l1.ga"]) < 1e-6 and rel_err(b.grad, z["l1.gb"]) < 1e-6
+
+
+def test_adam_amsgrad_vs_torch(ops):
+    from aas_enhancement_amd.optim import Adam
+    p0 = R(1000, seed=1)
+    pr = p0.clone().requires_grad_(True)
+    pg = p0.clone().cuda().requires_grad_(True)
+    o_ref = torch.optim.Adam([pr], lr=1e-3, betas=(0.5, 0.999), amsgrad=True)
+    o_gpu = Adam([pg], lr=1e-3, betas=(0.5, 0.999), amsgrad=True)
+    for it in range(5):
+        g = R(1000, seed=10 + it) * (10.0 ** (it - 2))
+        pr.grad = g.clone()
+        pg.grad = g.clone().cuda()
+        o_ref.step(); o_gpu.step()
+    assert rel_err(pg, pr) < 1e-6
+    o2r = torch.optim.Adam([pr], lr=1e-2)
+    o2g = Adam([pg], lr=1e-2)
+    pr.grad = R(1000, seed=99); pg.grad = pr.grad.clone().cuda()
+    o2r.step(); o2g.step()
+    assert rel_err(pg, pr) < 1e-6
+
+
+@pytest.mark.parametrize("slope", [1.0, 128.0])
+def test_batchnorm_rows(ops, slope):
+    Rr, C = 2550, 130
+    x = R(Rr, C, seed=1) * 3 + 1.5
+    gy = R(Rr, C, seed=2)
+    bn = nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(R(C, seed=3) * 0.1 + 1); bn.bias.copy_(R(C, seed=4) * 0.1)
+    xr = x.clone().requires_grad_(True)
+    yr = F.leaky_relu(bn(xr), slope) if slope != 1.0 else bn(xr)
+    yr.backward(gy)
+    g, b = bn.weight.detach().clone().cuda().requires_grad_(True), bn.bias.detach().clone().cuda().requires_grad_(True)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    xg = x.clone().cuda().requires_grad_(True)
+    yg = ops.batchnorm_rows(xg, g, b, rm, rv, 1e-5, 0.1, slope)
+    yg.backward(gy.cuda())
+    assert rel_err(yg, yr) < 1e-5
+    assert rel_err(xg.grad, xr.grad) < 1e-4
+    assert rel_err(g.grad, bn.weight.grad) < 1e-4 and rel_err(b.grad, bn.bias.grad) < 1e-4
+    assert rel_err(rm, bn.running_mean) < 1e-5 and rel_err(rv, bn.running_var) < 1e-5
+
+
+def test_conv_frontend_golden(ops):
+    """reference DeepSpeech.conv (conv k11 s2 + BN + LeakyReLU(slope=map), conv k11 s1 + BN + LReLU)"""
+    from aas_enhancement_amd.model import DeepSpeech
+    z = load("f4_ops.npz")
+    A = DeepSpeech(nn.GRU, "_'abcdefghijklmnopqrstuvwxyz ", 6, 2, True, 11, 2, 8, 2, nFreq=10)
+    load_sd(A.conv, sub(z, "dsconv.sd."))
+    A.cuda()
+    x = torch.from_numpy(z["dsconv.x"]).cuda().requires_grad_(True)
+    h = ops.layout(x, "nct_ntc")
+    for i in range(0, 6, 3):
+        h = ops.conv1d_cl(h, A.conv[i].weight, A.conv[i].bias, A.conv[i].stride)
+        h = A.conv[i + 1](h, slope=float(A.conv[i + 2].negative_slope))
+    y = ops.layout(h, "ntc_nct")
+    y.backward(torch.from_numpy(z["dsconv.gy"]).cuda())
+    assert rel_err(y, z["dsconv.y"]) < 1e-4
+    assert rel_err(x.grad, z["dsconv.gx"]) < 1e-3
+    for k, p in A.conv.named_parameters():
+        if k.endswith("bias") and k[0] in "03":
+            continue  # conv bias before train-mode BN: true gradient is 0 (noise)
+        assert rel_err(p.grad, z["dsconv.gw." + k]) < 1e-3, k
+
+
+@pytest.mark.parametrize("kind", ["lstm", "gru"])
+@pytest.mark.parametrize("tag", ["s", "m"])
+def test_brnn_golden(ops, kind, tag):
+    from aas_enhancement_amd.model import BRNN
+    z = load("f4_ops.npz")
+    p = "brnn_%s_%s." % (kind, tag)
+    H = z[p + "x"].shape[2]
+    m = BRNN(H, H, nn.LSTM if kind == "lstm" else nn.GRU, bidirectional=True)
+    load_sd(m, sub(z, p + "w."))
+    m.cuda()
+    x = torch.from_numpy(z[p + "x"]).cuda().requires_grad_(True)
+    y = m(x)
+    y.backward(torch.from_numpy(z[p + "gy"]).cuda())
+    assert not ops.rnn_timeout_flag()
+    assert rel_err(y, z[p + "y"]) < 1e-5
+    assert rel_err(x.grad, z[p + "gx"]) < 1e-4
+    for k, v in m.named_parameters():
+        assert rel_err(v.grad, z[p + "gw." + k]) < 1e-4, k
+
+
+def test_batchrnn_golden(ops):
+    from aas_enhancement_amd.model import BatchRNN
+    z = load("f4_ops.npz")
+    m = BatchRNN(6, 9, nn.GRU, bidirectional=True, batch_norm=True)
+    load_sd(m, sub(z, "batchrnn.sd."))
+    m.cuda()
+    x = torch.from_numpy(z["batchrnn.x"]).cuda().requires_grad_(True)
+    y = m(x)
+    y.backward(torch.from_numpy(z["batchrnn.gy"]).cuda())
+    assert rel_err(y, z["batchrnn.y"]) < 1e-5 and rel_err(x.grad, z["batchrnn.gx"]) < 1e-4
+    for k, v in m.named_parameters():
+        assert rel_err(v.grad, z["batchrnn.gw." + k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("kind,T,N,H", [("lstm", 200, 30, 500), ("gru", 85, 30, 1000), ("lstm", 40, 60, 128), ("gru", 30, 70, 64),
+                                        ("lstm", 9, 3, 16), ("gru", 1, 2, 12)])
+def test_birnn_layer_vs_cpu_at_size(ops, kind, T, N, H):
+    """config-2 layer shapes (E: T=200,N=30,H=500; A: T'=85,N=30,H=1000) and multi-group batches."""
+    torch.manual_seed(0)
+    ref = (nn.LSTM if kind == "lstm" else nn.GRU)(H, H, bidirectional=True, bias=False)
+    x = R(T, N, H, seed=1) * 0.5
+    gy = R(T, N, H, seed=2)
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref(xr)
+    yr = yr[..., :H] + yr[..., H:] + xr
+    yr.backward(gy)
+    w = [getattr(ref, k).detach().clone().cuda().requires_grad_(True) for k in
+         ("weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse")]
+    xg = x.clone().cuda().requires_grad_(True)
+    yg = ops.birnn_layer(xg, *w, kind=kind, residual=True)
+    yg.backward(gy.cuda())
+    torch.cuda.synchronize()
+    assert not ops.rnn_timeout_flag()
+    assert rel_err(yg, yr) < 2e-5
+    assert rel_err(xg.grad, xr.grad) < 2e-4
+    for wg, k in zip(w, ("weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse")):
+        assert rel_err(wg.grad, getattr(ref, k).grad) < 2e-4, k
+
+
+def test_ctc_vs_numpy_and_torch(ops):
+    from aas_enhancement_amd.ctc import CTCLoss
+    from oracle import ctc_np
+    rng = np.random.RandomState(0)
+    for (T, N, C, lab_lens, act_lens) in [(15, 3, 29, [4, 3, 2], [15, 12, 9]), (85, 30, 29, [20] * 30, [85] * 30),
+                                          (6, 4, 5, [0, 1, 3, 2], [6, 5, 6, 3]), (4, 2, 3, [3, 2], [4, 4])]:
+        acts = torch.from_numpy((rng.randn(T, N, C) * 2).astype(np.float32))
+        labels = []
+        for n, L in enumerate(lab_lens):
+            labels += list(rng.randint(1, C, size=L)) if n % 2 == 0 else [1 + (i % 2) * 0 for i in range(L)]  # repeats
+        labels = np.asarray(labels, np.int32)
+        ag = acts.clone().cuda().requires_grad_(True)
+        loss = CTCLoss()(ag, torch.from_numpy(labels), torch.tensor(act_lens, dtype=torch.int32), torch.tensor(lab_lens, dtype=torch.int32))
+        costs, grads = ctc_np.ctc_batch(acts.numpy(), labels, act_lens, lab_lens)
+        if np.isinf(costs).any():
+            assert np.isinf(float(loss))
+            continue
+        (loss * 0.5).backward()
+        assert float(loss) == pytest.approx(costs.sum(), rel=1e-5)
+        assert np.abs(ag.grad.cpu().numpy() - 0.5 * grads).max() < 2e-5
+    # warp-ctc-shaped synchronous entry point
+    import ctypes
+    from aas_enhancement_amd import _lib
+    L = _lib.lib()
+    T, N, C = 15, 3, 29
+    acts = torch.from_numpy(rng.randn(T, N, C).astype(np.float32)).cuda()
+    labels = np.array([3, 3, 7, 1, 28, 5, 9, 9, 2], np.int32)
+    ll, al = np.array([4, 3, 2], np.int32), np.array([15, 12, 9], np.int32)
+    sz = ctypes.c_size_t(0)
+    _lib.check(L.aas_ctc_get_workspace_size(ll.ctypes.data, al.ctypes.data, C, N, T, ctypes.byref(sz)))
+    ws = torch.empty(sz.value, dtype=torch.uint8, device="cuda")
+    grads = torch.empty_like(acts)
+    costs = np.zeros(N, np.float32)
+    _lib.check(L.aas_compute_ctc_loss(None, acts.data_ptr(), grads.data_ptr(), labels.ctypes.data, ll.ctypes.data,
+                                      al.ctypes.data, C, N, T, costs.ctypes.data, ws.data_ptr(), 0))
+    rc, rg = ctc_np.ctc_batch(acts.cpu().numpy(), labels, al, ll)
+    assert np.abs(costs - rc).max() < 1e-3 * rc.max() and np.abs(grads.cpu().numpy() - rg).max() < 2e-5
+
+
+def test_lmfb_vs_numpy(ops):
+    from aas_enhancement_amd.lmfb import LMFB
+    from aas_enhancement_amd import prng
+    from oracle import lmfb_np
+    wave = prng.normal(126, (3, 31840), 0.0, 0.1)
+    f = LMFB(n_mels=80).cuda()(torch.from_numpy(wave).cuda())
+    assert tuple(f.shape) == (3, 80, 200)
+    ref = np.stack([lmfb_np.lmfb(w) for w in wave])
+    assert rel_err(f, ref) < 1e-3
+    f40 = LMFB(n_mels=40).cuda()(torch.from_numpy(wave[:1, :1000]).cuda())
+    assert rel_err(f40, lmfb_np.lmfb(wave[0, :1000], n_mels=40)[None]) < 1e-3
