@@ -10,75 +10,79 @@
 
 namespace {
 
-__device__ __forceinline__ float lse2(float a, float b) {
-    if (a == -INFINITY) return b;
-    if (b == -INFINITY) return a;
-    const float m = fmaxf(a, b);
-    return m + log1pf(__expf(-fabsf(a - b)));
+// alpha/beta recursions run in fp64 (the op is latency-bound, not throughput-bound): keeps the
+// gradient at fp32 round-off instead of the ~1e-4 an fp32 log-space sweep over 85+ frames gives.
+typedef double real;
+#define NEG_INF (-(real)INFINITY)
+__device__ __forceinline__ real lse2(real a, real b) {
+    if (a == NEG_INF) return b;
+    if (b == NEG_INF) return a;
+    const real m = fmax(a, b);
+    return m + log1p(exp(-fabs(a - b)));
 }
 
 __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ acts, float* __restrict__ grads,
                                                   const int* __restrict__ labels, const int* __restrict__ lab_off,
                                                   const int* __restrict__ lab_lens, const int* __restrict__ act_lens,
                                                   int C, int N, int Tmax, int Smax, float* __restrict__ costs,
-                                                  float* __restrict__ ws, int blank, float gscale) {
+                                                  real* __restrict__ ws, int blank, float gscale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* ext = reinterpret_cast<int*>(smem);
-    float* a0 = reinterpret_cast<float*>(smem) + Smax;
-    float* a1 = a0 + Smax;
-    float* occ = a1 + Smax;
+    real* a0 = reinterpret_cast<real*>(smem);
+    real* a1 = a0 + Smax;
+    float* occ = reinterpret_cast<float*>(a1 + Smax);
+    int* ext = reinterpret_cast<int*>(occ + C);
     const int n = blockIdx.x, tid = threadIdx.x;
     const int L = lab_lens[n];
     int Tn = act_lens[n];
     if (Tn > Tmax) Tn = Tmax;
     const int S = 2 * L + 1;
-    float* alpha = ws + (int64_t)n * ((int64_t)Tmax * Smax + Tmax);
-    float* lse = alpha + (int64_t)Tmax * Smax;
+    real* alpha = ws + (int64_t)n * ((int64_t)Tmax * Smax + Tmax);
+    real* lse = alpha + (int64_t)Tmax * Smax;
     const int off = lab_off[n];
-    auto act = [&](int t, int c) { return acts[((int64_t)t * N + n) * C + c]; };
+    auto act = [&](int t, int c) { return (real)acts[((int64_t)t * N + n) * C + c]; };
 
     for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? labels[off + (s >> 1)] : blank;
     for (int t = tid; t < Tn; t += 256) {
-        float m = -INFINITY;
-        for (int c = 0; c < C; ++c) m = fmaxf(m, act(t, c));
-        float sum = 0.f;
-        for (int c = 0; c < C; ++c) sum += __expf(act(t, c) - m);
-        lse[t] = m + __logf(sum);
+        real m = NEG_INF;
+        for (int c = 0; c < C; ++c) m = fmax(m, act(t, c));
+        real sum = 0;
+        for (int c = 0; c < C; ++c) sum += exp(act(t, c) - m);
+        lse[t] = m + log(sum);
     }
     __syncthreads();
     bool feasible = (Tn >= 1) && (S <= Smax);
-    float ll = -INFINITY;
+    real ll = NEG_INF;
     if (feasible) {
         // ---- alpha sweep ----
         for (int s = tid; s < S; s += 256) {
-            float a = -INFINITY;
+            real a = NEG_INF;
             if (s < 2) a = act(0, ext[s]) - lse[0];
             a0[s] = a;
             alpha[s] = a;
         }
         __syncthreads();
         for (int t = 1; t < Tn; ++t) {
-            const float* prev = (t & 1) ? a0 : a1;
-            float* cur = (t & 1) ? a1 : a0;
-            const float l_t = lse[t];
+            const real* prev = (t & 1) ? a0 : a1;
+            real* cur = (t & 1) ? a1 : a0;
+            const real l_t = lse[t];
             for (int s = tid; s < S; s += 256) {
-                float x = prev[s];
+                real x = prev[s];
                 if (s >= 1) x = lse2(x, prev[s - 1]);
                 const int e = ext[s];
                 if (s >= 2 && e != blank && e != ext[s - 2]) x = lse2(x, prev[s - 2]);
-                if (x != -INFINITY) x += act(t, e) - l_t;
+                if (x != NEG_INF) x += act(t, e) - l_t;
                 cur[s] = x;
                 alpha[(int64_t)t * Smax + s] = x;
             }
             __syncthreads();
         }
-        const float* last = alpha + (int64_t)(Tn - 1) * Smax;
+        const real* last = alpha + (int64_t)(Tn - 1) * Smax;
         ll = last[S - 1];
         if (S > 1) ll = lse2(ll, last[S - 2]);
         __syncthreads();
-        feasible = (ll != -INFINITY);
+        feasible = (ll != NEG_INF);
     }
-    if (tid == 0) costs[n] = feasible ? -ll : INFINITY;
+    if (tid == 0) costs[n] = feasible ? (float)(-ll) : INFINITY;
     if (!grads) return;
     if (!feasible) {
         for (int i = tid; i < Tmax * C; i += 256) grads[((int64_t)(i / C) * N + n) * C + (i % C)] = 0.f;
@@ -87,44 +91,45 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ acts
     // ---- beta sweep fused with the gradient ----
     {
         const int t = Tn - 1;
-        for (int s = tid; s < S; s += 256) a0[s] = (s >= S - 2) ? act(t, ext[s]) - lse[t] : -INFINITY;
+        for (int s = tid; s < S; s += 256) a0[s] = (s >= S - 2) ? act(t, ext[s]) - lse[t] : NEG_INF;
     }
     __syncthreads();
     int flip = 0;
     for (int t = Tn - 1; t >= 0; --t) {
-        const float* bcur = flip ? a1 : a0;
-        float* bnext = flip ? a0 : a1;
+        const real* bcur = flip ? a1 : a0;
+        real* bnext = flip ? a0 : a1;
         for (int k = tid; k < C; k += 256) occ[k] = 0.f;
         __syncthreads();
-        const float l_t = lse[t];
+        const real l_t = lse[t];
         for (int s = tid; s < S; s += 256) {
-            const float al = alpha[(int64_t)t * Smax + s], be = bcur[s];
-            if (al != -INFINITY && be != -INFINITY) {
+            const real al = alpha[(int64_t)t * Smax + s], be = bcur[s];
+            if (al != NEG_INF && be != NEG_INF) {
                 const int e = ext[s];
-                atomicAdd(&occ[e], __expf(al + be - (act(t, e) - l_t) - ll));
+                atomicAdd(&occ[e], (float)exp(al + be - (act(t, e) - l_t) - ll));
             }
         }
         if (t > 0) {
-            const float l_p = lse[t - 1];
+            const real l_p = lse[t - 1];
             for (int s = tid; s < S; s += 256) {
-                float x = bcur[s];
+                real x = bcur[s];
                 if (s + 1 < S) x = lse2(x, bcur[s + 1]);
                 const int e = ext[s];
                 if (s + 2 < S && ext[s + 2] != blank && ext[s + 2] != e) x = lse2(x, bcur[s + 2]);
-                if (x != -INFINITY) x += act(t - 1, e) - l_p;
+                if (x != NEG_INF) x += act(t - 1, e) - l_p;
                 bnext[s] = x;
             }
         }
         __syncthreads();
         for (int k = tid; k < C; k += 256)
-            grads[((int64_t)t * N + n) * C + k] = gscale * (__expf(act(t, k) - l_t) - occ[k]);
+            grads[((int64_t)t * N + n) * C + k] = gscale * ((float)exp(act(t, k) - l_t) - occ[k]);
         __syncthreads();
         flip ^= 1;
     }
     for (int i = tid; i < (Tmax - Tn) * C; i += 256) grads[((int64_t)(Tn + i / C) * N + n) * C + (i % C)] = 0.f;
 }
 
-size_t ws_floats(int minibatch, int max_T, int smax) { return (size_t)minibatch * ((size_t)max_T * smax + max_T); }
+// workspace in 4-byte units (the scratch itself is fp64)
+size_t ws_floats(int minibatch, int max_T, int smax) { return 2 * (size_t)minibatch * ((size_t)max_T * smax + max_T); }
 
 }  // namespace
 
@@ -137,11 +142,11 @@ extern "C" int aas_ctc_loss_async(aasStream_t stream, const float* activations, 
     AAS_CHECK(alphabet > 0 && minibatch > 0 && max_T > 0 && max_label_len >= 0 && blank >= 0 && blank < alphabet,
               "aas_ctc_loss_async: bad sizes");
     const int smax = 2 * max_label_len + 1;
-    const size_t lds = sizeof(float) * ((size_t)3 * smax + alphabet);
+    const size_t lds = sizeof(real) * 2 * smax + sizeof(float) * alphabet + sizeof(int) * smax;
     AAS_CHECK(lds <= 64 * 1024, "aas_ctc_loss_async: label length %d too long for the LDS state arrays", max_label_len);
     hipLaunchKernelGGL(ctc_kernel, dim3(minibatch), dim3(256), lds, (hipStream_t)stream, activations, gradients, d_labels,
                        d_label_offsets, d_label_lens, d_act_lens, alphabet, minibatch, max_T, smax, costs,
-                       (float*)workspace, blank, grad_scale);
+                       (real*)workspace, blank, grad_scale);
     AAS_LAUNCH_CHECK("aas_ctc_loss_async");
     return 0;
 }

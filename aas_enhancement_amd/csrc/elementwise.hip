@@ -41,9 +41,9 @@ __global__ __launch_bounds__(256) void add3_kernel(float* __restrict__ out, cons
         if (c) v += reinterpret_cast<const f32x4*>(c)[i];
         reinterpret_cast<f32x4*>(out)[i] = v;
     }
-    // tail (n not a multiple of 4)
-    int64_t t = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t < n) out[t] = a[t] + b[t] + (c ? c[t] : 0.f);
+    // scalar tail (n not a multiple of 4, or unaligned pointers: n4 == 0)
+    for (int64_t t = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += stride)
+        out[t] = a[t] + b[t] + (c ? c[t] : 0.f);
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha,
@@ -200,9 +200,6 @@ extern "C" int aas_add3_f32(aasStream_t stream, float* out, const float* a, cons
                 reinterpret_cast<uintptr_t>(c)) & 15) == 0;
     int64_t n4 = al ? n / 4 : 0;
     int g = grid_for(n4 > 0 ? n4 : n);
-    if (!al) {  // unaligned: scalar path = tail handling over everything, needs enough threads
-        AAS_CHECK(false, "aas_add3_f32: pointers must be 16-byte aligned");
-    }
     hipLaunchKernelGGL(add3_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, out, a, b, c, n4, n);
     AAS_LAUNCH_CHECK("aas_add3_f32");
     return 0;

@@ -417,7 +417,7 @@ class _CTC(torch.autograd.Function):
         nl = labels.numel()
         d_lab, d_off, d_ll, d_al = meta[:nl], meta[nl:nl + N], meta[nl + N:nl + 2 * N], meta[nl + 2 * N:]
         smax = 2 * max_l + 1
-        ws = torch.empty((N * (T * smax + T),), device=dev, dtype=torch.float32)
+        ws = torch.empty((N * (T * smax + T),), device=dev, dtype=torch.float64)
         costs = torch.empty((N,), device=dev, dtype=torch.float32)
         grads = torch.empty_like(acts)
         lp = ptr(d_lab) if nl > 0 else ptr(meta)
@@ -425,11 +425,9 @@ class _CTC(torch.autograd.Function):
                                        max_l, ptr(costs), ptr(ws), int(blank), 1.0), "aas_ctc_loss_async")
         ctx.save_for_backward(grads)
         ctx.costs = costs
-        total = torch.zeros((1,), device=dev, dtype=torch.float64)
         # reduce the N costs with the colsum kernel (R = N rows, C = 1 column)
         out = torch.empty((1,), device=dev, dtype=torch.float32)
         check(lib().aas_colsum_f32(stream(), ptr(costs), N, 1, 1, ptr(out), 0), "aas_colsum_f32")
-        del total
         return out
 
     @staticmethod
