@@ -47,10 +47,62 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class Profiler:
+    """Optional HIP-event timing of individual launches on the launching stream (bench.py roofline).
+    `classes` selects which launch classes are bracketed with events: "rnn" and/or "gemm"."""
+    enabled = False
+    classes = ("rnn",)
+    records = []  # (name, algorithmic_flops, start_event, end_event)
+
+    @classmethod
+    def start(cls, classes=("rnn",)):
+        cls.enabled, cls.classes, cls.records = True, tuple(classes), []
+
+    @classmethod
+    def stop(cls):
+        """-> {name: dict(count, total_ms, avg_ms, flops_per_launch)}; call after a device sync."""
+        cls.enabled = False
+        out = {}
+        for name, flops, e0, e1 in cls.records:
+            d = out.setdefault(name, dict(count=0, total_ms=0.0, flops=0.0))
+            d["count"] += 1
+            d["total_ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / d["count"]
+            d["flops_per_launch"] = d["flops"] / d["count"]
+        cls.records = []
+        return out
+
+
+class _timed:
+    def __init__(self, klass, name, flops):
+        self.on = Profiler.enabled and klass in Profiler.classes
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record(torch.cuda.current_stream())
+            Profiler.records.append((self.name, self.flops, self.e0, self.e1))
+
+
 # --------------------------------------------------------------------------------------- GEMM
 def gemm(mode, M, N, K, A, lda, B, ldb, C, ldc, bias=None, addend=None, ldd=0, accumulate=False,
          batch=1, sA=0, sB=0, sC=0, kdivA=0, kouterA=0, kdivB=0, kouterB=0, a_off=0, b_off=0, c_off=0):
     """Raw GEMM on device pointers; *_off are element offsets into A/B/C."""
+    with _timed("gemm", "gemm_f32", 2.0 * M * N * K * batch):
+        _gemm_raw(mode, M, N, K, A, lda, B, ldb, C, ldc, bias, addend, ldd, accumulate, batch, sA, sB, sC, kdivA, kouterA,
+                  kdivB, kouterB, a_off, b_off, c_off)
+
+
+def _gemm_raw(mode, M, N, K, A, lda, B, ldb, C, ldc, bias, addend, ldd, accumulate, batch, sA, sB, sC, kdivA, kouterA,
+              kdivB, kouterB, a_off, b_off, c_off):
     check(lib().aas_gemm_f32(stream(), mode, M, N, K, A.data_ptr() + 4 * a_off, lda, B.data_ptr() + 4 * b_off, ldb,
                              C.data_ptr() + 4 * c_off, ldc, ptr(bias), ptr(addend), ldd, int(accumulate),
                              batch, sA, sB, sC, kdivA, kouterA, kdivB, kouterB), "aas_gemm_f32")
@@ -195,14 +247,17 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
     hout = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
     gact = torch.empty((2, T, N, 4 * H), device=dev, dtype=torch.float32)
     sync = _sync_buf(dev)
+    rflops = 2.0 * 2 * T * N * H * G * H  # both directions, T steps of [N,H]x[H,G*H]
     if kind == "lstm":
         cst = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
-        check(lib().aas_lstm_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(cst),
-                                 ptr(sync)), "aas_lstm_fwd")
+        with _timed("rnn", "lstm_fwd", rflops):
+            check(lib().aas_lstm_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(cst),
+                                     ptr(sync)), "aas_lstm_fwd")
     else:
         cst = None
-        check(lib().aas_gru_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync)),
-              "aas_gru_fwd")
+        with _timed("rnn", "gru_fwd", rflops):
+            check(lib().aas_gru_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync)),
+                  "aas_gru_fwd")
     return hout, gact, cst
 
 
@@ -215,14 +270,17 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     dy = _c(dy)
     sync = _sync_buf(dev)
     dgx = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
+    rflops = 2.0 * 2 * T * N * H * GH
     if kind == "lstm":
-        check(lib().aas_lstm_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), ptr(dgx),
-                                 ptr(sync)), "aas_lstm_bwd")
+        with _timed("rnn", "lstm_bwd", rflops):
+            check(lib().aas_lstm_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), ptr(dgx),
+                                     ptr(sync)), "aas_lstm_bwd")
         dgh = dgx
     else:
         dgh = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
-        check(lib().aas_gru_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(dgx),
-                                ptr(dgh), ptr(sync)), "aas_gru_bwd")
+        with _timed("rnn", "gru_bwd", rflops):
+            check(lib().aas_gru_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(dgx),
+                                    ptr(dgh), ptr(sync)), "aas_gru_bwd")
     x2 = x.view(T * N, I)
     R = T * N
     dW_ih = torch.empty((GH, I), device=dev, dtype=torch.float32)
