@@ -1,0 +1,106 @@
+"""Utterance-level data parallelism for the AAS step: one process per GPU, RCCL over xGMI through
+``torch.distributed`` (backend "nccl" on ROCm is RCCL; "gloo" for the CPU tests).
+
+The reference has no distributed code; this is new functionality:
+  * the length-sorted global minibatch is sharded by stride (rank r takes utterances r, r+W, ...),
+    padding kept at the global max T so the un-masked L1 sums are exactly the single-process ones;
+  * every loss is normalised by the GLOBAL normaliser (N_global, global nElement) before backward, so a
+    plain SUM all-reduce of the flat E / D (and A, when trainable) gradient buffers is exact;
+  * one small SUM all-reduce of the packed loss scalars gives every rank the same BEGAN kt;
+  * A's BatchNorm uses local-batch statistics ("8 replicas with local-batch BN", documented).
+No data-path collective other than these.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DPContext(object):
+    def __init__(self, world=1, rank=0, group=None):
+        self.world, self.rank, self.group = int(world), int(rank), group
+
+    @classmethod
+    def from_env(cls):
+        if dist.is_available() and dist.is_initialized():
+            return cls(dist.get_world_size(), dist.get_rank())
+        return cls(1, 0)
+
+    @property
+    def active(self):
+        return self.world > 1
+
+    def _dev(self, like=None):
+        if like is not None:
+            return like.device
+        return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+
+    def global_counts(self, values):
+        """SUM over ranks of a short list of integers (N, nElement ...) -> list[int]."""
+        if not self.active:
+            return [int(v) for v in values]
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self._dev())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return [int(round(v)) for v in t.tolist()]
+
+    def allreduce_sum_(self, tensor, async_op=False):
+        """In-place SUM all-reduce of a (flat gradient) buffer; returns a work handle if async."""
+        if not self.active:
+            return None
+        return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def reduce_scalars(self, tensor):
+        if self.active:
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+        return tensor
+
+    # ---- batch sharding ----------------------------------------------------------------------
+    def shard_rows(self, n):
+        return list(range(self.rank, n, self.world))
+
+    def shard_collated(self, data_list):
+        """Shard a `_collate_fn` tuple (inputs, targets, pct, target_sizes, mask) by stride."""
+        if not self.active:
+            return data_list
+        inputs, targets, pct, tsz, mask = data_list
+        rows = self.shard_rows(inputs.size(0))
+        idx = torch.tensor(rows, dtype=torch.long)
+        offs = [0]
+        for s in tsz.tolist():
+            offs.append(offs[-1] + int(s))
+        tg = torch.cat([targets[offs[r]:offs[r + 1]] for r in rows]) if targets is not None and len(rows) else targets
+        m = mask.index_select(0, idx.to(mask.device))
+        m.n_valid = int(m.numel()) - int(m.sum().item())
+        return (inputs.index_select(0, idx.to(inputs.device)), tg, pct.index_select(0, idx), tsz.index_select(0, idx), m)
+
+
+class FlatBuffers(object):
+    """Parameters and gradients of a module re-homed into two flat fp32 buffers (views keep the
+    nn.Parameter API and state_dict keys intact): ONE Adam launch, ONE grad-norm launch and ONE
+    all-reduce per network instead of one per tensor."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters()]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat_p = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        self.slices = []
+        for p in self.params:
+            n = p.numel()
+            self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + n].view_as(p)
+            self.slices.append((off, n))
+            off += n
+        self.bind_grads()
+
+    def bind_grads(self):
+        for p, (off, n) in zip(self.params, self.slices):
+            g = self.flat_g[off:off + n].view_as(p)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        self.bind_grads()

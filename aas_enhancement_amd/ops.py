@@ -117,11 +117,13 @@ def linear_fwd(x2d, W, bias=None):
     return y
 
 
-def linear_bwd(x2d, W, dy, need_dx=True, need_db=False):
+def linear_bwd(x2d, W, dy, need_dx=True, need_db=False, need_dw=True):
     R, K = x2d.shape
     Nn = W.shape[0]
-    dW = torch.empty((Nn, K), device=x2d.device, dtype=torch.float32)
-    gemm(TN, Nn, K, R, dy, Nn, x2d, K, dW, K)
+    dW = None
+    if need_dw:
+        dW = torch.empty((Nn, K), device=x2d.device, dtype=torch.float32)
+        gemm(TN, Nn, K, R, dy, Nn, x2d, K, dW, K)
     dx = None
     if need_dx:
         dx = torch.empty((R, K), device=x2d.device, dtype=torch.float32)
@@ -225,8 +227,9 @@ class _LinearRows(torch.autograd.Function):
     def backward(ctx, gy):
         x2, W2 = ctx.saved_tensors
         gy2 = _c(gy).view(-1, W2.shape[0])
-        dx, dW, db = linear_bwd(x2, W2, gy2, need_dx=ctx.needs_input_grad[0], need_db=ctx.has_b)
-        return (dx.view(ctx.xshape) if dx is not None else None), dW.view(ctx.wshape), db
+        dx, dW, db = linear_bwd(x2, W2, gy2, need_dx=ctx.needs_input_grad[0], need_db=ctx.has_b and ctx.needs_input_grad[2],
+                                need_dw=ctx.needs_input_grad[1])
+        return (dx.view(ctx.xshape) if dx is not None else None), (dW.view(ctx.wshape) if dW is not None else None), db
 
 
 def linear_rows(x, W, b=None):
@@ -261,7 +264,7 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
     return hout, gact, cst
 
 
-def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residual, need_dx=True):
+def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residual, need_dx=True, need_dw=True):
     T, N, I = x.shape
     G = 4 if kind == "lstm" else 3
     H = w_hh.shape[1]
@@ -283,6 +286,13 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
                                     ptr(dgh), ptr(sync)), "aas_gru_bwd")
     x2 = x.view(T * N, I)
     R = T * N
+    if not need_dw:
+        dx = None
+        if need_dx:
+            dx = torch.empty((T, N, I), device=dev, dtype=torch.float32)
+            gemm(NN, R, I, GH, dgx, 2 * GH, w_ih, I, dx, I, addend=dy if residual else None, ldd=I)
+            gemm(NN, R, I, GH, dgx, 2 * GH, w_ih_r, I, dx, I, accumulate=True, a_off=GH)
+        return dx, None, None, None, None
     dW_ih = torch.empty((GH, I), device=dev, dtype=torch.float32)
     dW_ih_r = torch.empty((GH, I), device=dev, dtype=torch.float32)
     gemm(TN, GH, I, R, dgx, 2 * GH, x2, I, dW_ih, I)
@@ -325,7 +335,7 @@ class _BiRNNLayer(torch.autograd.Function):
     def backward(ctx, dy):
         x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst = ctx.saved_tensors
         dx, a, b, c, d = _birnn_bwd(ctx.kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, ctx.residual,
-                                    need_dx=ctx.needs_input_grad[0])
+                                    need_dx=ctx.needs_input_grad[0], need_dw=any(ctx.needs_input_grad[1:5]))
         return dx, a, b, c, d, None, None
 
 
@@ -364,7 +374,7 @@ class _BatchNormRows(torch.autograd.Function):
         wsd = _wsd(x.device, 2 * C)
         check(lib().aas_bn_bwd(stream(), ptr(x), ptr(dy), ptr(dx), R, C, ptr(gamma), ptr(beta), float(ctx.slope),
                                ptr(stats), ptr(dgamma), ptr(dbeta), 0, ptr(wsd)), "aas_bn_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, (dgamma if ctx.needs_input_grad[1] else None), (dbeta if ctx.needs_input_grad[2] else None), None, None, None, None, None
 
 
 def batchnorm_rows(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, slope=1.0):
@@ -411,10 +421,13 @@ class _Conv1dCL(torch.autograd.Function):
         x, W2 = ctx.saved_tensors
         N, T, F, M, KW, T1, stride = ctx.dims
         dy = _c(dy)
-        dW2 = torch.empty((M, KW * F), device=x.device, dtype=torch.float32)
-        gemm(TN, M, KW * F, N * T1, dy, M, x, stride * F, dW2, KW * F, kdivB=T1, kouterB=T * F)
-        dW = _kf_to_w(dW2, F, KW)
-        db = colsum(dy.view(N * T1, M), N * T1, M) if ctx.has_b else None
+        dW = db = None
+        if ctx.needs_input_grad[1]:
+            dW2 = torch.empty((M, KW * F), device=x.device, dtype=torch.float32)
+            gemm(TN, M, KW * F, N * T1, dy, M, x, stride * F, dW2, KW * F, kdivB=T1, kouterB=T * F)
+            dW = _kf_to_w(dW2, F, KW)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = colsum(dy.view(N * T1, M), N * T1, M)
         dx = None
         if ctx.needs_input_grad[0]:
             dcol = torch.empty((N * T1, KW * F), device=x.device, dtype=torch.float32)

@@ -30,3 +30,23 @@ class Adam(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 ops.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], st.get("max_exp_avg_sq"), group["lr"], b1, b2,
                               group["eps"], st["step"], group["amsgrad"], grad_scale)
+
+
+class FlatAdam(object):
+    """Adam(-amsgrad) over a FlatBuffers pair: a single fused HIP launch per network per step."""
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, amsgrad=False):
+        self.flat, self.lr, self.betas, self.eps, self.amsgrad = flat, lr, betas, eps, amsgrad
+        self.step_count = 0
+        self.m = torch.zeros_like(flat.flat_p)
+        self.v = torch.zeros_like(flat.flat_p)
+        self.vmax = torch.zeros_like(flat.flat_p) if amsgrad else None
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        ops.adam_step(self.flat.flat_p, self.flat.flat_g, self.m, self.v, self.vmax, self.lr, self.betas[0],
+                      self.betas[1], self.eps, self.step_count, self.amsgrad, grad_scale)

@@ -22,7 +22,6 @@ from . import ops
 from .ctc import CTCLoss
 from .decoder import GreedyDecoder
 from .model import DeepSpeech, L1Loss_mask, stackedBRNN, supported_rnns
-from .optim import Adam
 from .utils import AverageMeter, _get_variable_nograd, _get_variable_volatile, attach_n_valid
 
 
@@ -60,10 +59,8 @@ class Trainer(object):
             os.makedirs(self.model_dir, exist_ok=True)
             self.logFile = open(self.model_dir + "/log.txt", "w")
         self._opts = None
-        self._gn_acc = None
-
-    def zero_grad_all(self):
-        self.G.zero_grad(); self.D.zero_grad(); self.ASR.zero_grad()
+        self._flat = None
+        self.dp = None
 
     def build_model(self):
         print("initialize enhancement & discriminator model")
@@ -88,37 +85,80 @@ class Trainer(object):
         print("[*] Model loaded")
 
     # ------------------------------------------------------------------------------------------
-    def make_optimizers(self):
+    def asr_frozen(self):
+        """north_star's "frozen A": optimizer_asr never steps when allow_ASR_update_iter >= max_iter (:187)."""
         c = self.config
-        mk = lambda m: Adam(m.parameters(), lr=c.lr, betas=(self.beta1, self.beta2), amsgrad=True)
-        self._opts = (mk(self.G), mk(self.ASR), mk(self.D))
+        return c.allow_ASR_update_iter >= getattr(c, "max_iter", 30000000) - 1
+
+    def make_optimizers(self):
+        """Adam(amsgrad) per network (:127-129) on flat parameter/gradient buffers: one fused HIP launch,
+        one grad-norm launch and (data parallel) one RCCL all-reduce per network."""
+        from .dist import DPContext, FlatBuffers
+        from .optim import FlatAdam
+        c = self.config
+        self.dp = getattr(self, "dp", None) or DPContext.from_env()
+        self._frozen_asr = self.asr_frozen()
+        if self._frozen_asr:
+            for p in self.ASR.parameters():
+                p.requires_grad_(False)  # its gradients are never applied: skip the wgrad GEMMs
+        self._flat = {"G": FlatBuffers(self.G), "D": FlatBuffers(self.D)}
+        if not self._frozen_asr:
+            self._flat["A"] = FlatBuffers(self.ASR)
+        mk = lambda f: FlatAdam(f, lr=c.lr, betas=(self.beta1, self.beta2), amsgrad=True)
+        self._opts = (mk(self._flat["G"]), mk(self._flat["A"]) if "A" in self._flat else None, mk(self._flat["D"]))
         return self._opts
 
+    def zero_grad_all(self):
+        if getattr(self, "_flat", None):
+            for f in self._flat.values():
+                f.zero_grad()
+        else:
+            self.G.zero_grad(); self.D.zero_grad(); self.ASR.zero_grad()
+
     def get_gradient_norm(self, model):
-        """sqrt(sum_p sum grad^2) (:353-361) - one fp64 device accumulator, one kernel per tensor."""
+        """sqrt(sum_p sum grad^2) (:353-361): fp64 device accumulator, one launch on the flat buffer."""
         dev = next(model.parameters()).device
         acc = torch.zeros((1,), device=dev, dtype=torch.float64)
-        for p in model.parameters():
-            if p.grad is not None:
-                ops.sqsum_into(acc, p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+        flat = getattr(self, "_flat", None)
+        key = "G" if model is self.G else ("D" if model is self.D else "A")
+        if flat and key in flat:
+            ops.sqsum_into(acc, flat[key].flat_g)
+        else:
+            for p in model.parameters():
+                if p.grad is not None:
+                    ops.sqsum_into(acc, p.grad if p.grad.is_contiguous() else p.grad.contiguous())
         return acc.sqrt().to(torch.float32)
 
     def _prep(self, data_list):
         inputs, targets, pct, target_sizes, mask = data_list[0], data_list[1], data_list[2], data_list[3], data_list[4]
-        attach_n_valid(mask) if not mask.is_cuda else None
+        if not mask.is_cuda:
+            attach_n_valid(mask)
         return (_get_variable_nograd(inputs), targets, pct, target_sizes, _get_variable_nograd(mask))
 
     def train_step(self, data_list, data_list_cl, iter, log_norms=True):
-        """One iteration of :131-194.  Returns the host scalars the reference logs."""
+        """One iteration of :131-194.  Returns the host scalars the reference logs.
+        Data parallel (world > 1): `data_list*` are this rank's shards; losses are normalised by the
+        global N / nElement so that summed gradients equal the single-process ones."""
         if self._opts is None:
             self.make_optimizers()
         optimizer_g, optimizer_asr, optimizer_d = self._opts
-        c = self.config
+        c, dp = self.config, self.dp
         self.zero_grad_all()
         inputs, targets, input_percentages, target_sizes, mask = self._prep(data_list)
+        cl_inputs, cl_mask = data_list_cl[0], data_list_cl[4]
+        if not cl_mask.is_cuda:
+            attach_n_valid(cl_mask)
+        cl_inputs, cl_mask = _get_variable_nograd(cl_inputs), _get_variable_nograd(cl_mask)
         N = inputs.size(0)
+        if dp.active:
+            nv = lambda m: getattr(m, "n_valid", None) or (int(m.numel()) - int(m.sum().item()))
+            N_glob, nv_ny, nv_cl = dp.global_counts([N, nv(mask), nv(cl_mask)])
+            mask.n_valid, cl_mask.n_valid = nv_ny, nv_cl
+        else:
+            N_glob = N
         enhanced = self.G(inputs)
         g_adv = g_ctc_adv = None
+        handle_d = None
         if self.schedule == "as_executed":
             enhanced_D = enhanced.detach()
             ae_ny_G = self.D(enhanced)
@@ -127,12 +167,22 @@ class Trainer(object):
             l_adv_ny_G.backward(retain_graph=True)
             if log_norms:
                 g_adv = self.get_gradient_norm(self.G)
-            self.D.zero_grad()
+            self._flat["D"].zero_grad()   # == self.D.zero_grad() (:152)
             ae_ny_D = self.D(enhanced_D)
             l_adv_ny_D, _ = self.diffLoss(ae_ny_D, enhanced_D, mask)
             l_adv_ny_D = l_adv_ny_D * (-self.kt) * c.w_adversarial
             l_adv_ny_D.backward()
             del l_adv_ny_D
+            prob = self.ASR(enhanced).transpose(0, 1)
+            sizes = input_percentages.clone().mul_(int(prob.size(0))).int()
+            l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes) / N_glob
+            l_CTC.backward()
+            if log_norms:
+                g_ctc_adv = self.get_gradient_norm(self.G)
+            ae_cl = self.D(cl_inputs)
+            l_adv_cl, _ = self.diffLoss(ae_cl, cl_inputs, cl_mask)
+            l_adv_cl = c.w_adversarial * l_adv_cl
+            l_adv_cl.backward()
         else:
             # E is back-propagated ONCE: both losses are taken on a detached leaf of `enhanced`, their
             # gradients wrt it add up (linear), then a single backward runs through E.  On logging
@@ -146,39 +196,41 @@ class Trainer(object):
                 enhanced.backward(leaf.grad, retain_graph=True)
                 g_adv = self.get_gradient_norm(self.G)
                 leaf.grad = None
-            # D-step == (-kt) x the D-parameter gradients of the G-step (identical forward values)
-            for p in self.D.parameters():
-                if p.grad is not None:
-                    ops.axpby_(p.grad, p.grad, -float(self.kt), 0.0)
-        # CTC loss (:163-172)
-        a_in = enhanced if self.schedule == "as_executed" else leaf
-        prob = self.ASR(a_in)
-        prob = prob.transpose(0, 1)
-        T = prob.size(0)
-        sizes = input_percentages.clone().mul_(int(T)).int()
-        l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes) / N
-        l_CTC.backward()
-        if self.schedule != "as_executed":
+            # D-step == (-kt) x the D-parameter gradients of the G-step (identical forward values, :152-160)
+            ops.axpby_(self._flat["D"].flat_g, self._flat["D"].flat_g, -float(self.kt), 0.0)
+            # clean batch (:174-182) before the acoustic branch so D's gradients are complete early
+            ae_cl = self.D(cl_inputs)
+            l_adv_cl, _ = self.diffLoss(ae_cl, cl_inputs, cl_mask)
+            l_adv_cl = c.w_adversarial * l_adv_cl
+            l_adv_cl.backward()
+            if dp.active:  # D's all-reduce overlaps the acoustic branch and E's backward
+                handle_d = dp.allreduce_sum_(self._flat["D"].flat_g, async_op=True)
+            # CTC loss (:163-172)
+            prob = self.ASR(leaf).transpose(0, 1)
+            sizes = input_percentages.clone().mul_(int(prob.size(0))).int()
+            l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes) / N_glob
+            l_CTC.backward()
             enhanced.backward(leaf.grad)
-        if log_norms:
-            g_ctc_adv = self.get_gradient_norm(self.G)
-        # clean data (:174-182)
-        cl_inputs, cl_mask = data_list_cl[0], data_list_cl[4]
-        attach_n_valid(cl_mask) if not cl_mask.is_cuda else None
-        cl_inputs, cl_mask = _get_variable_nograd(cl_inputs), _get_variable_nograd(cl_mask)
-        ae_cl = self.D(cl_inputs)
-        l_adv_cl, _ = self.diffLoss(ae_cl, cl_inputs, cl_mask)
-        l_adv_cl = c.w_adversarial * l_adv_cl
-        l_adv_cl.backward()
+            if log_norms:
+                g_ctc_adv = self.get_gradient_norm(self.G)
+        # data parallel: SUM all-reduce of the flat gradient buffers (RCCL over xGMI)
+        if dp.active:
+            if handle_d is None:
+                handle_d = dp.allreduce_sum_(self._flat["D"].flat_g, async_op=True)
+            hs = [handle_d, dp.allreduce_sum_(self._flat["G"].flat_g, async_op=True)]
+            if "A" in self._flat and iter > c.allow_ASR_update_iter:
+                hs.append(dp.allreduce_sum_(self._flat["A"].flat_g, async_op=True))
+            for h in hs:
+                h.wait()
         # update (:184-188)
         optimizer_g.step()
         optimizer_d.step()
-        if iter > c.allow_ASR_update_iter:
+        if optimizer_asr is not None and iter > c.allow_ASR_update_iter:
             optimizer_asr.step()
         # one packed device->host read for the three scalars the controller / log need
-        packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), l_CTC.detach().reshape(())]).tolist()
-        l_adv_ny_G_data, l_adv_cl_data, l_ctc_data = packed
-        self.ctc_tr_local.update(l_ctc_data, N)
+        packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), l_CTC.detach().reshape(())])
+        l_adv_ny_G_data, l_adv_cl_data, l_ctc_data = dp.reduce_scalars(packed).tolist()
+        self.ctc_tr_local.update(l_ctc_data, N_glob)
         # Proportional Control Theory (:190-194)
         g_d_balance = self.gamma * l_adv_cl_data - l_adv_ny_G_data
         self.kt += self.lb * g_d_balance

@@ -56,13 +56,29 @@ def make_batches(rank, dev):
     return ny, cl
 
 
+def usable_cores():
+    """CPUs this process may actually use: min(os.cpu_count, affinity mask, cgroup cpu.max quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline():
     """Oracle AAS step (as-executed schedule of trainer_AAS.py:131-194, stock torch CPU kernels) on the same
-    synthetic config-2 batch; one un-warmed... one warm-up-free timed step is ~10-30 s of CPU work."""
+    synthetic config-2 batch: ONE full step (a bounded sample: ~10-30 s of CPU work, no warm-up)."""
     from aas_enhancement_amd import prng
     from oracle import ref_model as RM
     from oracle import ref_step as RS
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     G, D = RM.RefStackedBRNN(F, F, H, 4), RM.RefStackedBRNN(F, F, H, 4)
     A = RM.RefDeepSpeech(nn.GRU, LABELS, HA, 5, 11, 2, M, 2, nFreq=F)
@@ -91,7 +107,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schedule", default="fused")
     ap.add_argument("--profile-gemm", action="store_true", help="also bracket every GEMM launch with HIP events")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -162,10 +182,17 @@ def main():
                                          "tflops": v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12,
                                          "share_of_step": v["total_ms"] / (1000.0 * dt)} for k, v in prof.items()}},
         }
+        out["cpu_baseline"] = None
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        else:
-            out["cpu_baseline"] = None
+            # run in a child process under a hard timeout so a slow host can never hang the bench
+            import subprocess
+            try:
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True,
+                                    text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+                out["cpu_baseline"] = json.loads(cp.stdout.strip().splitlines()[-1])
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": usable_cores(), "kind": "port",
+                                       "sample": "FAILED: %r" % (e,)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
