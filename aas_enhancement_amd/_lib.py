@@ -22,11 +22,13 @@ SIGNATURES = {
     "aas_version": [],
     "aas_last_error": [],
     "aas_device_cus": [],
+    "aas_set_debug_flags": [c_int],
     "aas_gemm_f32": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                      c_int, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_i64],
     "aas_transpose_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64],
     "aas_swap01_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "aas_add3_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64],
+    "aas_scale_rows_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int],
     "aas_axpby_f32": [c_vp, c_vp, c_vp, c_f32, c_f32, c_i64],
     "aas_colsum_f32": [c_vp, c_vp, c_i64, c_int, c_i64, c_vp, c_int],
     "aas_sqsum_f32": [c_vp, c_vp, c_i64, c_vp],

@@ -20,3 +20,10 @@ extern "C" int aas_device_cus(void) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
     return cus;
 }
+
+static int g_debug_flags = 0;
+int aas_debug_flags_value() { return g_debug_flags; }
+extern "C" int aas_set_debug_flags(int flags) {
+    g_debug_flags = flags;
+    return 0;
+}

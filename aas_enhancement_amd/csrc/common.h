@@ -12,6 +12,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 void aas_set_error(const char* fmt, ...);
+int aas_debug_flags_value();
 
 #define AAS_CHECK(cond, ...)            \
     do {                                \

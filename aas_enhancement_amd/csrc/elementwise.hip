@@ -169,6 +169,18 @@ __global__ __launch_bounds__(256) void swap01_kernel(const float* __restrict__ i
     }
 }
 
+// out[(t,n), c] = in[(t,n), c] * scale[n]   (rows are time-major: row = t*Nb + n)
+__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                         const float* __restrict__ scale, int64_t rows, int Nb, int C) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tot = rows * C;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < tot; i += stride) {
+        const int64_t r = i / C;
+        out[i] = in[i] * scale[(int)(r % Nb)];
+    }
+}
+
 inline int grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > MAXB ? MAXB : b));
@@ -190,6 +202,15 @@ extern "C" int aas_swap01_f32(aasStream_t stream, const float* in, float* out, i
     AAS_CHECK(in && out && A > 0 && B > 0 && C > 0, "aas_swap01_f32: bad args");
     hipLaunchKernelGGL(swap01_kernel, dim3(grid_for((int64_t)A * B * C)), dim3(256), 0, (hipStream_t)stream, in, out, A, B, C);
     AAS_LAUNCH_CHECK("aas_swap01_f32");
+    return 0;
+}
+
+extern "C" int aas_scale_rows_f32(aasStream_t stream, float* out, const float* in, const float* scale, int64_t rows,
+                                  int Nb, int C) {
+    AAS_CHECK(out && in && scale && rows >= 0 && Nb > 0 && C > 0, "aas_scale_rows_f32: bad args");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, out, in, scale, rows, Nb, C);
+    AAS_LAUNCH_CHECK("aas_scale_rows_f32");
     return 0;
 }
 

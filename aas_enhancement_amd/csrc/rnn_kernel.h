@@ -42,6 +42,7 @@ struct RnnP {
     unsigned* sync;
     int P, Q;
     int n0, n1;          // batch rows [n0, n1) handled by this launch
+    int flags;           // debug/ablation bits (aas_set_debug_flags): 1 no exchange loads, 2 no MFMA, 4 no wait, 8 no publish
 };
 
 __device__ __forceinline__ unsigned ld_cnt(const unsigned* p) {
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
         const int tp = FWD ? (d == 0 ? t - 1 : t + 1) : (d == 0 ? t + 1 : t - 1);  // step processed before this one
 
         // ---- prefetch the step's private inputs (independent of the exchange) ----------------
-        float pin[EPT][4];
+        float pin[EPT][4];   // fwd: input projections of the G gates; bwd: [0] = dy
+        float sav[EPT][6];   // bwd: saved gate activations [0..3], cell / previous-state values [4..5]
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
             const int idx = tid + i * 256;
@@ -163,13 +165,29 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
             const bool ok = (idx < ROWS * U) && gr < NB && unit < H;
 #pragma unroll
             for (int g = 0; g < 4; ++g) pin[i][g] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 6; ++g) sav[i][g] = 0.f;
             if (ok) {
+                const int64_t tn = (int64_t)t * N + gr;
                 if (FWD) {
-                    const float* pp = p.pre + (((int64_t)t * N + gr) * 2 + d) * GH + unit;
+                    const float* pp = p.pre + (tn * 2 + d) * GH + unit;
 #pragma unroll
                     for (int g = 0; g < G; ++g) pin[i][g] = pp[g * H];
                 } else {
-                    pin[i][0] = p.dy[((int64_t)t * N + gr) * H + unit];
+                    pin[i][0] = p.dy[tn * H + unit];
+                    const float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) sav[i][g] = ga[g * H];
+                    // state at the previous time step IN FORWARD ORDER: t-1 for d=0, t+1 for d=1 (zero at the start)
+                    const int tq = (d == 0) ? t - 1 : t + 1;
+                    const bool hasq = (tq >= 0 && tq < T);
+                    const int64_t qn = ((int64_t)d * T * N + (int64_t)tq * N + gr) * H + unit;
+                    if (LSTM) {
+                        sav[i][4] = p.cst[((int64_t)d * T * N + tn) * H + unit];
+                        sav[i][5] = hasq ? p.cst[qn] : 0.f;
+                    } else {
+                        sav[i][5] = hasq ? p.hout[qn] : 0.f;
+                    }
                 }
             }
         }
@@ -181,8 +199,10 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            if (tid == 0) wait_counter(cnt, (unsigned)p.P * (unsigned)s, err);
-            __syncthreads();
+            if (!(p.flags & 4)) {
+                if (tid == 0) wait_counter(cnt, (unsigned)p.P * (unsigned)s, err);
+                __syncthreads();
+            }
             const int m = lane & 15, q = lane >> 4;
             // element offset of row 0 of the previous step's vector
             const int64_t rbase = FWD ? ((int64_t)d * T + tp) * N * H : ((int64_t)tp * N * 2 + d) * GH;
@@ -195,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
                     const int gr = q0 + mt * 16 + m;
                     const int k = kb + ks * 16 + q * 4;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (gr < NB && k < Kx) {
+                    if (gr < NB && k < Kx && !(p.flags & 1)) {
                         const int64_t off = (rbase + (int64_t)gr * rstride + k) * 4;
                         if (VEC) {
                             v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 16));
@@ -209,6 +229,7 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
                     }
                     a[mt] = v;
                 }
+                if (!(p.flags & 2))
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -271,12 +292,8 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
                 ga[0] = rg; ga[H] = zg; ga[2 * H] = ng; ga[3 * H] = hn;
             } else if (MODE == LSTM_BWD) {
                 const float dh = pin[i][0] + rs[0];
-                const float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
-                const float ig = ga[0], fg = ga[H], gg = ga[2 * H], og = ga[3 * H];
-                const float c = p.cst[((int64_t)d * T * N + tn) * H + unit];
-                // c_{prev in forward order}: t-1 for d=0, t+1 for d=1 (zero at the sequence start)
-                const int tq = (d == 0) ? t - 1 : t + 1;
-                const float cp = (tq >= 0 && tq < T) ? p.cst[((int64_t)d * T * N + (int64_t)tq * N + gr) * H + unit] : 0.f;
+                const float ig = sav[i][0], fg = sav[i][1], gg = sav[i][2], og = sav[i][3];
+                const float c = sav[i][4], cp = sav[i][5];
                 const float tc = tanhf_(c);
                 const float dc = dh * og * (1.f - tc * tc) + carry[i];
                 carry[i] = dc * fg;
@@ -287,10 +304,8 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
                 st_sc1(dg + 3 * H, dh * tc * og * (1.f - og));
             } else {  // GRU_BWD
                 const float dh = pin[i][0] + rs[0] + carry[i];
-                const float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
-                const float rg = ga[0], zg = ga[H], ng = ga[2 * H], hn = ga[3 * H];
-                const int tq = (d == 0) ? t - 1 : t + 1;
-                const float hp = (tq >= 0 && tq < T) ? p.hout[((int64_t)d * T * N + (int64_t)tq * N + gr) * H + unit] : 0.f;
+                const float rg = sav[i][0], zg = sav[i][1], ng = sav[i][2], hn = sav[i][3];
+                const float hp = sav[i][5];
                 carry[i] = dh * zg;
                 const float dnp = dh * (1.f - zg) * (1.f - ng * ng);
                 const float dzp = dh * (hp - ng) * zg * (1.f - zg);
@@ -304,9 +319,9 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
             }
         }
         // ---- publish: drain this wave's stores, workgroup barrier, one arrival per workgroup ---
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(p.flags & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && !(p.flags & 8)) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -344,6 +359,7 @@ int run(const char* name, RnnP p, hipStream_t s) {
     AAS_CHECK(p.T >= 1 && p.N >= 1 && p.H >= 1, "%s: bad sizes T=%d N=%d H=%d", name, p.T, p.N, p.H);
     const int cus = aas_device_cus();
     AAS_CHECK(cus > 0, "%s: no HIP device", name);
+    p.flags = aas_debug_flags_value();
     p.P = cdiv(p.H, C::U);
     AAS_CHECK(p.P * 2 <= cus, "%s: H=%d needs %d resident workgroups, device has %d CUs", name, p.H, p.P * 2, cus);
     const int kx = FWD ? p.H : C::G * p.H;

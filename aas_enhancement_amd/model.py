@@ -62,9 +62,9 @@ class _RNNWeights(nn.Module):
     def flatten_parameters(self):
         pass
 
-    def run(self, x, residual):
+    def run(self, x, residual, rs=None):
         return ops.birnn_layer(x, self.weight_ih_l0, self.weight_hh_l0, self.weight_ih_l0_reverse,
-                               self.weight_hh_l0_reverse, self.kind, residual)
+                               self.weight_hh_l0_reverse, self.kind, residual, rs)
 
 
 class _BNParams(nn.Module):
@@ -138,8 +138,8 @@ class BRNN(nn.Module):
     def flatten_parameters(self):
         pass
 
-    def forward(self, x, residual=False):
-        return self.rnn.run(x, residual=residual)
+    def forward(self, x, residual=False, wgrad_row_scale=None):
+        return self.rnn.run(x, residual=residual, rs=wgrad_row_scale)
 
 
 class _PointwiseConv(nn.Module):
@@ -168,16 +168,19 @@ class stackedBRNN(nn.Module):
         self.first_linear = _PointwiseConv(I, H)
         self.final_linear = _PointwiseConv(H, O)
 
-    def _trunk(self, input):
+    def _trunk(self, input, rs=None):
         h = ops.layout(input, "nct_tnc")                                  # [N,I,T] -> [T,N,I]
-        h = ops.linear_rows(h, self.first_linear.weight, self.first_linear.bias)
+        h = ops.linear_rows(h, self.first_linear.weight, self.first_linear.bias, rs)
         for l in range(1, self.L + 1):
-            h = getattr(self, "rnn%d" % l)(h, residual=True)             # BRNN(h) + h
+            h = getattr(self, "rnn%d" % l)(h, residual=True, wgrad_row_scale=rs)   # BRNN(h) + h
         return h
 
-    def forward(self, input):
-        h = self._trunk(input)
-        out = ops.linear_rows(h, self.final_linear.weight, self.final_linear.bias)
+    def forward(self, input, wgrad_row_scale=None):
+        """`wgrad_row_scale` [N] (extension, default None = reference behaviour): per-utterance weights applied to
+        the PARAMETER gradients only (input gradients are unaffected) - lets D(enhanced) and D(clean) share one
+        batched pass while the enhanced half's parameter gradients carry the BEGAN factor (-kt)."""
+        h = self._trunk(input, wgrad_row_scale)
+        out = ops.linear_rows(h, self.final_linear.weight, self.final_linear.bias, wgrad_row_scale)
         return ops.layout(out, "tnc_nct")                                 # [T,N,O] -> [N,O,T]
 
     def forward_paired(self, input, paired):

@@ -149,6 +149,15 @@ def add3(a, b, c=None):
     return out
 
 
+def scale_rows(x, scale, nb, out=None):
+    """out[(t,n), :] = x[(t,n), :] * scale[n] (time-major rows); out=None -> new tensor, out=x -> in place."""
+    C = x.shape[-1] if x.dim() == 2 else x.numel() // (x.shape[0] * x.shape[1])
+    rows = x.numel() // C
+    out = torch.empty_like(x) if out is None else out
+    check(lib().aas_scale_rows_f32(stream(), ptr(out), ptr(x), ptr(scale), rows, nb, C), "aas_scale_rows_f32")
+    return out
+
+
 def axpby_(y, x, alpha, beta):
     check(lib().aas_axpby_f32(stream(), ptr(y), ptr(x), float(alpha), float(beta), y.numel()), "aas_axpby_f32")
     return y
@@ -211,13 +220,14 @@ class _LinearRows(torch.autograd.Function):
     """y[..., N] = x[..., K] W[N,K]^T (+ b) on the flattened leading dims."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, rs=None):
         require_cuda(x, W)
         x = _c(x)
         W2 = _c(W).view(W.shape[0], -1)
         x2 = x.view(-1, x.shape[-1])
         y = linear_fwd(x2, W2, _c(b) if b is not None else None)
         ctx.save_for_backward(x2, W2)
+        ctx.rs, ctx.nb = rs, (x.shape[1] if x.dim() == 3 else 1)
         ctx.wshape = W.shape
         ctx.has_b = b is not None
         ctx.xshape = x.shape
@@ -227,13 +237,19 @@ class _LinearRows(torch.autograd.Function):
     def backward(ctx, gy):
         x2, W2 = ctx.saved_tensors
         gy2 = _c(gy).view(-1, W2.shape[0])
-        dx, dW, db = linear_bwd(x2, W2, gy2, need_dx=ctx.needs_input_grad[0], need_db=ctx.has_b and ctx.needs_input_grad[2],
-                                need_dw=ctx.needs_input_grad[1])
-        return (dx.view(ctx.xshape) if dx is not None else None), (dW.view(ctx.wshape) if dW is not None else None), db
+        if ctx.rs is None:
+            dx, dW, db = linear_bwd(x2, W2, gy2, need_dx=ctx.needs_input_grad[0], need_db=ctx.has_b and ctx.needs_input_grad[2],
+                                    need_dw=ctx.needs_input_grad[1])
+        else:  # per-utterance weights on the parameter gradients only
+            dx, _, _ = linear_bwd(x2, W2, gy2, need_dx=ctx.needs_input_grad[0], need_db=False, need_dw=False)
+            gys = scale_rows(gy2, ctx.rs, ctx.nb)
+            _, dW, db = linear_bwd(x2, W2, gys, need_dx=False, need_db=ctx.has_b and ctx.needs_input_grad[2],
+                                   need_dw=ctx.needs_input_grad[1])
+        return (dx.view(ctx.xshape) if dx is not None else None), (dW.view(ctx.wshape) if dW is not None else None), db, None
 
 
-def linear_rows(x, W, b=None):
-    return _LinearRows.apply(x, W, b)
+def linear_rows(x, W, b=None, rs=None):
+    return _LinearRows.apply(x, W, b, rs)
 
 
 # --------------------------------------------------------------------------------------- RNN layers
@@ -264,7 +280,7 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
     return hout, gact, cst
 
 
-def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residual, need_dx=True, need_dw=True):
+def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residual, need_dx=True, need_dw=True, rs=None):
     T, N, I = x.shape
     G = 4 if kind == "lstm" else 3
     H = w_hh.shape[1]
@@ -286,13 +302,17 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
                                     ptr(dgh), ptr(sync)), "aas_gru_bwd")
     x2 = x.view(T * N, I)
     R = T * N
+    dx = None
+    if need_dx:
+        dx = torch.empty((T, N, I), device=dev, dtype=torch.float32)
+        gemm(NN, R, I, GH, dgx, 2 * GH, w_ih, I, dx, I, addend=dy if residual else None, ldd=I)
+        gemm(NN, R, I, GH, dgx, 2 * GH, w_ih_r, I, dx, I, accumulate=True, a_off=GH)
     if not need_dw:
-        dx = None
-        if need_dx:
-            dx = torch.empty((T, N, I), device=dev, dtype=torch.float32)
-            gemm(NN, R, I, GH, dgx, 2 * GH, w_ih, I, dx, I, addend=dy if residual else None, ldd=I)
-            gemm(NN, R, I, GH, dgx, 2 * GH, w_ih_r, I, dx, I, accumulate=True, a_off=GH)
         return dx, None, None, None, None
+    if rs is not None:  # per-utterance weights on the parameter gradients only (after dx used the unscaled d(gates))
+        scale_rows(dgx, rs, N, out=dgx)
+        if dgh is not dgx:
+            scale_rows(dgh, rs, N, out=dgh)
     dW_ih = torch.empty((GH, I), device=dev, dtype=torch.float32)
     dW_ih_r = torch.empty((GH, I), device=dev, dtype=torch.float32)
     gemm(TN, GH, I, R, dgx, 2 * GH, x2, I, dW_ih, I)
@@ -308,11 +328,6 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     else:
         dW_hh.zero_()
         dW_hh_r.zero_()
-    dx = None
-    if need_dx:
-        dx = torch.empty((T, N, I), device=dev, dtype=torch.float32)
-        gemm(NN, R, I, GH, dgx, 2 * GH, w_ih, I, dx, I, addend=dy if residual else None, ldd=I)
-        gemm(NN, R, I, GH, dgx, 2 * GH, w_ih_r, I, dx, I, accumulate=True, a_off=GH)
     return dx, dW_ih, dW_hh, dW_ih_r, dW_hh_r
 
 
@@ -321,8 +336,9 @@ class _BiRNNLayer(torch.autograd.Function):
     (reference model.py:80-86,101-105 and the residual adds at :223-226)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual):
+    def forward(ctx, x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual, rs=None):
         require_cuda(x, w_ih, w_hh)
+        ctx.rs = rs
         x = _c(x)
         w_ih, w_hh, w_ih_r, w_hh_r = _c(w_ih), _c(w_hh), _c(w_ih_r), _c(w_hh_r)
         hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r)
@@ -335,12 +351,12 @@ class _BiRNNLayer(torch.autograd.Function):
     def backward(ctx, dy):
         x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst = ctx.saved_tensors
         dx, a, b, c, d = _birnn_bwd(ctx.kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, ctx.residual,
-                                    need_dx=ctx.needs_input_grad[0], need_dw=any(ctx.needs_input_grad[1:5]))
-        return dx, a, b, c, d, None, None
+                                    need_dx=ctx.needs_input_grad[0], need_dw=any(ctx.needs_input_grad[1:5]), rs=ctx.rs)
+        return dx, a, b, c, d, None, None, None
 
 
-def birnn_layer(x, w_ih, w_hh, w_ih_r, w_hh_r, kind="lstm", residual=False):
-    return _BiRNNLayer.apply(x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual)
+def birnn_layer(x, w_ih, w_hh, w_ih_r, w_hh_r, kind="lstm", residual=False, rs=None):
+    return _BiRNNLayer.apply(x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual, rs)
 
 
 # --------------------------------------------------------------------------------------- batch norm

@@ -188,21 +188,35 @@ class Trainer(object):
             # gradients wrt it add up (linear), then a single backward runs through E.  On logging
             # iterations g_adv needs E's adversarial-only gradients, so E is back-propagated per loss.
             leaf = enhanced.detach().requires_grad_(True)
-            ae_ny_G = self.D(leaf)
-            l_adv_ny_G, _ = self.diffLoss(ae_ny_G, leaf, mask)
-            l_adv_ny_G = l_adv_ny_G * c.w_adversarial
-            l_adv_ny_G.backward()
+            Nn = leaf.size(0)
+            if tuple(cl_inputs.shape[1:]) == tuple(leaf.shape[1:]):
+                # D(enhanced) and D(clean) share ONE batched pass (rows are independent: D has no batch
+                # statistics).  The D-step gradients of the enhanced half are (-kt) x its G-step parameter
+                # gradients (:152-160), applied as per-utterance weights on the weight-gradient products only,
+                # so the gradient flowing back to `enhanced` stays the G-step one.
+                rs = torch.empty(Nn + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
+                rs[:Nn] = -float(self.kt)
+                rs[Nn:] = 1.0
+                ae = self.D(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
+                l_adv_ny_G, _ = self.diffLoss(ae[:Nn], leaf, mask)
+                l_adv_cl, _ = self.diffLoss(ae[Nn:], cl_inputs, cl_mask)
+                l_adv_ny_G = l_adv_ny_G * c.w_adversarial
+                l_adv_cl = c.w_adversarial * l_adv_cl
+                (l_adv_ny_G + l_adv_cl).backward()
+            else:  # different padded lengths: two D passes, D-step = (-kt) x G-step parameter gradients
+                ae_ny_G = self.D(leaf)
+                l_adv_ny_G, _ = self.diffLoss(ae_ny_G, leaf, mask)
+                l_adv_ny_G = l_adv_ny_G * c.w_adversarial
+                l_adv_ny_G.backward()
+                ops.axpby_(self._flat["D"].flat_g, self._flat["D"].flat_g, -float(self.kt), 0.0)
+                ae_cl = self.D(cl_inputs)
+                l_adv_cl, _ = self.diffLoss(ae_cl, cl_inputs, cl_mask)
+                l_adv_cl = c.w_adversarial * l_adv_cl
+                l_adv_cl.backward()
             if log_norms:
                 enhanced.backward(leaf.grad, retain_graph=True)
                 g_adv = self.get_gradient_norm(self.G)
                 leaf.grad = None
-            # D-step == (-kt) x the D-parameter gradients of the G-step (identical forward values, :152-160)
-            ops.axpby_(self._flat["D"].flat_g, self._flat["D"].flat_g, -float(self.kt), 0.0)
-            # clean batch (:174-182) before the acoustic branch so D's gradients are complete early
-            ae_cl = self.D(cl_inputs)
-            l_adv_cl, _ = self.diffLoss(ae_cl, cl_inputs, cl_mask)
-            l_adv_cl = c.w_adversarial * l_adv_cl
-            l_adv_cl.backward()
             if dp.active:  # D's all-reduce overlaps the acoustic branch and E's backward
                 handle_d = dp.allreduce_sum_(self._flat["D"].flat_g, async_op=True)
             # CTC loss (:163-172)

@@ -29,6 +29,9 @@ int aas_version(void);
 const char* aas_last_error(void);
 /* number of CUs of the current device (persistent recurrent kernels size their grids from it) */
 int aas_device_cus(void);
+/* ablation bits for the persistent RNN kernels (profiling only; results are wrong when non-zero):
+ * 1 skip exchange loads, 2 skip MFMA, 4 skip arrival wait, 8 skip publish (drain + arrival). */
+int aas_set_debug_flags(int flags);
 
 /* ---------------------------------------------------------------- dense linear algebra --------
  * fp32 MFMA GEMM  C = op(A) op(B) [+ bias broadcast over rows] [+ addend] [+ C if accumulate].
@@ -60,6 +63,10 @@ int aas_transpose_f32(aasStream_t stream, const float* in, float* out, int B, in
 int aas_swap01_f32(aasStream_t stream, const float* in, float* out, int A, int B, int C);
 /* out = a + b (+ c if c != NULL), n elements.  Direction sum + residual (model.py:85,104,223-226). */
 int aas_add3_f32(aasStream_t stream, float* out, const float* a, const float* b, const float* c, int64_t n);
+/* out[(t,n), :] = in[(t,n), :] * scale[n] for time-major rows (row = t*Nb + n); out may alias in.
+ * Per-utterance weighting of the weight-gradient products when D(enhanced) and D(clean) share one
+ * batched pass: parameter gradients of the enhanced half carry (-kt) (trainer_AAS.py:152-160). */
+int aas_scale_rows_f32(aasStream_t stream, float* out, const float* in, const float* scale, int64_t rows, int Nb, int C);
 /* y = alpha * x + beta * y  (gradient scaling / accumulation; y may alias x) */
 int aas_axpby_f32(aasStream_t stream, float* y, const float* x, float alpha, float beta, int64_t n);
 /* out[c] (+)= sum_r x[r, c]   (bias gradients) */

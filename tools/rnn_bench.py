@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Micro-benchmark / ablation of the persistent RNN kernels and GEMM shapes of the AAS step (GPU box only).
+    python tools/rnn_bench.py [--flags 0,1,2,...]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from aas_enhancement_amd import _lib, ops
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def rnn_case(kind, T, N, H):
+    G = 4 if kind == "lstm" else 3
+    dev = "cuda"
+    x = torch.randn(T, N, H, device=dev) * 0.5
+    w = [torch.randn(G * H, H, device=dev) / H ** 0.5 for _ in range(4)]
+    hout, gact, cst = ops._birnn_fwd(kind, x, *w)
+    dy = torch.randn(T, N, H, device=dev)
+    L = _lib.lib()
+    sync = ops._sync_buf(x.device)
+    pre = torch.randn(T, N, 2, G * H, device=dev)
+    dgx = torch.empty(T, N, 2, G * H, device=dev)
+    dgh = torch.empty(T, N, 2, G * H, device=dev)
+    s = _lib.stream()
+    p = _lib.ptr
+    if kind == "lstm":
+        f = lambda: L.aas_lstm_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(cst), p(sync))
+        b = lambda: L.aas_lstm_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(gact), p(cst), p(dgx), p(sync))
+    else:
+        f = lambda: L.aas_gru_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(sync))
+        b = lambda: L.aas_gru_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(hout), p(gact), p(dgx), p(dgh), p(sync))
+    return f, b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--flags", default="0")
+    ap.add_argument("--gemm", action="store_true")
+    a = ap.parse_args()
+    L = _lib.lib()
+    cases = [("lstm", 200, 30, 500), ("gru", 85, 30, 1000), ("lstm", 200, 60, 500)]
+    for kind, T, N, H in cases:
+        f, b = rnn_case(kind, T, N, H)
+        for fl in [int(v) for v in a.flags.split(",")]:
+            L.aas_set_debug_flags(fl)
+            tf, tb = timeit(f), timeit(b)
+            print("%s T=%d N=%d H=%d flags=%2d  fwd %.3f ms (%.2f us/step)  bwd %.3f ms (%.2f us/step)" % (kind, T, N, H, fl, tf, 1e3 * tf / T, tb, 1e3 * tb / T), flush=True)
+        L.aas_set_debug_flags(0)
+    torch.cuda.synchronize()
+    assert not ops.rnn_timeout_flag() or a.flags != "0", "timeout flag set"
+    if a.gemm:
+        shapes = [("NT pre", ops.NT, 6000, 2000, 500), ("NN dx", ops.NN, 6000, 500, 2000), ("TN dWih", ops.TN, 2000, 500, 6000),
+                  ("NT gru pre", ops.NT, 2550, 3000, 1000), ("NN gru dx", ops.NN, 2550, 1000, 3000), ("TN gru dW", ops.TN, 3000, 1000, 2550),
+                  ("NT first", ops.NT, 6000, 500, 80), ("NT final", ops.NT, 6000, 80, 500), ("NT big", ops.NT, 8192, 8192, 1024)]
+        for name, mode, M, N, K in shapes:
+            if mode == ops.NT:
+                A, B = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda"); lda, ldb = K, K
+            elif mode == ops.NN:
+                A, B = torch.randn(M, K, device="cuda"), torch.randn(K, N, device="cuda"); lda, ldb = K, N
+            else:
+                A, B = torch.randn(K, M, device="cuda"), torch.randn(K, N, device="cuda"); lda, ldb = M, N
+            C = torch.empty(M, N, device="cuda")
+            t = timeit(lambda: ops.gemm(mode, M, N, K, A, lda, B, ldb, C, N), n=10)
+            print("gemm %-12s M=%5d N=%5d K=%5d  %.3f ms  %.1f TFLOP/s" % (name, M, N, K, t, 2.0 * M * N * K / t / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    main()
