@@ -27,3 +27,15 @@ extern "C" int aas_set_debug_flags(int flags) {
     g_debug_flags = flags;
     return 0;
 }
+
+// 0 = exact fp32 MFMA everywhere; 1 = split-bf16 (hi/lo, 3 MFMAs) operands in the GEMMs
+static int g_precision = 1;
+int aas_precision_value() { return g_precision; }
+extern "C" int aas_set_precision(int mode) {
+    if (mode < 0 || mode > 1) {
+        aas_set_error("aas_set_precision: mode must be 0 (fp32) or 1 (split-bf16)");
+        return 1;
+    }
+    g_precision = mode;
+    return 0;
+}

@@ -189,6 +189,231 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
         }
 }
 
+
+// =================================================================================================
+// Split-bf16 ("bf16x3") GEMM: every fp32 operand x is staged in LDS as hi = bf16(trunc x) and
+// lo = bf16(x - hi); C += Ah*Bh + Al*Bh + Ah*Bl on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+// Dropped term Al*Bl ~ 2^-16 relative: fp32-class accuracy (~1e-5 rel) at 3/16 of the fp32-MFMA
+// issue time.  Tile 128x128x32, 4 waves (2x2) of 64x64, LDS rows of 32 bf16 padded to 80 B
+// (conflict-free ds_read_b128), register-prefetched double buffering.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SBK = 32;          // k per stage
+constexpr int SROW = 80;         // bytes per LDS row (32 bf16 + 16 B pad)
+constexpr int SARR = 128 * SROW; // bytes per (operand, hi|lo) array
+
+// split 4 floats -> packed hi (2 dwords) and lo (2 dwords)
+__device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, v.x), u1 = __builtin_bit_cast(unsigned, v.y);
+    const unsigned u2 = __builtin_bit_cast(unsigned, v.z), u3 = __builtin_bit_cast(unsigned, v.w);
+    const unsigned h0 = u0 & 0xFFFF0000u, h1 = u1 & 0xFFFF0000u, h2 = u2 & 0xFFFF0000u, h3 = u3 & 0xFFFF0000u;
+    hi.x = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+    hi.y = __builtin_amdgcn_perm(h3, h2, 0x07060302u);
+    const bf16x2 l01 = {(__bf16)(v.x - __builtin_bit_cast(float, h0)), (__bf16)(v.y - __builtin_bit_cast(float, h1))};
+    const bf16x2 l23 = {(__bf16)(v.z - __builtin_bit_cast(float, h2)), (__bf16)(v.w - __builtin_bit_cast(float, h3))};
+    lo.x = __builtin_bit_cast(unsigned, l01);
+    lo.y = __builtin_bit_cast(unsigned, l23);
+}
+
+// k-contiguous operand: tile [128 rows][32 k]; 4 float4 per thread (row = idx>>3, kq = idx&7)
+template <bool VEC>
+__device__ __forceinline__ void sload_kc(const float* __restrict__ base, int64_t ld, int row0, int rmax, int k0, int kend,
+                                         int tid, f32x4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx >> 3, kq = idx & 7;
+        const int gr = row0 + row, gk = k0 + kq * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < rmax) {
+            const float* p = base + (int64_t)gr * ld + gk;
+            if (VEC) {
+                if (gk < kend) v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+                if (gk + 0 < kend) v.x = p[0];
+                if (gk + 1 < kend) v.y = p[1];
+                if (gk + 2 < kend) v.z = p[2];
+                if (gk + 3 < kend) v.w = p[3];
+            }
+        }
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void sstore_kc(char* hi, char* lo, int tid, const f32x4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx >> 3, kq = idx & 7;
+        u32x2 h, l;
+        split4(r[i], h, l);
+        *reinterpret_cast<u32x2*>(hi + row * SROW + kq * 8) = h;
+        *reinterpret_cast<u32x2*>(lo + row * SROW + kq * 8) = l;
+    }
+}
+// row-contiguous operand ([K, cols]): each thread loads a 4(k) x 4(col) micro-tile (4 float4 from 4
+// consecutive k rows), transposes it in registers and stores, per column, 4 consecutive k as 8 B.
+template <bool VEC>
+__device__ __forceinline__ void sload_rc(const float* __restrict__ base, int64_t ld, int kdiv, int64_t kouter, int c0,
+                                         int cmax, int k0, int kend, int tid, f32x4 (&r)[4]) {
+    const int kg = tid >> 5, cq = tid & 31;  // 8 k-groups x 32 column quads
+    const int gc = c0 + cq * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gk = k0 + kg * 4 + i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gk < kend) {
+            const float* p = base + krow_addr(gk, kdiv, kouter, ld) + gc;
+            if (VEC) {
+                if (gc < cmax) v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+                if (gc + 0 < cmax) v.x = p[0];
+                if (gc + 1 < cmax) v.y = p[1];
+                if (gc + 2 < cmax) v.z = p[2];
+                if (gc + 3 < cmax) v.w = p[3];
+            }
+        }
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void sstore_rc(char* hi, char* lo, int tid, const f32x4 (&r)[4]) {
+    const int kg = tid >> 5, cq = tid & 31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // column cq*4 + j gets k = kg*4 .. kg*4+3
+        const f32x4 col = {r[0][j], r[1][j], r[2][j], r[3][j]};
+        u32x2 h, l;
+        split4(col, h, l);
+        const int row = cq * 4 + j;
+        *reinterpret_cast<u32x2*>(hi + row * SROW + kg * 8) = h;
+        *reinterpret_cast<u32x2*>(lo + row * SROW + kg * 8) = l;
+    }
+}
+
+template <bool A_KC, bool B_KC, bool VECA, bool VECB>
+__global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A_hi, A_lo, B_hi, B_lo][128][80 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int z = blockIdx.z;
+    const float* A = p.A;
+    const float* B = p.B;
+    float* C = p.C;
+    const float* addend = p.addend;
+    int kbeg = 0, kend = p.K;
+    if (p.splitk > 1) {
+        int ktiles = (p.K + SBK - 1) / SBK;
+        int per = (ktiles + p.splitk - 1) / p.splitk;
+        kbeg = z * per * SBK;
+        kend = min(p.K, (z + 1) * per * SBK);
+        if (kbeg >= kend) return;
+    } else if (p.batch > 1) {
+        A += (int64_t)z * p.sA;
+        B += (int64_t)z * p.sB;
+        C += (int64_t)z * p.sC;
+        if (addend) addend += (int64_t)z * p.sC;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+        if (A_KC) sload_kc<VECA>(A, p.lda, m0, p.M, k0, kend, tid, ra);
+        else sload_rc<VECA>(A, p.lda, p.kdivA, p.kouterA, m0, p.M, k0, kend, tid, ra);
+        if (B_KC) sload_kc<VECB>(B, p.ldb, n0, p.N, k0, kend, tid, rb);
+        else sload_rc<VECB>(B, p.ldb, p.kdivB, p.kouterB, n0, p.N, k0, kend, tid, rb);
+    };
+    auto sstore = [&](int buf) {
+        char* st = smem + buf * 4 * SARR;
+        if (A_KC) sstore_kc(st, st + SARR, tid, ra); else sstore_rc(st, st + SARR, tid, ra);
+        if (B_KC) sstore_kc(st + 2 * SARR, st + 3 * SARR, tid, rb); else sstore_rc(st + 2 * SARR, st + 3 * SARR, tid, rb);
+    };
+    gload(kbeg);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int k0 = kbeg; k0 < kend; k0 += SBK) {
+        const bool more = (k0 + SBK) < kend;
+        if (more) gload(k0 + SBK);
+        const char* st = smem + buf * 4 * SARR;
+#pragma unroll
+        for (int kk = 0; kk < SBK; kk += 16) {
+            // A operand of 32x32x16: lane (row l&31, half l>>5) holds k = 8*half + j; same map for B columns
+            const int ko = (kk + lh * 8) * 2;
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ra_ = (wm * 64 + t * 32 + l31) * SROW + ko;
+                const int rb_ = (wn * 64 + t * 32 + l31) * SROW + ko;
+                ah[t] = *reinterpret_cast<const bf16x8*>(st + ra_);
+                al[t] = *reinterpret_cast<const bf16x8*>(st + SARR + ra_);
+                bh[t] = *reinterpret_cast<const bf16x8*>(st + 2 * SARR + rb_);
+                bl[t] = *reinterpret_cast<const bf16x8*>(st + 3 * SARR + rb_);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const bool first = (p.splitk <= 1) || (z == 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            int n = n0 + wn * 64 + nt * 32 + l31;
+            if (n >= p.N) continue;
+            float bv = (p.bias && first) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[mt][nt][r] + bv;
+                if (addend && first) v += addend[(int64_t)m * p.ldd + n];
+                float* cp = C + (int64_t)m * p.ldc + n;
+                if (p.splitk > 1) atomicAdd(cp, v);
+                else if (p.accumulate) *cp += v;
+                else *cp = v;
+            }
+        }
+}
+
+constexpr int SPLIT_LDS = 2 * 4 * SARR;  // 81920 B
+
+template <bool A_KC, bool B_KC>
+int launch_split(const GemmP& p, bool va, bool vb, dim3 grid, hipStream_t s) {
+#define AAS_SPLIT_LAUNCH(VA, VB)                                                                              \
+    do {                                                                                                      \
+        static bool attr_set = false;                                                                         \
+        auto kfn = gemm_split_kernel<A_KC, B_KC, VA, VB>;                                                     \
+        if (!attr_set) {                                                                                      \
+            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS) != hipSuccess) return 3; \
+            attr_set = true;                                                                                  \
+        }                                                                                                     \
+        hipLaunchKernelGGL(kfn, grid, dim3(256), SPLIT_LDS, s, p);                                            \
+    } while (0)
+    if (va && vb) AAS_SPLIT_LAUNCH(true, true);
+    else if (va) AAS_SPLIT_LAUNCH(true, false);
+    else if (vb) AAS_SPLIT_LAUNCH(false, true);
+    else AAS_SPLIT_LAUNCH(false, false);
+#undef AAS_SPLIT_LAUNCH
+    return 0;
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <bool A_KC, bool B_KC>
@@ -239,20 +464,26 @@ extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, c
         }
     }
     bool va, vb;
+    const bool split = aas_precision_value() != 0;
+    int rc = 0;
     if (mode == AAS_GEMM_TN) {
         va = al16(A) && lda % 4 == 0 && M % 4 == 0 && (kdivA == 0 || kouterA % 4 == 0);
         vb = al16(B) && ldb % 4 == 0 && N % 4 == 0 && (kdivB == 0 || kouterB % 4 == 0);
-        launch<false, false>(p, va, vb, grid, s);
+        if (split) rc = launch_split<false, false>(p, va, vb, grid, s);
+        else launch<false, false>(p, va, vb, grid, s);
     } else {
         va = al16(A) && lda % 4 == 0 && K % 4 == 0 && strideA % 4 == 0;
         if (mode == AAS_GEMM_NT) {
             vb = al16(B) && ldb % 4 == 0 && K % 4 == 0 && strideB % 4 == 0;
-            launch<true, true>(p, va, vb, grid, s);
+            if (split) rc = launch_split<true, true>(p, va, vb, grid, s);
+            else launch<true, true>(p, va, vb, grid, s);
         } else {
             vb = al16(B) && ldb % 4 == 0 && N % 4 == 0 && strideB % 4 == 0;
-            launch<true, false>(p, va, vb, grid, s);
+            if (split) rc = launch_split<true, false>(p, va, vb, grid, s);
+            else launch<true, false>(p, va, vb, grid, s);
         }
     }
+    AAS_CHECK(rc == 0, "aas_gemm_f32: could not raise the dynamic LDS limit for the split-bf16 kernel");
     AAS_LAUNCH_CHECK("aas_gemm_f32");
     return 0;
 }

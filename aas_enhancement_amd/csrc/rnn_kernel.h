@@ -204,39 +204,72 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
                 __syncthreads();
             }
             const int m = lane & 15, q = lane >> 4;
-            // element offset of row 0 of the previous step's vector
+            // byte offset of this lane's first float4 of the previous step's vector, per 16-row tile; rows
+            // beyond the batch get an out-of-range offset: the buffer descriptor's bounds check returns 0
+            // for them, so the loads below are branch-free and can be issued back to back.
             const int64_t rbase = FWD ? ((int64_t)d * T + tp) * N * H : ((int64_t)tp * N * 2 + d) * GH;
             const int64_t rstride = FWD ? H : 2 * GH;
+            constexpr unsigned OOB = 0x80000000u;
+            unsigned roff[MT];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                f32x4 a[MT];
+            for (int mt = 0; mt < MT; ++mt) {
+                const int gr = q0 + mt * 16 + m;
+                roff[mt] = (gr < NB && !(p.flags & 1)) ? (unsigned)((rbase + (int64_t)gr * rstride + kb + q * 4) * 4) : OOB;
+            }
+            const int klane = kb + q * 4;  // first k of this lane within super-step 0
+            if (VEC) {
+                // software pipeline over chunks of CH super-steps: loads of chunk c+DEPTH are in flight while the
+                // MFMAs of chunk c issue (the compiler emits counted vmcnt waits for these builtin loads)
+                constexpr int CH = KS >= 4 ? 4 : KS;
+                constexpr int NCH = KS / CH;
+                constexpr int DEPTH = NCH >= 3 ? 2 : (NCH >= 2 ? 1 : 0);
+                f32x4 abuf[DEPTH + 1][CH][MT];
+                auto issue = [&](int c, f32x4 (&dst)[CH][MT]) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int gr = q0 + mt * 16 + m;
-                    const int k = kb + ks * 16 + q * 4;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (gr < NB && k < Kx && !(p.flags & 1)) {
-                        const int64_t off = (rbase + (int64_t)gr * rstride + k) * 4;
-                        if (VEC) {
-                            v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 16));
-                        } else {
-                            const float* xp = xbase + off / 4;
-                            v.x = __hip_atomic_load(xp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (k + 1 < Kx) v.y = __hip_atomic_load(xp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (k + 2 < Kx) v.z = __hip_atomic_load(xp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (k + 3 < Kx) v.w = __hip_atomic_load(xp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int j = 0; j < CH; ++j) {
+                        const int ks = c * CH + j;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const unsigned off = (klane + ks * 16 < Kx) ? roff[mt] + (unsigned)(ks * 64) : OOB;
+                            dst[j][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 16));
                         }
                     }
-                    a[mt] = v;
+                };
+#pragma unroll
+                for (int c = 0; c < DEPTH && c < NCH; ++c) issue(c, abuf[c % (DEPTH + 1)]);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + DEPTH < NCH) issue(c + DEPTH, abuf[(c + DEPTH) % (DEPTH + 1)]);
+                    if (!(p.flags & 2)) {
+#pragma unroll
+                        for (int j = 0; j < CH; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt)
+                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[c % (DEPTH + 1)][j][mt][e], bf[c * CH + j][e][nt], acc[mt][nt], 0, 0, 0);
+                    }
                 }
-                if (!(p.flags & 2))
+            } else {
+                // H % 4 != 0 (tiny test shapes only, KS == 1): scalar sc1 loads
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (roff[mt] != OOB && klane < Kx) {
+                        const float* xp = xbase + roff[mt] / 4;
+                        v.x = __hip_atomic_load(xp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (klane + 1 < Kx) v.y = __hip_atomic_load(xp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (klane + 2 < Kx) v.z = __hip_atomic_load(xp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (klane + 3 < Kx) v.w = __hip_atomic_load(xp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][e], bf[ks][e][nt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e], bf[0][e][nt], acc[mt][nt], 0, 0, 0);
+                }
             }
         }
         // ---- cross-wave reduction through LDS: C/D map col = lane&15, row = (lane>>4)*4 + r ----

@@ -47,6 +47,11 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def set_precision(mode):
+    """0 = exact fp32-input MFMA; 1 (library default) = split-bf16 operands (hi/lo, 3 MFMAs, ~1e-5 relative)."""
+    check(lib().aas_set_precision(int(mode)), "aas_set_precision")
+
+
 class Profiler:
     """Optional HIP-event timing of individual launches on the launching stream (bench.py roofline).
     `classes` selects which launch classes are bracketed with events: "rnn" and/or "gemm"."""

@@ -32,6 +32,10 @@ int aas_device_cus(void);
 /* ablation bits for the persistent RNN kernels (profiling only; results are wrong when non-zero):
  * 1 skip exchange loads, 2 skip MFMA, 4 skip arrival wait, 8 skip publish (drain + arrival). */
 int aas_set_debug_flags(int flags);
+/* Matrix-product operand precision: 0 = exact fp32-input MFMA; 1 (default) = split-bf16: each fp32 operand is
+ * carried as bf16 hi + bf16 lo and the product as hi*hi + lo*hi + hi*lo with fp32 accumulation (~1e-5 relative,
+ * fp32-class; 3 bf16 MFMAs instead of 16 fp32-MFMA issue slots). */
+int aas_set_precision(int mode);
 
 /* ---------------------------------------------------------------- dense linear algebra --------
  * fp32 MFMA GEMM  C = op(A) op(B) [+ bias broadcast over rows] [+ addend] [+ C if accumulate].
