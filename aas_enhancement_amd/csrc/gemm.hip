@@ -207,13 +207,15 @@ constexpr int SARR = 128 * SROW; // bytes per (operand, hi|lo) array
 
 // split 4 floats -> packed hi (2 dwords) and lo (2 dwords)
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
-    const unsigned u0 = __builtin_bit_cast(unsigned, v.x), u1 = __builtin_bit_cast(unsigned, v.y);
-    const unsigned u2 = __builtin_bit_cast(unsigned, v.z), u3 = __builtin_bit_cast(unsigned, v.w);
-    const unsigned h0 = u0 & 0xFFFF0000u, h1 = u1 & 0xFFFF0000u, h2 = u2 & 0xFFFF0000u, h3 = u3 & 0xFFFF0000u;
+    // NB: copy the lanes to scalars first - __builtin_bit_cast applied directly to an ext_vector
+    // element (v.y ...) is miscompiled by ROCm 7.2 clang into a read of element 0.
+    const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+    const unsigned h0 = __float_as_uint(x0) & 0xFFFF0000u, h1 = __float_as_uint(x1) & 0xFFFF0000u;
+    const unsigned h2 = __float_as_uint(x2) & 0xFFFF0000u, h3 = __float_as_uint(x3) & 0xFFFF0000u;
     hi.x = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
     hi.y = __builtin_amdgcn_perm(h3, h2, 0x07060302u);
-    const bf16x2 l01 = {(__bf16)(v.x - __builtin_bit_cast(float, h0)), (__bf16)(v.y - __builtin_bit_cast(float, h1))};
-    const bf16x2 l23 = {(__bf16)(v.z - __builtin_bit_cast(float, h2)), (__bf16)(v.w - __builtin_bit_cast(float, h3))};
+    const bf16x2 l01 = {(__bf16)(x0 - __uint_as_float(h0)), (__bf16)(x1 - __uint_as_float(h1))};
+    const bf16x2 l23 = {(__bf16)(x2 - __uint_as_float(h2)), (__bf16)(x3 - __uint_as_float(h3))};
     lo.x = __builtin_bit_cast(unsigned, l01);
     lo.y = __builtin_bit_cast(unsigned, l23);
 }
@@ -293,7 +295,7 @@ __device__ __forceinline__ void sstore_rc(char* hi, char* lo, int tid, const f32
 
 template <bool A_KC, bool B_KC, bool VECA, bool VECB>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A_hi, A_lo, B_hi, B_lo][128][80 B]
+    __shared__ __attribute__((aligned(16))) char smem[4 * SARR];  // [A_hi, A_lo, B_hi, B_lo][128][80 B] = 40 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -329,20 +331,21 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
         if (B_KC) sload_kc<VECB>(B, p.ldb, n0, p.N, k0, kend, tid, rb);
         else sload_rc<VECB>(B, p.ldb, p.kdivB, p.kouterB, n0, p.N, k0, kend, tid, rb);
     };
-    auto sstore = [&](int buf) {
-        char* st = smem + buf * 4 * SARR;
+    auto sstore = [&]() {
+        char* st = smem;
         if (A_KC) sstore_kc(st, st + SARR, tid, ra); else sstore_rc(st, st + SARR, tid, ra);
         if (B_KC) sstore_kc(st + 2 * SARR, st + 3 * SARR, tid, rb); else sstore_rc(st + 2 * SARR, st + 3 * SARR, tid, rb);
     };
+    // single LDS stage (40 KB -> 3-4 blocks per CU hide the two barriers per k-step); the next tile's
+    // global loads are in flight in registers while the MFMAs of the current tile issue
     gload(kbeg);
-    sstore(0);
-    __syncthreads();
-    int buf = 0;
     const int l31 = lane & 31, lh = lane >> 5;
     for (int k0 = kbeg; k0 < kend; k0 += SBK) {
         const bool more = (k0 + SBK) < kend;
+        sstore();
+        __syncthreads();
         if (more) gload(k0 + SBK);
-        const char* st = smem + buf * 4 * SARR;
+        const char* st = smem;
 #pragma unroll
         for (int kk = 0; kk < SBK; kk += 16) {
             // A operand of 32x32x16: lane (row l&31, half l>>5) holds k = 8*half + j; same map for B columns
@@ -366,9 +369,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
                 }
         }
-        if (more) sstore(buf ^ 1);
         __syncthreads();
-        buf ^= 1;
     }
     const bool first = (p.splitk <= 1) || (z == 0);
 #pragma unroll
@@ -392,25 +393,12 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
         }
 }
 
-constexpr int SPLIT_LDS = 2 * 4 * SARR;  // 81920 B
-
 template <bool A_KC, bool B_KC>
 int launch_split(const GemmP& p, bool va, bool vb, dim3 grid, hipStream_t s) {
-#define AAS_SPLIT_LAUNCH(VA, VB)                                                                              \
-    do {                                                                                                      \
-        static bool attr_set = false;                                                                         \
-        auto kfn = gemm_split_kernel<A_KC, B_KC, VA, VB>;                                                     \
-        if (!attr_set) {                                                                                      \
-            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS) != hipSuccess) return 3; \
-            attr_set = true;                                                                                  \
-        }                                                                                                     \
-        hipLaunchKernelGGL(kfn, grid, dim3(256), SPLIT_LDS, s, p);                                            \
-    } while (0)
-    if (va && vb) AAS_SPLIT_LAUNCH(true, true);
-    else if (va) AAS_SPLIT_LAUNCH(true, false);
-    else if (vb) AAS_SPLIT_LAUNCH(false, true);
-    else AAS_SPLIT_LAUNCH(false, false);
-#undef AAS_SPLIT_LAUNCH
+    if (va && vb) hipLaunchKernelGGL((gemm_split_kernel<A_KC, B_KC, true, true>), grid, dim3(256), 0, s, p);
+    else if (va) hipLaunchKernelGGL((gemm_split_kernel<A_KC, B_KC, true, false>), grid, dim3(256), 0, s, p);
+    else if (vb) hipLaunchKernelGGL((gemm_split_kernel<A_KC, B_KC, false, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_split_kernel<A_KC, B_KC, false, false>), grid, dim3(256), 0, s, p);
     return 0;
 }
 

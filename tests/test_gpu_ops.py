@@ -187,9 +187,14 @@ def test_conv_frontend_golden(ops):
         assert rel_err(p.grad, z["dsconv.gw." + k]) < 1e-3, k
 
 
+def otol(precision):
+    """(forward, gradient) relative tolerances of a recurrent layer: exact fp32 vs split-bf16 GEMM operands"""
+    return (1e-5, 1e-4) if precision == 0 else (1e-4, 5e-4)
+
+
 @pytest.mark.parametrize("kind", ["lstm", "gru"])
 @pytest.mark.parametrize("tag", ["s", "m"])
-def test_brnn_golden(ops, kind, tag):
+def test_brnn_golden(ops, precision, kind, tag):
     from aas_enhancement_amd.model import BRNN
     z = load("f4_ops.npz")
     p = "brnn_%s_%s." % (kind, tag)
@@ -201,13 +206,14 @@ def test_brnn_golden(ops, kind, tag):
     y = m(x)
     y.backward(torch.from_numpy(z[p + "gy"]).cuda())
     assert not ops.rnn_timeout_flag()
-    assert rel_err(y, z[p + "y"]) < 1e-5
-    assert rel_err(x.grad, z[p + "gx"]) < 1e-4
+    ft, gt = otol(precision)
+    assert rel_err(y, z[p + "y"]) < ft
+    assert rel_err(x.grad, z[p + "gx"]) < gt
     for k, v in m.named_parameters():
-        assert rel_err(v.grad, z[p + "gw." + k]) < 1e-4, k
+        assert rel_err(v.grad, z[p + "gw." + k]) < gt, k
 
 
-def test_batchrnn_golden(ops):
+def test_batchrnn_golden(ops, precision):
     from aas_enhancement_amd.model import BatchRNN
     z = load("f4_ops.npz")
     m = BatchRNN(6, 9, nn.GRU, bidirectional=True, batch_norm=True)
@@ -216,14 +222,15 @@ def test_batchrnn_golden(ops):
     x = torch.from_numpy(z["batchrnn.x"]).cuda().requires_grad_(True)
     y = m(x)
     y.backward(torch.from_numpy(z["batchrnn.gy"]).cuda())
-    assert rel_err(y, z["batchrnn.y"]) < 1e-5 and rel_err(x.grad, z["batchrnn.gx"]) < 1e-4
+    ft, gt = otol(precision)
+    assert rel_err(y, z["batchrnn.y"]) < ft and rel_err(x.grad, z["batchrnn.gx"]) < gt
     for k, v in m.named_parameters():
-        assert rel_err(v.grad, z["batchrnn.gw." + k]) < 1e-4, k
+        assert rel_err(v.grad, z["batchrnn.gw." + k]) < gt, k
 
 
 @pytest.mark.parametrize("kind,T,N,H", [("lstm", 200, 30, 500), ("gru", 85, 30, 1000), ("lstm", 40, 60, 128), ("gru", 30, 70, 64),
                                         ("lstm", 9, 3, 16), ("gru", 1, 2, 12)])
-def test_birnn_layer_vs_cpu_at_size(ops, kind, T, N, H):
+def test_birnn_layer_vs_cpu_at_size(ops, precision, kind, T, N, H):
     """config-2 layer shapes (E: T=200,N=30,H=500; A: T'=85,N=30,H=1000) and multi-group batches."""
     torch.manual_seed(0)
     ref = (nn.LSTM if kind == "lstm" else nn.GRU)(H, H, bidirectional=True, bias=False)
@@ -240,10 +247,11 @@ def test_birnn_layer_vs_cpu_at_size(ops, kind, T, N, H):
     yg.backward(gy.cuda())
     torch.cuda.synchronize()
     assert not ops.rnn_timeout_flag()
-    assert rel_err(yg, yr) < 2e-5
-    assert rel_err(xg.grad, xr.grad) < 2e-4
+    ft, gt = otol(precision)
+    assert rel_err(yg, yr) < 2 * ft
+    assert rel_err(xg.grad, xr.grad) < 2 * gt
     for wg, k in zip(w, ("weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse")):
-        assert rel_err(wg.grad, getattr(ref, k).grad) < 2e-4, k
+        assert rel_err(wg.grad, getattr(ref, k).grad) < 2 * gt, k
 
 
 def test_ctc_vs_numpy_and_torch(ops):

@@ -42,8 +42,16 @@ def build_tiny(z):
     return G, D, A
 
 
+@pytest.fixture(params=[1, 0], ids=["splitbf16", "fp32"])
+def precision(request, gpu):
+    from aas_enhancement_amd import ops
+    ops.set_precision(request.param)
+    yield request.param
+    ops.set_precision(1)
+
+
 @pytest.mark.parametrize("schedule", ["fused", "as_executed"])
-def test_aas_step_tiny_golden(gpu, schedule):
+def test_aas_step_tiny_golden(gpu, precision, schedule):
     """F1: 3 full AAS iterations, ragged batch, every tensor checked."""
     from aas_enhancement_amd.trainer_AAS import Trainer
     z = load("f1_aas_tiny.npz")
@@ -112,7 +120,7 @@ def test_dce_config1_golden(gpu):
         assert float(r["outputs"].detach().double().sum()) == pytest.approx(float(z["out_sums"][it]), rel=1e-3)
 
 
-def test_aas_config2_golden(gpu):
+def test_aas_config2_golden(gpu, precision):
     """F3: BASELINE config 2 (N=30,T=200,F=80; E/D 4x500 BiLSTM; A 2xconv+5x1000 BiGRU+CTC), 2 iterations."""
     from aas_enhancement_amd import prng
     from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
@@ -213,6 +221,6 @@ def test_round_trip_properties_full_size(gpu):
     y = G(x)
     (gx1,) = torch.autograd.grad(y, x, g1, retain_graph=True)
     (gx2,) = torch.autograd.grad(y, x, 2.5 * g1, retain_graph=True)
-    assert rel_err(gx2, 2.5 * gx1) < 1e-5
+    assert rel_err(gx2, 2.5 * gx1) < 1e-4  # split-bf16 products are not exactly linear in fp32 rounding
     y2 = G(x)
     assert rel_err(y2, y) < 1e-6
