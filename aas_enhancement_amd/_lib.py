@@ -31,6 +31,7 @@ SIGNATURES = {
     "aas_add3_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64],
     "aas_scale_rows_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int],
     "aas_axpby_f32": [c_vp, c_vp, c_vp, c_f32, c_f32, c_i64],
+    "aas_scale_dev_f32": [c_vp, c_vp, c_vp, c_vp, c_f32, c_i64],
     "aas_colsum_f32": [c_vp, c_vp, c_i64, c_int, c_i64, c_vp, c_int],
     "aas_sqsum_f32": [c_vp, c_vp, c_i64, c_vp],
     "aas_rnn_sync_bytes": [],
@@ -42,7 +43,7 @@ SIGNATURES = {
     "aas_bn_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_vp],
     "aas_col2im_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int],
     "aas_l1_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp],
-    "aas_l1_bwd": [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_int],
+    "aas_l1_bwd": [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_int],
     "aas_ctc_get_workspace_size": [c_vp, c_vp, c_int, c_int, c_int, ctypes.POINTER(c_sz)],
     "aas_compute_ctc_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int],
     "aas_ctc_loss_async": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_f32],

@@ -47,9 +47,10 @@ __global__ __launch_bounds__(256) void add3_kernel(float* __restrict__ out, cons
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha,
-                                                    float beta, int64_t n) {
+                                                    float beta, int64_t n, const float* __restrict__ d_alpha) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * 256;
+    if (d_alpha) alpha *= d_alpha[0];
     for (; i < n; i += stride) {
         float v = alpha * x[i];
         if (beta != 0.f) v += beta * y[i];
@@ -99,10 +100,11 @@ __global__ __launch_bounds__(256) void l1_fwd_kernel(const float* __restrict__ a
 }
 
 __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                     int64_t n, float scale, float* __restrict__ ga,
-                                                     float* __restrict__ gb, int accumulate) {
+                                                     int64_t n, float scale, const float* __restrict__ d_scale,
+                                                     float* __restrict__ ga, float* __restrict__ gb, int accumulate) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * 256;
+    if (d_scale) scale *= d_scale[0];
     for (; i < n; i += stride) {
         float d = a[i] - b[i];
         float g = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);  // torch.abs backward: sign(d), 0 at 0
@@ -229,8 +231,16 @@ extern "C" int aas_add3_f32(aasStream_t stream, float* out, const float* a, cons
 extern "C" int aas_axpby_f32(aasStream_t stream, float* y, const float* x, float alpha, float beta, int64_t n) {
     AAS_CHECK(y && x && n >= 0, "aas_axpby_f32: bad args");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, beta, n);
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, beta, n, (const float*)nullptr);
     AAS_LAUNCH_CHECK("aas_axpby_f32");
+    return 0;
+}
+
+extern "C" int aas_scale_dev_f32(aasStream_t stream, float* y, const float* x, const float* d_alpha, float alpha, int64_t n) {
+    AAS_CHECK(y && x && d_alpha && n >= 0, "aas_scale_dev_f32: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, 0.f, n, d_alpha);
+    AAS_LAUNCH_CHECK("aas_scale_dev_f32");
     return 0;
 }
 
@@ -263,11 +273,11 @@ extern "C" int aas_l1_fwd(aasStream_t stream, const float* a, const float* b, in
     return 0;
 }
 
-extern "C" int aas_l1_bwd(aasStream_t stream, const float* a, const float* b, int64_t n, float scale, float* ga,
-                          float* gb, int accumulate) {
+extern "C" int aas_l1_bwd(aasStream_t stream, const float* a, const float* b, int64_t n, float scale,
+                          const float* d_scale, float* ga, float* gb, int accumulate) {
     AAS_CHECK(a && b && n >= 0, "aas_l1_bwd: bad args");
     if (n == 0 || (!ga && !gb)) return 0;
-    hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, scale, ga, gb, accumulate);
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, scale, d_scale, ga, gb, accumulate);
     AAS_LAUNCH_CHECK("aas_l1_bwd");
     return 0;
 }

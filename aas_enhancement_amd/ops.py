@@ -478,11 +478,11 @@ class _L1Sum(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        # the upstream scalar lives on the device; read it once (it is the loss weight / nElement)
-        scale = float(g)
+        # the upstream scalar (loss weight / nElement) stays on the device: no host sync in backward
+        g = _c(g.reshape(1).to(torch.float32))
         ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
-        check(lib().aas_l1_bwd(stream(), ptr(a), ptr(b), a.numel(), scale, ptr(ga), ptr(gb), 0), "aas_l1_bwd")
+        check(lib().aas_l1_bwd(stream(), ptr(a), ptr(b), a.numel(), 1.0, ptr(g), ptr(ga), ptr(gb), 0), "aas_l1_bwd")
         return ga, gb
 
 
@@ -525,9 +525,8 @@ class _CTC(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grads,) = ctx.saved_tensors
-        scale = float(g.reshape(-1)[0])
-        if scale != 1.0:
-            axpby_(grads, grads, scale, 0.0)
+        g = _c(g.reshape(-1)[:1].to(torch.float32))
+        check(lib().aas_scale_dev_f32(stream(), ptr(grads), ptr(grads), ptr(g), 1.0, grads.numel()), "aas_scale_dev_f32")
         return grads, None, None, None, None
 
 

@@ -189,6 +189,7 @@ class Trainer(object):
             # iterations g_adv needs E's adversarial-only gradients, so E is back-propagated per loss.
             leaf = enhanced.detach().requires_grad_(True)
             Nn = leaf.size(0)
+            acoustic = self._acoustic_branch(enhanced, targets, input_percentages, target_sizes, N_glob)
             if tuple(cl_inputs.shape[1:]) == tuple(leaf.shape[1:]):
                 # D(enhanced) and D(clean) share ONE batched pass (rows are independent: D has no batch
                 # statistics).  The D-step gradients of the enhanced half are (-kt) x its G-step parameter
@@ -219,12 +220,15 @@ class Trainer(object):
                 leaf.grad = None
             if dp.active:  # D's all-reduce overlaps the acoustic branch and E's backward
                 handle_d = dp.allreduce_sum_(self._flat["D"].flat_g, async_op=True)
-            # CTC loss (:163-172)
-            prob = self.ASR(leaf).transpose(0, 1)
-            sizes = input_percentages.clone().mul_(int(prob.size(0))).int()
-            l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes) / N_glob
-            l_CTC.backward()
-            enhanced.backward(leaf.grad)
+            # CTC loss (:163-172).  The acoustic branch A(enhanced) -> CTC -> backward is independent of the
+            # D branch above: it was enqueued on a second HIP stream BEFORE the D branch (see _acoustic_branch),
+            # so the two chains of persistent recurrent launches overlap on the 256 CUs.
+            prob, l_CTC, leaf_a = acoustic
+            torch.cuda.current_stream().wait_stream(self._side)
+            leaf_a.grad.record_stream(torch.cuda.current_stream())
+            # (on logging iterations the adversarial part was already back-propagated for g_adv)
+            gsum = ops.add3(leaf.grad, leaf_a.grad) if leaf.grad is not None else leaf_a.grad
+            enhanced.backward(gsum)
             if log_norms:
                 g_ctc_adv = self.get_gradient_norm(self.G)
         # data parallel: SUM all-reduce of the flat gradient buffers (RCCL over xGMI)
@@ -252,6 +256,22 @@ class Trainer(object):
         conv_measure = l_adv_cl_data + abs(g_d_balance)
         return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, kt=self.kt,
                     conv_measure=conv_measure, g_adv=g_adv, g_ctc_adv=g_ctc_adv, enhanced=enhanced, prob=prob)
+
+    def _acoustic_branch(self, enhanced, targets, input_percentages, target_sizes, N_glob):
+        """A(enhanced) -> CTC/N -> backward down to a private leaf, on the side stream."""
+        c = self.config
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            leaf_a = enhanced.detach().requires_grad_(True)
+            enhanced.record_stream(self._side)
+            prob = self.ASR(leaf_a).transpose(0, 1)
+            sizes = input_percentages.clone().mul_(int(prob.size(0))).int()
+            l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes) / N_glob
+            l_CTC.backward()
+        return prob, l_CTC, leaf_a
 
     def train(self):
         from tqdm import trange

@@ -73,6 +73,8 @@ int aas_add3_f32(aasStream_t stream, float* out, const float* a, const float* b,
 int aas_scale_rows_f32(aasStream_t stream, float* out, const float* in, const float* scale, int64_t rows, int Nb, int C);
 /* y = alpha * x + beta * y  (gradient scaling / accumulation; y may alias x) */
 int aas_axpby_f32(aasStream_t stream, float* y, const float* x, float alpha, float beta, int64_t n);
+/* y = (alpha * d_alpha[0]) * x with the factor read from device memory (y may alias x) */
+int aas_scale_dev_f32(aasStream_t stream, float* y, const float* x, const float* d_alpha, float alpha, int64_t n);
 /* out[c] (+)= sum_r x[r, c]   (bias gradients) */
 int aas_colsum_f32(aasStream_t stream, const float* x, int64_t R, int C, int64_t ld, float* out, int accumulate);
 /* acc[0] += sum x^2 (fp64 accumulator on device). trainer_AAS.py:353-361 get_gradient_norm. */
@@ -129,8 +131,9 @@ int aas_col2im_f32(aasStream_t stream, const float* dcol, float* dx, int N, int 
  * L1Loss_mask (model.py:19-31): loss_sum[0] (+)= sum |a-b| over ALL elements (mask not applied,
  * as in the reference); the caller divides by nElement = #unmasked (n,t). fp64 accumulator. */
 int aas_l1_fwd(aasStream_t stream, const float* a, const float* b, int64_t n, double* loss_sum);
-/* ga = scale*sign(a-b) (if ga), gb = -scale*sign(a-b) (if gb); `accumulate` adds into them. */
-int aas_l1_bwd(aasStream_t stream, const float* a, const float* b, int64_t n, float scale,
+/* ga = s*sign(a-b) (if ga), gb = -s*sign(a-b) (if gb), s = scale * (d_scale ? d_scale[0] : 1): the upstream
+ * gradient can stay on the device (no host sync in backward); `accumulate` adds into ga/gb. */
+int aas_l1_bwd(aasStream_t stream, const float* a, const float* b, int64_t n, float scale, const float* d_scale,
                float* ga, float* gb, int accumulate);
 
 /* CTC (warpctc_pytorch.CTCLoss; call site trainer_AAS.py:168).  Mirrors warp-ctc's C ABI
