@@ -40,6 +40,7 @@ struct RnnP {
     float* dg1;          // bwd: LSTM dgates / GRU dgh  [T,N,2,G*H]  (exchanged)
     float* dg2;          // bwd: GRU dgx               [T,N,2,G*H]
     unsigned* sync;
+    unsigned* xchg;      // split-bf16 exchange arrays (hi | lo), NULL -> exact fp32 kernels
     int P, Q;
     int n0, n1;          // batch rows [n0, n1) handled by this launch
     int flags;           // debug/ablation bits (aas_set_debug_flags): 1 no exchange loads, 2 no MFMA, 4 no wait, 8 no publish

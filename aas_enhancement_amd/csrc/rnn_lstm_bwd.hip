@@ -1,11 +1,11 @@
-#include "rnn_kernel.h"
+#include "rnn_split_kernel.h"
 
 extern "C" int aas_lstm_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
-                            const float* gact, const float* cst, float* dgates, void* sync) {
+                            const float* gact, const float* cst, float* dgates, void* sync, void* xchg) {
     AAS_CHECK(dy && w_hh && w_hh_rev && gact && cst && dgates && sync, "aas_lstm_bwd: null pointer");
     RnnP p = {};
     p.T = T; p.N = N; p.H = H; p.dy = dy; p.w_hh = w_hh; p.w_hh_r = w_hh_rev; p.gact = (float*)gact; p.cst = (float*)cst; p.dg1 = dgates;
-    p.sync = (unsigned*)sync;
-    return run<LSTM_BWD>("aas_lstm_bwd", p, (hipStream_t)stream);
+    p.sync = (unsigned*)sync; p.xchg = (unsigned*)xchg;
+    return run_any<LSTM_BWD>("aas_lstm_bwd", p, (hipStream_t)stream);
 }
 

@@ -1,13 +1,17 @@
-#include "rnn_kernel.h"
+#include "rnn_split_kernel.h"
 
 extern "C" size_t aas_rnn_sync_bytes(void) { return SYNC_BYTES; }
+// hi + lo arrays of the widest exchanged vector (BPTT: 2*T*N rows x G*Hp bf16, Hp <= H + 15)
+extern "C" size_t aas_rnn_xchg_bytes(int T, int N, int H, int gates) {
+    return (size_t)2 * 2 * T * N * (size_t)gates * (H + 16) * 2;
+}
 
 extern "C" int aas_lstm_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh, const float* w_hh_rev, float* hout,
-                            float* gact, float* cst, void* sync) {
+                            float* gact, float* cst, void* sync, void* xchg) {
     AAS_CHECK(pre && w_hh && w_hh_rev && hout && gact && cst && sync, "aas_lstm_fwd: null pointer");
     RnnP p = {};
     p.T = T; p.N = N; p.H = H; p.pre = pre; p.w_hh = w_hh; p.w_hh_r = w_hh_rev; p.hout = hout; p.gact = gact; p.cst = cst;
-    p.sync = (unsigned*)sync;
-    return run<LSTM_FWD>("aas_lstm_fwd", p, (hipStream_t)stream);
+    p.sync = (unsigned*)sync; p.xchg = (unsigned*)xchg;
+    return run_any<LSTM_FWD>("aas_lstm_fwd", p, (hipStream_t)stream);
 }
 

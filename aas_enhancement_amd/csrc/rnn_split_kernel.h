@@ -1,0 +1,384 @@
+// Split-bf16 variant of the persistent recurrent kernels (see rnn_kernel.h for the structure).
+//
+// The exchanged vector (h_t forward, d(gates)_t in BPTT) is published by its PRODUCER already split
+// into bf16 hi = trunc(x) and bf16 lo = rne(x - hi), two values per 32-bit word, in two arrays with
+// a row pitch of Hp = P*U units (pad units are written as zeros).  Consumers load MFMA A-fragments
+// of 8 consecutive k straight from those arrays (16-byte sc1 buffer loads, no VALU in the loop) and
+// issue hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: fp32-class accuracy
+// (~1e-5 relative, dropped term lo*lo) at 3/16 of the fp32-MFMA issue time.  The W_hh slice is
+// split once before the time loop.  fp32 copies of h / d(gates) are still written (plain stores)
+// for the layer's GEMMs.  Selected by aas_set_precision(1) when the caller passes an exchange buffer.
+#pragma once
+#include "rnn_kernel.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_bf16(float x, unsigned& hi16, unsigned& lo16) {
+    const unsigned h = __float_as_uint(x) & 0xFFFF0000u;
+    const __bf16 l = (__bf16)(x - __uint_as_float(h));
+    hi16 = h >> 16;
+    lo16 = (unsigned)__builtin_bit_cast(unsigned short, l);
+}
+
+__device__ __forceinline__ void st_sc1_u32(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// MODE, MT = 16-row batch tiles per workgroup, KS = 32-wide k chunks per wave
+template <int MODE, int MT, int KS>
+__global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
+    using C = Cfg<MODE>;
+    constexpr int G = C::G, U = C::U, NT = C::NT;
+    constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD);
+    constexpr bool LSTM = (MODE == LSTM_FWD || MODE == LSTM_BWD);
+    constexpr int LDR = red_ld(NT, U);
+    constexpr int ROWS = MT * 16;
+    constexpr int UP = U / 2;                           // unit pairs per row in this slice
+    constexpr int EPT = (ROWS * UP + 255) / 256;        // (row, unit-pair) slots per thread
+    __shared__ float red[4][ROWS][LDR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pslice = blockIdx.x, qg = blockIdx.y, d = blockIdx.z;
+    const int T = p.T, N = p.N, H = p.H, GH = G * H;
+    const int Hp = p.P * U;                             // padded unit pitch of the exchange arrays
+    const int u0 = pslice * U;
+    const int q0 = p.n0 + qg * ROWS;
+    const int NB = p.n1;
+    const int Kxp = FWD ? Hp : G * Hp;                  // exchanged (padded) vector length per row
+    const int kb = wave * KS * 32;
+    unsigned* cnt = p.sync + (d * p.Q + qg) * CNT_STRIDE;
+    unsigned* err = p.sync + ERR_WORD;
+
+    // ---- B fragments (hi / lo) of this workgroup's W_hh slice ---------------------------------
+    const float* W = d == 0 ? p.w_hh : p.w_hh_r;
+    bf16x8 bh[KS][NT], bl[KS][NT];
+    {
+        const int n = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = nt * 16 + n;
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    unsigned h2[2], l2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int k = kb + ks * 32 + q * 8 + jj * 2 + e;
+                        float v = 0.f;
+                        if (FWD) {
+                            const int gate = c / U, unit = u0 + c % U;
+                            if (c < G * U && unit < H && k < H) v = W[(int64_t)(gate * H + unit) * H + k];
+                        } else {
+                            const int unit = u0 + c, gate = k / Hp, ku = k - gate * Hp;
+                            if (c < U && unit < H && gate < G && ku < H) v = W[(int64_t)(gate * H + ku) * H + unit];
+                        }
+                        split_bf16(v, h2[e], l2[e]);
+                    }
+                    hw[jj] = h2[0] | (h2[1] << 16);
+                    lw[jj] = l2[0] | (l2[1] << 16);
+                }
+                const u32x4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
+                bh[ks][nt] = __builtin_bit_cast(bf16x8, hv);
+                bl[ks][nt] = __builtin_bit_cast(bf16x8, lv);
+            }
+    }
+
+    // exchange arrays: hi then lo, each rows x (Kxp/2) 32-bit words
+    const int64_t xrows = (int64_t)2 * T * N;           // fwd: [2][T][N]; bwd: [T][N][2]
+    const int64_t xhalf_words = xrows * (Kxp / 2);
+    unsigned* xhi = p.xchg;
+    unsigned* xlo = p.xchg + xhalf_words;
+    auto rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)xhi, 0, (int)(xhalf_words * 4), 0x00020000);
+    auto rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)xlo, 0, (int)(xhalf_words * 4), 0x00020000);
+
+    float carry[EPT][2];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) carry[i][0] = carry[i][1] = 0.f;
+
+    for (int s = 0; s < T; ++s) {
+        const int fwd_order = (d == 0) ? s : T - 1 - s;
+        const int t = FWD ? fwd_order : (T - 1 - fwd_order);
+        const int tp = FWD ? (d == 0 ? t - 1 : t + 1) : (d == 0 ? t + 1 : t - 1);
+
+        // ---- prefetch the step's private inputs ------------------------------------------------
+        float pin[EPT][2][4];
+        float sav[EPT][2][6];
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / UP, up = idx % UP;
+            const int gr = q0 + row;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int unit = u0 + 2 * up + e;
+                const bool ok = (idx < ROWS * UP) && gr < NB && unit < H;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pin[i][e][g] = 0.f;
+#pragma unroll
+                for (int g = 0; g < 6; ++g) sav[i][e][g] = 0.f;
+                if (ok) {
+                    const int64_t tn = (int64_t)t * N + gr;
+                    if (FWD) {
+                        const float* pp = p.pre + (tn * 2 + d) * GH + unit;
+#pragma unroll
+                        for (int g = 0; g < G; ++g) pin[i][e][g] = pp[g * H];
+                    } else {
+                        pin[i][e][0] = p.dy[tn * H + unit];
+                        const float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) sav[i][e][g] = ga[g * H];
+                        const int tq = (d == 0) ? t - 1 : t + 1;
+                        const bool hasq = (tq >= 0 && tq < T);
+                        const int64_t qn = ((int64_t)d * T * N + (int64_t)tq * N + gr) * H + unit;
+                        if (LSTM) {
+                            sav[i][e][4] = p.cst[((int64_t)d * T * N + tn) * H + unit];
+                            sav[i][e][5] = hasq ? p.cst[qn] : 0.f;
+                        } else {
+                            sav[i][e][5] = hasq ? p.hout[qn] : 0.f;
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- recurrent product ------------------------------------------------------------------
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            if (!(p.flags & 4)) {
+                if (tid == 0) wait_counter(cnt, (unsigned)p.P * (unsigned)s, err);
+                __syncthreads();
+            }
+            const int m = lane & 15, q = lane >> 4;
+            // byte offset (within the hi or lo array) of this lane's first 8 elements
+            constexpr unsigned OOB = 0x80000000u;
+            unsigned roff[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int gr = q0 + mt * 16 + m;
+                const int64_t xr = FWD ? ((int64_t)d * T + tp) * N + gr : ((int64_t)tp * N + gr) * 2 + d;
+                roff[mt] = (gr < NB && !(p.flags & 1)) ? (unsigned)((xr * Kxp + kb + q * 8) * 2) : OOB;
+            }
+            const int klane = kb + q * 8;
+            constexpr int CH = KS >= 2 ? 2 : 1;
+            constexpr int NCH = KS / CH;
+            constexpr int DEPTH = NCH >= 3 ? 2 : (NCH >= 2 ? 1 : 0);
+            u32x4 ahb[DEPTH + 1][CH][MT], alb[DEPTH + 1][CH][MT];
+            auto issue = [&](int c, u32x4 (&dh)[CH][MT], u32x4 (&dl)[CH][MT]) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int ks = c * CH + j;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const unsigned off = (klane + ks * 32 < Kxp) ? roff[mt] + (unsigned)(ks * 64) : OOB;
+                        dh[j][mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_hi, (int)off, 0, 16));
+                        dl[j][mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_lo, (int)off, 0, 16));
+                    }
+                }
+            };
+#pragma unroll
+            for (int c = 0; c < DEPTH && c < NCH; ++c) issue(c, ahb[c % (DEPTH + 1)], alb[c % (DEPTH + 1)]);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c + DEPTH < NCH) issue(c + DEPTH, ahb[(c + DEPTH) % (DEPTH + 1)], alb[(c + DEPTH) % (DEPTH + 1)]);
+                if (!(p.flags & 2)) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, ahb[c % (DEPTH + 1)][j][mt]);
+                            const bf16x8 al = __builtin_bit_cast(bf16x8, alb[c % (DEPTH + 1)][j][mt]);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c * CH + j][nt], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c * CH + j][nt], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c * CH + j][nt], acc[mt][nt], 0, 0, 0);
+                            }
+                        }
+                }
+            }
+        }
+        // ---- cross-wave reduction through LDS ---------------------------------------------------
+        {
+            const int col = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave][mt * 16 + rq + r][nt * 16 + col] = acc[mt][nt][r];
+        }
+        __syncthreads();
+
+        // ---- gate math: one (row, unit pair) per thread slot ------------------------------------
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / UP, up = idx % UP;
+            const int gr = q0 + row;
+            if (!((idx < ROWS * UP) && gr < NB)) continue;
+            const int64_t tn = (int64_t)t * N + gr;
+            float xv[2][4];  // values to publish: fwd [e][0] = h; bwd [e][g] = exchanged gate gradients
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int u = 2 * up + e, unit = u0 + u;
+                const bool ok = unit < H;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xv[e][g] = 0.f;
+                if (!ok) continue;
+                float rs[G];
+                if (FWD) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        rs[g] = red[0][row][g * U + u] + red[1][row][g * U + u] + red[2][row][g * U + u] + red[3][row][g * U + u];
+                } else {
+                    rs[0] = red[0][row][u] + red[1][row][u] + red[2][row][u] + red[3][row][u];
+                }
+                if (MODE == LSTM_FWD) {
+                    const float ig = sigmoidf_(pin[i][e][0] + rs[0]);
+                    const float fg = sigmoidf_(pin[i][e][1] + rs[1]);
+                    const float gg = tanhf_(pin[i][e][2] + rs[2]);
+                    const float og = sigmoidf_(pin[i][e][3] + rs[3]);
+                    const float c = fg * carry[i][e] + ig * gg;
+                    carry[i][e] = c;
+                    const float h = og * tanhf_(c);
+                    xv[e][0] = h;
+                    p.hout[((int64_t)d * T * N + tn) * H + unit] = h;
+                    float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
+                    ga[0] = ig; ga[H] = fg; ga[2 * H] = gg; ga[3 * H] = og;
+                    p.cst[((int64_t)d * T * N + tn) * H + unit] = c;
+                } else if (MODE == GRU_FWD) {
+                    const float rg = sigmoidf_(pin[i][e][0] + rs[0]);
+                    const float zg = sigmoidf_(pin[i][e][1] + rs[1]);
+                    const float hn = rs[2];
+                    const float ng = tanhf_(pin[i][e][2] + rg * hn);
+                    const float h = (1.f - zg) * ng + zg * carry[i][e];
+                    carry[i][e] = h;
+                    xv[e][0] = h;
+                    p.hout[((int64_t)d * T * N + tn) * H + unit] = h;
+                    float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
+                    ga[0] = rg; ga[H] = zg; ga[2 * H] = ng; ga[3 * H] = hn;
+                } else if (MODE == LSTM_BWD) {
+                    const float dh = pin[i][e][0] + rs[0];
+                    const float ig = sav[i][e][0], fg = sav[i][e][1], gg = sav[i][e][2], og = sav[i][e][3];
+                    const float c = sav[i][e][4], cp = sav[i][e][5];
+                    const float tc = tanhf_(c);
+                    const float dc = dh * og * (1.f - tc * tc) + carry[i][e];
+                    carry[i][e] = dc * fg;
+                    xv[e][0] = dc * gg * ig * (1.f - ig);
+                    xv[e][1] = dc * cp * fg * (1.f - fg);
+                    xv[e][2] = dc * ig * (1.f - gg * gg);
+                    xv[e][3] = dh * tc * og * (1.f - og);
+                    float* dg = p.dg1 + (tn * 2 + d) * GH + unit;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) dg[g * H] = xv[e][g];
+                } else {  // GRU_BWD
+                    const float dh = pin[i][e][0] + rs[0] + carry[i][e];
+                    const float rg = sav[i][e][0], zg = sav[i][e][1], ng = sav[i][e][2], hn = sav[i][e][3];
+                    const float hp = sav[i][e][5];
+                    carry[i][e] = dh * zg;
+                    const float dnp = dh * (1.f - zg) * (1.f - ng * ng);
+                    const float dzp = dh * (hp - ng) * zg * (1.f - zg);
+                    const float drp = dnp * hn * rg * (1.f - rg);
+                    xv[e][0] = drp; xv[e][1] = dzp; xv[e][2] = dnp * rg;
+                    float* dh_ = p.dg1 + (tn * 2 + d) * GH + unit;
+                    dh_[0] = drp; dh_[H] = dzp; dh_[2 * H] = dnp * rg;
+                    float* dx_ = p.dg2 + (tn * 2 + d) * GH + unit;
+                    dx_[0] = drp; dx_[H] = dzp; dx_[2 * H] = dnp;
+                }
+            }
+            // publish hi / lo words (pad units publish zeros)
+            constexpr int GX = FWD ? 1 : G;
+            const int64_t xr = FWD ? ((int64_t)d * T + t) * N + gr : ((int64_t)t * N + gr) * 2 + d;
+            const int64_t wbase = xr * (Kxp / 2) + (u0 + 2 * up) / 2;
+#pragma unroll
+            for (int g = 0; g < GX; ++g) {
+                unsigned h0, l0, h1, l1;
+                split_bf16(xv[0][g], h0, l0);
+                split_bf16(xv[1][g], h1, l1);
+                st_sc1_u32(xhi + wbase + g * (Hp / 2), h0 | (h1 << 16));
+                st_sc1_u32(xlo + wbase + g * (Hp / 2), l0 | (l1 << 16));
+            }
+        }
+        if (!(p.flags & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && !(p.flags & 8)) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int MODE, int MT, int KS>
+int launch_sk(const RnnP& p, hipStream_t s) {
+    dim3 grid(p.P, p.Q, 2);
+    hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS>), grid, dim3(256), 0, s, p);
+    return 0;
+}
+
+template <int MODE, int MT>
+int launch_split_mt(const RnnP& p, int ks_need, hipStream_t s) {
+    constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD);
+    if (ks_need <= 1) return launch_sk<MODE, MT, 1>(p, s);
+    if (ks_need <= 2) return launch_sk<MODE, MT, 2>(p, s);
+    if (ks_need <= 4) return launch_sk<MODE, MT, 4>(p, s);
+    if constexpr (MODE == LSTM_FWD) return -1;
+    else {
+        if (ks_need <= 8) return launch_sk<MODE, MT, 8>(p, s);
+        if constexpr (FWD) return -1;
+        else {
+            if (ks_need <= 16) return launch_sk<MODE, MT, 16>(p, s);
+            if (ks_need <= 24) return launch_sk<MODE, MT, 24>(p, s);
+            return -1;
+        }
+    }
+}
+
+// Same chunking of the batch as run() in rnn_kernel.h; falls back to the fp32 kernel (returns -1)
+// when the shape is outside the instantiated split kernels.
+template <int MODE>
+int run_split(const char* name, RnnP p, hipStream_t s) {
+    using C = Cfg<MODE>;
+    constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD);
+    AAS_CHECK(p.T >= 1 && p.N >= 1 && p.H >= 1, "%s: bad sizes T=%d N=%d H=%d", name, p.T, p.N, p.H);
+    const int cus = aas_device_cus();
+    AAS_CHECK(cus > 0, "%s: no HIP device", name);
+    p.flags = aas_debug_flags_value();
+    p.P = cdiv(p.H, C::U);
+    AAS_CHECK(p.P * 2 <= cus, "%s: H=%d needs %d resident workgroups, device has %d CUs", name, p.H, p.P * 2, cus);
+    const int Hp = p.P * C::U;
+    const int kxp = FWD ? Hp : C::G * Hp;
+    const int ks_need = cdiv(kxp, 128);
+    const int64_t half_bytes = (int64_t)2 * p.T * p.N * kxp * 2;
+    if (half_bytes >= 0x7fffffffLL) return -1;
+    const int mt = p.N <= 16 ? 1 : 2;
+    const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
+    for (int n0 = 0; n0 < p.N; n0 += qmax * mt * 16) {
+        p.n0 = n0;
+        const int rows = (p.N - n0) < qmax * mt * 16 ? (p.N - n0) : qmax * mt * 16;
+        p.n1 = n0 + rows;
+        p.Q = cdiv(rows, mt * 16);
+        AAS_CHECK((p.Q * 2) * CNT_STRIDE <= SYNC_WORDS, "%s: too many batch groups", name);
+        AAS_HIP(hipMemsetAsync(p.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
+        int rc = (mt == 1) ? launch_split_mt<MODE, 1>(p, ks_need, s) : launch_split_mt<MODE, 2>(p, ks_need, s);
+        if (rc != 0) return -1;
+        AAS_LAUNCH_CHECK(name);
+    }
+    return 0;
+}
+
+template <int MODE>
+int run_any(const char* name, RnnP p, hipStream_t s) {
+    if (p.xchg && aas_precision_value() != 0) {
+        const int rc = run_split<MODE>(name, p, s);
+        if (rc >= 0) return rc;
+    }
+    return run<MODE>(name, p, s);
+}
+
+}  // namespace

@@ -34,6 +34,17 @@ def rnn_timeout_flag(dev=None):
     return bad
 
 
+def _xchg_buf(dev, T, N, H, G):
+    """split-bf16 exchange scratch of the persistent RNN kernels (per device+stream, grown on demand)."""
+    need = int(lib().aas_rnn_xchg_bytes(T, N, H, G))
+    key = ("xchg", dev, torch.cuda.current_stream().cuda_stream)
+    b = _scratch.get(key)
+    if b is None or b.numel() < need:
+        b = torch.empty(need, dtype=torch.uint8, device=dev)
+        _scratch[key] = b
+    return b
+
+
 def _wsd(dev, n):
     key = ("wsd", dev, torch.cuda.current_stream().cuda_stream)
     b = _scratch.get(key)
@@ -271,17 +282,18 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
     hout = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
     gact = torch.empty((2, T, N, 4 * H), device=dev, dtype=torch.float32)
     sync = _sync_buf(dev)
+    xchg = _xchg_buf(dev, T, N, H, G)
     rflops = 2.0 * 2 * T * N * H * G * H  # both directions, T steps of [N,H]x[H,G*H]
     if kind == "lstm":
         cst = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
         with _timed("rnn", "lstm_fwd", rflops):
             check(lib().aas_lstm_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(cst),
-                                     ptr(sync)), "aas_lstm_fwd")
+                                     ptr(sync), ptr(xchg)), "aas_lstm_fwd")
     else:
         cst = None
         with _timed("rnn", "gru_fwd", rflops):
-            check(lib().aas_gru_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync)),
-                  "aas_gru_fwd")
+            check(lib().aas_gru_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync),
+                                    ptr(xchg)), "aas_gru_fwd")
     return hout, gact, cst
 
 
@@ -293,18 +305,19 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     dev = x.device
     dy = _c(dy)
     sync = _sync_buf(dev)
+    xchg = _xchg_buf(dev, T, N, H, G)
     dgx = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
     rflops = 2.0 * 2 * T * N * H * GH
     if kind == "lstm":
         with _timed("rnn", "lstm_bwd", rflops):
             check(lib().aas_lstm_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), ptr(dgx),
-                                     ptr(sync)), "aas_lstm_bwd")
+                                     ptr(sync), ptr(xchg)), "aas_lstm_bwd")
         dgh = dgx
     else:
         dgh = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
         with _timed("rnn", "gru_bwd", rflops):
             check(lib().aas_gru_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(dgx),
-                                    ptr(dgh), ptr(sync)), "aas_gru_bwd")
+                                    ptr(dgh), ptr(sync), ptr(xchg)), "aas_gru_bwd")
     x2 = x.view(T * N, I)
     R = T * N
     dx = None

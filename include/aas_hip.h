@@ -93,21 +93,26 @@ int aas_sqsum_f32(aasStream_t stream, const float* x, int64_t n, double* acc);
  * agent-scope arrival counter per (batch group, direction).
  */
 size_t aas_rnn_sync_bytes(void);
+/* bytes of the split-bf16 exchange scratch `xchg` (gates = 4 LSTM / 3 GRU); pass xchg = NULL to force the
+ * exact-fp32 kernels.  With aas_set_precision(1) and xchg != NULL the exchanged vector is published as bf16
+ * hi/lo pairs and the recurrent product runs as hi*hi + lo*hi + hi*lo on bf16 MFMA (fp32 accumulate). */
+size_t aas_rnn_xchg_bytes(int T, int N, int H, int gates);
 int aas_lstm_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh,
-                 const float* w_hh_rev, float* hout, float* gact, float* cst, void* sync);
+                 const float* w_hh_rev, float* hout, float* gact, float* cst, void* sync, void* xchg);
 /* BPTT.  dy [T,N,H] is the gradient wrt (h_fwd + h_bwd) (shared by both directions);
  * dgates [T,N,2,4H] receives d(loss)/d(pre) (same layout as pre). */
 int aas_lstm_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh,
-                 const float* w_hh_rev, const float* gact, const float* cst, float* dgates, void* sync);
+                 const float* w_hh_rev, const float* gact, const float* cst, float* dgates, void* sync, void* xchg);
 
 /* Bidirectional bias-free GRU (cuDNN RNN under model.py:73-74,83), gate order r,z,n:
  *   pre [T,N,2,3H]; w_hh, w_hh_rev [3H,H]; hout [2,T,N,H];
  *   gact [2,T,N,4H] saves r, z, n and hn = (W_hn h_{t-1}) for backward. */
 int aas_gru_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh,
-                const float* w_hh_rev, float* hout, float* gact, void* sync);
+                const float* w_hh_rev, float* hout, float* gact, void* sync, void* xchg);
 /* dgx [T,N,2,3H] = d/d(pre) (for dW_ih, dx); dgh [T,N,2,3H] = d/d(W_hh h) (for dW_hh). */
 int aas_gru_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh,
-                const float* w_hh_rev, const float* hout, const float* gact, float* dgx, float* dgh, void* sync);
+                const float* w_hh_rev, const float* hout, const float* gact, float* dgx, float* dgh, void* sync,
+                void* xchg);
 
 /* ---------------------------------------------------------------- batch norm (train mode) -----
  * Rows-by-channels BatchNorm with batch statistics (nn.BatchNorm1d in train mode: model.py:72,82

@@ -30,17 +30,18 @@ def rnn_case(kind, T, N, H):
     dy = torch.randn(T, N, H, device=dev)
     L = _lib.lib()
     sync = ops._sync_buf(x.device)
+    xc = ops._xchg_buf(x.device, T, N, H, G)
     pre = torch.randn(T, N, 2, G * H, device=dev)
     dgx = torch.empty(T, N, 2, G * H, device=dev)
     dgh = torch.empty(T, N, 2, G * H, device=dev)
     s = _lib.stream()
     p = _lib.ptr
     if kind == "lstm":
-        f = lambda: L.aas_lstm_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(cst), p(sync))
-        b = lambda: L.aas_lstm_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(gact), p(cst), p(dgx), p(sync))
+        f = lambda: L.aas_lstm_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(cst), p(sync), p(xc))
+        b = lambda: L.aas_lstm_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(gact), p(cst), p(dgx), p(sync), p(xc))
     else:
-        f = lambda: L.aas_gru_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(sync))
-        b = lambda: L.aas_gru_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(hout), p(gact), p(dgx), p(dgh), p(sync))
+        f = lambda: L.aas_gru_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(sync), p(xc))
+        b = lambda: L.aas_gru_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(hout), p(gact), p(dgx), p(dgh), p(sync), p(xc))
     return f, b
 
 
@@ -48,8 +49,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flags", default="0")
     ap.add_argument("--gemm", action="store_true")
+    ap.add_argument("--precision", type=int, default=1)
     a = ap.parse_args()
     L = _lib.lib()
+    L.aas_set_precision(a.precision)
     cases = [("lstm", 200, 30, 500), ("gru", 85, 30, 1000), ("lstm", 200, 60, 500)]
     for kind, T, N, H in cases:
         f, b = rnn_case(kind, T, N, H)
