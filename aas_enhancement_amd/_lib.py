@@ -67,6 +67,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, c_int)
+        if os.environ.get("AAS_PRECISION") in ("0", "1"):  # 0 = exact fp32 MFMA, 1 = split-bf16 (library default)
+            L.aas_set_precision(int(os.environ["AAS_PRECISION"]))
         _lib = L
     return _lib
 

@@ -43,9 +43,14 @@ int aas_precision_value();
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-// tanh with full fp32 accuracy (tanhf from ocml)
-__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+// sigmoid / tanh on the hardware exp + reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error ~1e-7,
+// far inside the 1e-3 parity budget, and ~5x fewer instructions than ocml tanhf on the serial critical path
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    const float e = __expf(-2.0f * fabsf(x));            // in (0, 1]: no overflow
+    const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+    return copysignf(t, x);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

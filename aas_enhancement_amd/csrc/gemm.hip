@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 
 
 // =================================================================================================
-// Split-bf16 ("bf16x3") GEMM: every fp32 operand x is staged in LDS as hi = bf16(trunc x) and
+// Split-bf16 ("bf16x3") GEMM: every fp32 operand x is staged in LDS as hi = bf16(x) (RNE) and
 // lo = bf16(x - hi); C += Ah*Bh + Al*Bh + Ah*Bl on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 // Dropped term Al*Bl ~ 2^-16 relative: fp32-class accuracy (~1e-5 rel) at 3/16 of the fp32-MFMA
 // issue time.  Tile 128x128x32, 4 waves (2x2) of 64x64, LDS rows of 32 bf16 padded to 80 B
@@ -207,15 +207,16 @@ constexpr int SARR = 128 * SROW; // bytes per (operand, hi|lo) array
 
 // split 4 floats -> packed hi (2 dwords) and lo (2 dwords)
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
-    // NB: copy the lanes to scalars first - __builtin_bit_cast applied directly to an ext_vector
-    // element (v.y ...) is miscompiled by ROCm 7.2 clang into a read of element 0.
+    // hi = rne_bf16(x), lo = rne_bf16(x - hi): |x - hi - lo| <= 2^-18 |x| (round-to-nearest on both halves gains
+    // two bits over truncation).  NB: copy the lanes to scalars first - __builtin_bit_cast applied directly to an
+    // ext_vector element (v.y ...) is miscompiled by ROCm 7.2 clang into a read of element 0.
     const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
-    const unsigned h0 = __float_as_uint(x0) & 0xFFFF0000u, h1 = __float_as_uint(x1) & 0xFFFF0000u;
-    const unsigned h2 = __float_as_uint(x2) & 0xFFFF0000u, h3 = __float_as_uint(x3) & 0xFFFF0000u;
-    hi.x = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
-    hi.y = __builtin_amdgcn_perm(h3, h2, 0x07060302u);
-    const bf16x2 l01 = {(__bf16)(x0 - __uint_as_float(h0)), (__bf16)(x1 - __uint_as_float(h1))};
-    const bf16x2 l23 = {(__bf16)(x2 - __uint_as_float(h2)), (__bf16)(x3 - __uint_as_float(h3))};
+    const bf16x2 h01 = {(__bf16)x0, (__bf16)x1}, h23 = {(__bf16)x2, (__bf16)x3};
+    const unsigned w01 = __builtin_bit_cast(unsigned, h01), w23 = __builtin_bit_cast(unsigned, h23);
+    hi.x = w01;
+    hi.y = w23;
+    const bf16x2 l01 = {(__bf16)(x0 - __uint_as_float(w01 << 16)), (__bf16)(x1 - __uint_as_float(w01 & 0xFFFF0000u))};
+    const bf16x2 l23 = {(__bf16)(x2 - __uint_as_float(w23 << 16)), (__bf16)(x3 - __uint_as_float(w23 & 0xFFFF0000u))};
     lo.x = __builtin_bit_cast(unsigned, l01);
     lo.y = __builtin_bit_cast(unsigned, l23);
 }

@@ -43,6 +43,7 @@ struct RnnP {
     unsigned* xchg;      // split-bf16 exchange arrays (hi | lo), NULL -> exact fp32 kernels
     int P, Q;
     int n0, n1;          // batch rows [n0, n1) handled by this launch
+    int rpg;             // batch rows per group (<= 16*MT): smaller groups = fewer exchanged bytes per workgroup
     int flags;           // debug/ablation bits (aas_set_debug_flags): 1 no exchange loads, 2 no MFMA, 4 no wait, 8 no publish
 };
 
@@ -72,7 +73,7 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
 }
 
 template <int MODE> struct Cfg;
-template <> struct Cfg<LSTM_FWD> { static constexpr int G = 4, U = 8, NT = 2; };
+template <> struct Cfg<LSTM_FWD> { static constexpr int G = 4, U = 16, NT = 4; };
 template <> struct Cfg<GRU_FWD>  { static constexpr int G = 3, U = 16, NT = 3; };
 template <> struct Cfg<LSTM_BWD> { static constexpr int G = 4, U = 16, NT = 1; };
 template <> struct Cfg<GRU_BWD>  { static constexpr int G = 3, U = 16, NT = 1; };
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
     const int pslice = blockIdx.x, qg = blockIdx.y, d = blockIdx.z;
     const int T = p.T, N = p.N, H = p.H, GH = G * H;
     const int u0 = pslice * U;   // first hidden unit of this workgroup
-    const int q0 = p.n0 + qg * ROWS;  // first batch row
-    const int NB = p.n1;         // rows >= NB belong to a later launch
+    const int q0 = p.n0 + qg * p.rpg;  // first batch row of this group
+    const int NB = min(p.n1, q0 + p.rpg);  // rows >= NB belong to another group / a later launch
     const int Kx = FWD ? H : GH; // length of the exchanged vector per row
     const int kw = KS * 16;      // k-range per wave
     const int kb = wave * kw;
@@ -386,6 +387,16 @@ int launch_mt(const RnnP& p, int ks_need, bool vec, hipStream_t s) {
     }
 }
 
+// rows per group: the smallest of {8, 16, 32} whose grid P x ceil(N/rpg) x 2 fits the CUs (else 32 + chunking)
+inline void pick_groups(int P, int N, int cus, int& mt, int& rpg) {
+    const int cand[3] = {8, 16, 32};
+    rpg = 32;
+    for (int i = 0; i < 3; ++i)
+        if (P * cdiv(N, cand[i]) * 2 <= cus) { rpg = cand[i]; break; }
+    if (N <= 8 && rpg > 8) rpg = 8;
+    mt = rpg > 16 ? 2 : 1;
+}
+
 template <int MODE>
 int run(const char* name, RnnP p, hipStream_t s) {
     using C = Cfg<MODE>;
@@ -401,15 +412,18 @@ int run(const char* name, RnnP p, hipStream_t s) {
     const bool vec = (p.H % 4 == 0);
     const int64_t xbytes = (FWD ? (int64_t)2 * p.T * p.N * p.H : (int64_t)p.T * p.N * 2 * C::G * p.H) * 4;
     AAS_CHECK(xbytes < 0x7fffffffLL, "%s: exchanged buffer of %lld bytes exceeds the 2 GiB buffer-descriptor range", name, (long long)xbytes);
-    // batch rows are independent: process them in chunks of Q groups of (16*mt) rows so that the
-    // persistent grid P x Q x 2 stays resident
-    const int mt = p.N <= 16 ? 1 : 2;
+    // batch rows are independent: they are split into groups of `rpg` rows, one workgroup column per group, so
+    // that the persistent grid P x Q x 2 stays resident; smaller groups mean fewer exchanged bytes per workgroup
+    // and step (the per-CU L2 fetch rate is what bounds a step), so take the smallest that still fits
+    int mt, rpg;
+    pick_groups(p.P, p.N, cus, mt, rpg);
+    p.rpg = rpg;
     const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
-    for (int n0 = 0; n0 < p.N; n0 += qmax * mt * 16) {
+    for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {
         p.n0 = n0;
-        const int rows = (p.N - n0) < qmax * mt * 16 ? (p.N - n0) : qmax * mt * 16;
+        const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
         p.n1 = n0 + rows;
-        p.Q = cdiv(rows, mt * 16);
+        p.Q = cdiv(rows, rpg);
         AAS_CHECK((p.Q * 2) * CNT_STRIDE <= SYNC_WORDS, "%s: too many batch groups", name);
         AAS_HIP(hipMemsetAsync(p.sync, 0, SYNC_WORDS * sizeof(unsigned), s));  // the ERR word after it stays sticky
         int rc = (mt == 1) ? launch_mt<MODE, 1>(p, ks_need, vec, s) : launch_mt<MODE, 2>(p, ks_need, vec, s);

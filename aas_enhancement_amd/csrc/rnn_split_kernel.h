@@ -1,7 +1,7 @@
 // Split-bf16 variant of the persistent recurrent kernels (see rnn_kernel.h for the structure).
 //
 // The exchanged vector (h_t forward, d(gates)_t in BPTT) is published by its PRODUCER already split
-// into bf16 hi = trunc(x) and bf16 lo = rne(x - hi), two values per 32-bit word, in two arrays with
+// into bf16 hi = rne(x) and bf16 lo = rne(x - hi), two values per 32-bit word, in two arrays with
 // a row pitch of Hp = P*U units (pad units are written as zeros).  Consumers load MFMA A-fragments
 // of 8 consecutive k straight from those arrays (16-byte sc1 buffer loads, no VALU in the loop) and
 // issue hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: fp32-class accuracy
@@ -17,9 +17,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split_bf16(float x, unsigned& hi16, unsigned& lo16) {
-    const unsigned h = __float_as_uint(x) & 0xFFFF0000u;
-    const __bf16 l = (__bf16)(x - __uint_as_float(h));
-    hi16 = h >> 16;
+    // round-to-nearest on both halves: |x - hi - lo| <= 2^-18 |x|
+    const __bf16 hb = (__bf16)x;
+    hi16 = (unsigned)__builtin_bit_cast(unsigned short, hb);
+    const __bf16 l = (__bf16)(x - __uint_as_float(hi16 << 16));
     lo16 = (unsigned)__builtin_bit_cast(unsigned short, l);
 }
 
@@ -36,8 +37,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     constexpr bool LSTM = (MODE == LSTM_FWD || MODE == LSTM_BWD);
     constexpr int LDR = red_ld(NT, U);
     constexpr int ROWS = MT * 16;
-    constexpr int UP = U / 2;                           // unit pairs per row in this slice
-    constexpr int EPT = (ROWS * UP + 255) / 256;        // (row, unit-pair) slots per thread
+    constexpr int EPT = (ROWS * U + 255) / 256;         // (row, unit) slots per thread; lanes l, l^1 hold a unit pair
     __shared__ float red[4][ROWS][LDR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     const int T = p.T, N = p.N, H = p.H, GH = G * H;
     const int Hp = p.P * U;                             // padded unit pitch of the exchange arrays
     const int u0 = pslice * U;
-    const int q0 = p.n0 + qg * ROWS;
-    const int NB = p.n1;
+    const int q0 = p.n0 + qg * p.rpg;
+    const int NB = min(p.n1, q0 + p.rpg);
     const int Kxp = FWD ? Hp : G * Hp;                  // exchanged (padded) vector length per row
     const int kb = wave * KS * 32;
     unsigned* cnt = p.sync + (d * p.Q + qg) * CNT_STRIDE;
@@ -96,9 +96,9 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     auto rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)xhi, 0, (int)(xhalf_words * 4), 0x00020000);
     auto rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)xlo, 0, (int)(xhalf_words * 4), 0x00020000);
 
-    float carry[EPT][2];
+    float carry[EPT];
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) carry[i][0] = carry[i][1] = 0.f;
+    for (int i = 0; i < EPT; ++i) carry[i] = 0.f;
 
     for (int s = 0; s < T; ++s) {
         const int fwd_order = (d == 0) ? s : T - 1 - s;
@@ -106,41 +106,37 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
         const int tp = FWD ? (d == 0 ? t - 1 : t + 1) : (d == 0 ? t + 1 : t - 1);
 
         // ---- prefetch the step's private inputs ------------------------------------------------
-        float pin[EPT][2][4];
-        float sav[EPT][2][6];
+        float pin[EPT][4];
+        float sav[EPT][6];
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
             const int idx = tid + i * 256;
-            const int row = idx / UP, up = idx % UP;
-            const int gr = q0 + row;
+            const int row = idx / U, u = idx % U;
+            const int gr = q0 + row, unit = u0 + u;
+            const bool ok = (idx < ROWS * U) && gr < NB && unit < H;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int unit = u0 + 2 * up + e;
-                const bool ok = (idx < ROWS * UP) && gr < NB && unit < H;
+            for (int g = 0; g < 4; ++g) pin[i][g] = 0.f;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pin[i][e][g] = 0.f;
+            for (int g = 0; g < 6; ++g) sav[i][g] = 0.f;
+            if (ok) {
+                const int64_t tn = (int64_t)t * N + gr;
+                if (FWD) {
+                    const float* pp = p.pre + (tn * 2 + d) * GH + unit;
 #pragma unroll
-                for (int g = 0; g < 6; ++g) sav[i][e][g] = 0.f;
-                if (ok) {
-                    const int64_t tn = (int64_t)t * N + gr;
-                    if (FWD) {
-                        const float* pp = p.pre + (tn * 2 + d) * GH + unit;
+                    for (int g = 0; g < G; ++g) pin[i][g] = pp[g * H];
+                } else {
+                    pin[i][0] = p.dy[tn * H + unit];
+                    const float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
 #pragma unroll
-                        for (int g = 0; g < G; ++g) pin[i][e][g] = pp[g * H];
+                    for (int g = 0; g < 4; ++g) sav[i][g] = ga[g * H];
+                    const int tq = (d == 0) ? t - 1 : t + 1;
+                    const bool hasq = (tq >= 0 && tq < T);
+                    const int64_t qn = ((int64_t)d * T * N + (int64_t)tq * N + gr) * H + unit;
+                    if (LSTM) {
+                        sav[i][4] = p.cst[((int64_t)d * T * N + tn) * H + unit];
+                        sav[i][5] = hasq ? p.cst[qn] : 0.f;
                     } else {
-                        pin[i][e][0] = p.dy[tn * H + unit];
-                        const float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) sav[i][e][g] = ga[g * H];
-                        const int tq = (d == 0) ? t - 1 : t + 1;
-                        const bool hasq = (tq >= 0 && tq < T);
-                        const int64_t qn = ((int64_t)d * T * N + (int64_t)tq * N + gr) * H + unit;
-                        if (LSTM) {
-                            sav[i][e][4] = p.cst[((int64_t)d * T * N + tn) * H + unit];
-                            sav[i][e][5] = hasq ? p.cst[qn] : 0.f;
-                        } else {
-                            sav[i][e][5] = hasq ? p.hout[qn] : 0.f;
-                        }
+                        sav[i][5] = hasq ? p.hout[qn] : 0.f;
                     }
                 }
             }
@@ -218,22 +214,18 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
         }
         __syncthreads();
 
-        // ---- gate math: one (row, unit pair) per thread slot ------------------------------------
+        // ---- gate math: one (row, unit) per thread slot; lanes l and l^1 (adjacent units) pair up to publish
+        //      one hi word and one lo word ---------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
             const int idx = tid + i * 256;
-            const int row = idx / UP, up = idx % UP;
-            const int gr = q0 + row;
-            if (!((idx < ROWS * UP) && gr < NB)) continue;
+            const int row = idx / U, u = idx % U;
+            const int gr = q0 + row, unit = u0 + u;
+            const bool rowok = (idx < ROWS * U) && gr < NB;
+            const bool ok = rowok && unit < H;
             const int64_t tn = (int64_t)t * N + gr;
-            float xv[2][4];  // values to publish: fwd [e][0] = h; bwd [e][g] = exchanged gate gradients
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int u = 2 * up + e, unit = u0 + u;
-                const bool ok = unit < H;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) xv[e][g] = 0.f;
-                if (!ok) continue;
+            float xv[4] = {0.f, 0.f, 0.f, 0.f};  // published values: fwd [0] = h; bwd [g] = exchanged gate gradients
+            if (ok) {
                 float rs[G];
                 if (FWD) {
 #pragma unroll
@@ -243,69 +235,72 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     rs[0] = red[0][row][u] + red[1][row][u] + red[2][row][u] + red[3][row][u];
                 }
                 if (MODE == LSTM_FWD) {
-                    const float ig = sigmoidf_(pin[i][e][0] + rs[0]);
-                    const float fg = sigmoidf_(pin[i][e][1] + rs[1]);
-                    const float gg = tanhf_(pin[i][e][2] + rs[2]);
-                    const float og = sigmoidf_(pin[i][e][3] + rs[3]);
-                    const float c = fg * carry[i][e] + ig * gg;
-                    carry[i][e] = c;
+                    const float ig = sigmoidf_(pin[i][0] + rs[0]);
+                    const float fg = sigmoidf_(pin[i][1] + rs[1]);
+                    const float gg = tanhf_(pin[i][2] + rs[2]);
+                    const float og = sigmoidf_(pin[i][3] + rs[3]);
+                    const float c = fg * carry[i] + ig * gg;
+                    carry[i] = c;
                     const float h = og * tanhf_(c);
-                    xv[e][0] = h;
+                    xv[0] = h;
                     p.hout[((int64_t)d * T * N + tn) * H + unit] = h;
                     float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
                     ga[0] = ig; ga[H] = fg; ga[2 * H] = gg; ga[3 * H] = og;
                     p.cst[((int64_t)d * T * N + tn) * H + unit] = c;
                 } else if (MODE == GRU_FWD) {
-                    const float rg = sigmoidf_(pin[i][e][0] + rs[0]);
-                    const float zg = sigmoidf_(pin[i][e][1] + rs[1]);
+                    const float rg = sigmoidf_(pin[i][0] + rs[0]);
+                    const float zg = sigmoidf_(pin[i][1] + rs[1]);
                     const float hn = rs[2];
-                    const float ng = tanhf_(pin[i][e][2] + rg * hn);
-                    const float h = (1.f - zg) * ng + zg * carry[i][e];
-                    carry[i][e] = h;
-                    xv[e][0] = h;
+                    const float ng = tanhf_(pin[i][2] + rg * hn);
+                    const float h = (1.f - zg) * ng + zg * carry[i];
+                    carry[i] = h;
+                    xv[0] = h;
                     p.hout[((int64_t)d * T * N + tn) * H + unit] = h;
                     float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
                     ga[0] = rg; ga[H] = zg; ga[2 * H] = ng; ga[3 * H] = hn;
                 } else if (MODE == LSTM_BWD) {
-                    const float dh = pin[i][e][0] + rs[0];
-                    const float ig = sav[i][e][0], fg = sav[i][e][1], gg = sav[i][e][2], og = sav[i][e][3];
-                    const float c = sav[i][e][4], cp = sav[i][e][5];
+                    const float dh = pin[i][0] + rs[0];
+                    const float ig = sav[i][0], fg = sav[i][1], gg = sav[i][2], og = sav[i][3];
+                    const float c = sav[i][4], cp = sav[i][5];
                     const float tc = tanhf_(c);
-                    const float dc = dh * og * (1.f - tc * tc) + carry[i][e];
-                    carry[i][e] = dc * fg;
-                    xv[e][0] = dc * gg * ig * (1.f - ig);
-                    xv[e][1] = dc * cp * fg * (1.f - fg);
-                    xv[e][2] = dc * ig * (1.f - gg * gg);
-                    xv[e][3] = dh * tc * og * (1.f - og);
+                    const float dc = dh * og * (1.f - tc * tc) + carry[i];
+                    carry[i] = dc * fg;
+                    xv[0] = dc * gg * ig * (1.f - ig);
+                    xv[1] = dc * cp * fg * (1.f - fg);
+                    xv[2] = dc * ig * (1.f - gg * gg);
+                    xv[3] = dh * tc * og * (1.f - og);
                     float* dg = p.dg1 + (tn * 2 + d) * GH + unit;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) dg[g * H] = xv[e][g];
+                    for (int g = 0; g < 4; ++g) dg[g * H] = xv[g];
                 } else {  // GRU_BWD
-                    const float dh = pin[i][e][0] + rs[0] + carry[i][e];
-                    const float rg = sav[i][e][0], zg = sav[i][e][1], ng = sav[i][e][2], hn = sav[i][e][3];
-                    const float hp = sav[i][e][5];
-                    carry[i][e] = dh * zg;
+                    const float dh = pin[i][0] + rs[0] + carry[i];
+                    const float rg = sav[i][0], zg = sav[i][1], ng = sav[i][2], hn = sav[i][3];
+                    const float hp = sav[i][5];
+                    carry[i] = dh * zg;
                     const float dnp = dh * (1.f - zg) * (1.f - ng * ng);
                     const float dzp = dh * (hp - ng) * zg * (1.f - zg);
                     const float drp = dnp * hn * rg * (1.f - rg);
-                    xv[e][0] = drp; xv[e][1] = dzp; xv[e][2] = dnp * rg;
+                    xv[0] = drp; xv[1] = dzp; xv[2] = dnp * rg;
                     float* dh_ = p.dg1 + (tn * 2 + d) * GH + unit;
                     dh_[0] = drp; dh_[H] = dzp; dh_[2 * H] = dnp * rg;
                     float* dx_ = p.dg2 + (tn * 2 + d) * GH + unit;
                     dx_[0] = drp; dx_[H] = dzp; dx_[2 * H] = dnp;
                 }
             }
-            // publish hi / lo words (pad units publish zeros)
+            // publish: even-unit lanes store {own, partner} packed hi and lo words (pad units publish zeros)
             constexpr int GX = FWD ? 1 : G;
             const int64_t xr = FWD ? ((int64_t)d * T + t) * N + gr : ((int64_t)t * N + gr) * 2 + d;
-            const int64_t wbase = xr * (Kxp / 2) + (u0 + 2 * up) / 2;
+            const int64_t wbase = xr * (Kxp / 2) + (unit >> 1);
 #pragma unroll
             for (int g = 0; g < GX; ++g) {
-                unsigned h0, l0, h1, l1;
-                split_bf16(xv[0][g], h0, l0);
-                split_bf16(xv[1][g], h1, l1);
-                st_sc1_u32(xhi + wbase + g * (Hp / 2), h0 | (h1 << 16));
-                st_sc1_u32(xlo + wbase + g * (Hp / 2), l0 | (l1 << 16));
+                unsigned h0, l0;
+                split_bf16(xv[g], h0, l0);
+                const unsigned mine = h0 | (l0 << 16);
+                const unsigned other = __shfl_xor(mine, 1, 64);
+                if (rowok && !(u & 1)) {
+                    st_sc1_u32(xhi + wbase + g * (Hp / 2), (mine & 0xFFFFu) | (other << 16));
+                    st_sc1_u32(xlo + wbase + g * (Hp / 2), (mine >> 16) | (other & 0xFFFF0000u));
+                }
             }
         }
         if (!(p.flags & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -327,7 +322,7 @@ int launch_split_mt(const RnnP& p, int ks_need, hipStream_t s) {
     if (ks_need <= 1) return launch_sk<MODE, MT, 1>(p, s);
     if (ks_need <= 2) return launch_sk<MODE, MT, 2>(p, s);
     if (ks_need <= 4) return launch_sk<MODE, MT, 4>(p, s);
-    if constexpr (MODE == LSTM_FWD) return -1;
+    if constexpr (MODE == LSTM_FWD) return -1;  // H > 512: fall back to the fp32 kernel
     else {
         if (ks_need <= 8) return launch_sk<MODE, MT, 8>(p, s);
         if constexpr (FWD) return -1;
@@ -356,13 +351,15 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
     const int ks_need = cdiv(kxp, 128);
     const int64_t half_bytes = (int64_t)2 * p.T * p.N * kxp * 2;
     if (half_bytes >= 0x7fffffffLL) return -1;
-    const int mt = p.N <= 16 ? 1 : 2;
+    int mt, rpg;
+    pick_groups(p.P, p.N, cus, mt, rpg);
+    p.rpg = rpg;
     const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
-    for (int n0 = 0; n0 < p.N; n0 += qmax * mt * 16) {
+    for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {
         p.n0 = n0;
-        const int rows = (p.N - n0) < qmax * mt * 16 ? (p.N - n0) : qmax * mt * 16;
+        const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
         p.n1 = n0 + rows;
-        p.Q = cdiv(rows, mt * 16);
+        p.Q = cdiv(rows, rpg);
         AAS_CHECK((p.Q * 2) * CNT_STRIDE <= SYNC_WORDS, "%s: too many batch groups", name);
         AAS_HIP(hipMemsetAsync(p.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
         int rc = (mt == 1) ? launch_split_mt<MODE, 1>(p, ks_need, s) : launch_split_mt<MODE, 2>(p, ks_need, s);

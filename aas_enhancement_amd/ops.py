@@ -58,9 +58,17 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_precision = [int(__import__('os').environ.get('AAS_PRECISION', '1'))]
+
+
 def set_precision(mode):
     """0 = exact fp32-input MFMA; 1 (library default) = split-bf16 operands (hi/lo, 3 MFMAs, ~1e-5 relative)."""
     check(lib().aas_set_precision(int(mode)), "aas_set_precision")
+    _precision[0] = int(mode)
+
+
+def get_precision():
+    return _precision[0]
 
 
 class Profiler:

@@ -264,13 +264,22 @@ class Trainer(object):
             self._side = torch.cuda.Stream()
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
+        exact_a = getattr(c, "asr_exact_fp32", None)
+        if exact_a is None:
+            exact_a = os.environ.get("AAS_ASR_EXACT", "0") == "1"
+        prev = ops.get_precision()
         with torch.cuda.stream(self._side):
-            leaf_a = enhanced.detach().requires_grad_(True)
-            enhanced.record_stream(self._side)
-            prob = self.ASR(leaf_a).transpose(0, 1)
-            sizes = input_percentages.clone().mul_(int(prob.size(0))).int()
-            l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes) / N_glob
-            l_CTC.backward()
+            if exact_a:
+                ops.set_precision(0)
+            try:
+                leaf_a = enhanced.detach().requires_grad_(True)
+                enhanced.record_stream(self._side)
+                prob = self.ASR(leaf_a).transpose(0, 1)
+                sizes = input_percentages.clone().mul_(int(prob.size(0))).int()
+                l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes) / N_glob
+                l_CTC.backward()
+            finally:
+                ops.set_precision(prev)
         return prob, l_CTC, leaf_a
 
     def train(self):
