@@ -8,6 +8,14 @@
 // (~1e-5 relative, dropped term lo*lo) at 3/16 of the fp32-MFMA issue time.  The W_hh slice is
 // split once before the time loop.  fp32 copies of h / d(gates) are still written (plain stores)
 // for the layer's GEMMs.  Selected by aas_set_precision(1) when the caller passes an exchange buffer.
+//
+// Hand-off without a counter: the exchange arrays are filled with the poison word 0xFFFFFFFF (two bf16
+// NaNs with all mantissa bits set - never produced by the gate math) before the launch; a consumer
+// simply re-issues its sc1 loads until no word of the fragment is poison.  Every word is written by
+// exactly one 4-byte write-through store and every address is written once per launch, so a non-poison
+// word IS the data (the "data is the flag" granule form of MI355X_MICROARCH.md, with 4-byte granules):
+// no drain, no arrival atomic, no poll of a separate flag - one store->load trip per step instead of
+// three dependent round trips.  Spins are bounded (0.5 s) and set the sticky error word.
 #pragma once
 #include "rnn_kernel.h"
 
@@ -38,7 +46,9 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     constexpr int LDR = red_ld(NT, U);
     constexpr int ROWS = MT * 16;
     constexpr int EPT = (ROWS * U + 255) / 256;         // (row, unit) slots per thread; lanes l, l^1 hold a unit pair
-    __shared__ float red[4][ROWS][LDR];
+    // double-buffered by step parity (one barrier per step) when it fits the 64 KB static LDS limit
+    constexpr bool DB = (2 * 4 * ROWS * LDR * 4 <= 65536);
+    __shared__ float red2[DB ? 2 : 1][4][ROWS][LDR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pslice = blockIdx.x, qg = blockIdx.y, d = blockIdx.z;
@@ -49,7 +59,6 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     const int NB = min(p.n1, q0 + p.rpg);
     const int Kxp = FWD ? Hp : G * Hp;                  // exchanged (padded) vector length per row
     const int kb = wave * KS * 32;
-    unsigned* cnt = p.sync + (d * p.Q + qg) * CNT_STRIDE;
     unsigned* err = p.sync + ERR_WORD;
 
     // ---- B fragments (hi / lo) of this workgroup's W_hh slice ---------------------------------
@@ -149,13 +158,10 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            if (!(p.flags & 4)) {
-                if (tid == 0) wait_counter(cnt, (unsigned)p.P * (unsigned)s, err);
-                __syncthreads();
-            }
             const int m = lane & 15, q = lane >> 4;
             // byte offset (within the hi or lo array) of this lane's first 8 elements
             constexpr unsigned OOB = 0x80000000u;
+            constexpr unsigned POISON = 0xFFFFFFFFu;
             unsigned roff[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -180,11 +186,65 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     }
                 }
             };
+            // a fragment is complete when none of its words is the poison word
+            auto poisoned = [&](const u32x4 (&dh)[CH][MT], const u32x4 (&dl)[CH][MT]) -> bool {
+                unsigned mx = 0u;
+#pragma unroll
+                for (int j = 0; j < CH; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const u32x4 a = dh[j][mt], b = dl[j][mt];
+                        mx = max(mx, max(max(a.x, a.y), max(a.z, a.w)));
+                        mx = max(mx, max(max(b.x, b.y), max(b.z, b.w)));
+                    }
+                return __any(mx == POISON) != 0;
+            };
+            // cheap pre-poll: before streaming the fragments, each wave watches ONE word per producer slice of its
+            // k-range (first row of the group, hi array) with a single 4-byte sc1 load per lane; the full loads
+            // below are still validated word by word, this only keeps 250 workgroups from hammering the fabric
+            // with 16-byte re-loads while the step's data is in flight.
+            if (!(p.flags & 4)) {
+                const int nprod = (KS * 32) / U;               // producer slices inside this wave's k-range
+                const int64_t xr0 = FWD ? ((int64_t)d * T + tp) * N + q0 : ((int64_t)tp * N + q0) * 2 + d;
+                const int kprobe = kb + lane * U;
+                const bool probe = lane < nprod && kprobe < Kxp && !(p.flags & 1);
+                const unsigned* wp = xhi + xr0 * (Kxp / 2) + kprobe / 2;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0;
+                while (true) {
+                    const unsigned w = probe ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    if (!__any(w == POISON)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 255u) == 0) {
+                        if (ld_cnt(err) != 0) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
+                            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int c = 0; c < DEPTH && c < NCH; ++c) issue(c, ahb[c % (DEPTH + 1)], alb[c % (DEPTH + 1)]);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 if (c + DEPTH < NCH) issue(c + DEPTH, ahb[(c + DEPTH) % (DEPTH + 1)], alb[(c + DEPTH) % (DEPTH + 1)]);
+                if (!(p.flags & 4)) {
+                    if (poisoned(ahb[c % (DEPTH + 1)], alb[c % (DEPTH + 1)])) {
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                        unsigned spins = 0;
+                        do {
+                            issue(c, ahb[c % (DEPTH + 1)], alb[c % (DEPTH + 1)]);
+                            if ((++spins & 63u) == 0) {
+                                if (ld_cnt(err) != 0) break;
+                                if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
+                                    if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    break;
+                                }
+                            }
+                        } while (poisoned(ahb[c % (DEPTH + 1)], alb[c % (DEPTH + 1)]));
+                    }
+                }
                 if (!(p.flags & 2)) {
 #pragma unroll
                     for (int j = 0; j < CH; ++j)
@@ -202,6 +262,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                 }
             }
         }
+        float (*red)[ROWS][LDR] = red2[DB ? (s & 1) : 0];
         // ---- cross-wave reduction through LDS ---------------------------------------------------
         {
             const int col = lane & 15, rq = (lane >> 4) * 4;
@@ -297,15 +358,13 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                 split_bf16(xv[g], h0, l0);
                 const unsigned mine = h0 | (l0 << 16);
                 const unsigned other = __shfl_xor(mine, 1, 64);
-                if (rowok && !(u & 1)) {
+                if (rowok && !(u & 1) && s + 1 < T && !(p.flags & 8)) {  // the last step's output is not exchanged
                     st_sc1_u32(xhi + wbase + g * (Hp / 2), (mine & 0xFFFFu) | (other << 16));
                     st_sc1_u32(xlo + wbase + g * (Hp / 2), (mine >> 16) | (other & 0xFFFF0000u));
                 }
             }
         }
-        if (!(p.flags & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0 && !(p.flags & 8)) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!DB) __syncthreads();  // single reduction buffer: readers must finish before the next step's writes
     }
 }
 
@@ -360,8 +419,8 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
         const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
         p.n1 = n0 + rows;
         p.Q = cdiv(rows, rpg);
-        AAS_CHECK((p.Q * 2) * CNT_STRIDE <= SYNC_WORDS, "%s: too many batch groups", name);
-        AAS_HIP(hipMemsetAsync(p.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
+        // poison the exchange arrays (hi | lo): a word is valid data once it is no longer 0xFFFFFFFF
+        AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)2 * half_bytes, s));
         int rc = (mt == 1) ? launch_split_mt<MODE, 1>(p, ks_need, s) : launch_split_mt<MODE, 2>(p, ks_need, s);
         if (rc != 0) return -1;
         AAS_LAUNCH_CHECK(name);
