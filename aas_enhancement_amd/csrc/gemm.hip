@@ -25,6 +25,7 @@ struct GemmP {
     int kdivB;
     int64_t kouterB;
     int splitk;
+    int flags;  // ablation bits (aas_set_debug_flags): 16 skip MFMA, 32 skip LDS staging, 64 skip global loads
 };
 
 __device__ __forceinline__ int64_t krow_addr(int r, int kdiv, int64_t kouter, int64_t ld) {
@@ -283,14 +284,18 @@ __device__ __forceinline__ void sload_rc(const float* __restrict__ base, int64_t
 }
 __device__ __forceinline__ void sstore_rc(char* hi, char* lo, int tid, const f32x4 (&r)[4]) {
     const int kg = tid >> 5, cq = tid & 31;
+    // lanes of a wave write rows 4 apart (80-B rows): un-swizzled that is a 16-way LDS bank conflict.  XOR the
+    // 16-byte pair index with ((row >> 3) & 3): a wave64 8-byte store then takes its 4-cycle floor; readers of a
+    // row-contiguous operand apply the same XOR (rc_swz below).
+    const int kgs = kg ^ (((cq >> 1) & 3) << 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {  // column cq*4 + j gets k = kg*4 .. kg*4+3
         const f32x4 col = {r[0][j], r[1][j], r[2][j], r[3][j]};
         u32x2 h, l;
         split4(col, h, l);
         const int row = cq * 4 + j;
-        *reinterpret_cast<u32x2*>(hi + row * SROW + kg * 8) = h;
-        *reinterpret_cast<u32x2*>(lo + row * SROW + kg * 8) = l;
+        *reinterpret_cast<u32x2*>(hi + row * SROW + kgs * 8) = h;
+        *reinterpret_cast<u32x2*>(lo + row * SROW + kgs * 8) = l;
     }
 }
 
@@ -325,37 +330,34 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    f32x4 ra[4], rb[4];
-    auto gload = [&](int k0) {
+    // two register sets: the global loads of tile i+2 are issued right after tile i has been written to LDS,
+    // so every load has two full k-steps (MFMA phases) to land - the small-grid shapes (wgrad, dgrad with
+    // ~1 block per CU) are latency- not bandwidth-bound
+    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+    auto gload = [&](int k0, f32x4 (&ra)[4], f32x4 (&rb)[4]) {
         if (A_KC) sload_kc<VECA>(A, p.lda, m0, p.M, k0, kend, tid, ra);
         else sload_rc<VECA>(A, p.lda, p.kdivA, p.kouterA, m0, p.M, k0, kend, tid, ra);
         if (B_KC) sload_kc<VECB>(B, p.ldb, n0, p.N, k0, kend, tid, rb);
         else sload_rc<VECB>(B, p.ldb, p.kdivB, p.kouterB, n0, p.N, k0, kend, tid, rb);
     };
-    auto sstore = [&]() {
+    auto sstore = [&](const f32x4 (&ra)[4], const f32x4 (&rb)[4]) {
         char* st = smem;
         if (A_KC) sstore_kc(st, st + SARR, tid, ra); else sstore_rc(st, st + SARR, tid, ra);
         if (B_KC) sstore_kc(st + 2 * SARR, st + 3 * SARR, tid, rb); else sstore_rc(st + 2 * SARR, st + 3 * SARR, tid, rb);
     };
-    // single LDS stage (40 KB -> 3-4 blocks per CU hide the two barriers per k-step); the next tile's
-    // global loads are in flight in registers while the MFMAs of the current tile issue
-    gload(kbeg);
     const int l31 = lane & 31, lh = lane >> 5;
-    for (int k0 = kbeg; k0 < kend; k0 += SBK) {
-        const bool more = (k0 + SBK) < kend;
-        sstore();
-        __syncthreads();
-        if (more) gload(k0 + SBK);
+    auto compute = [&]() {
         const char* st = smem;
 #pragma unroll
         for (int kk = 0; kk < SBK; kk += 16) {
             // A operand of 32x32x16: lane (row l&31, half l>>5) holds k = 8*half + j; same map for B columns
-            const int ko = (kk + lh * 8) * 2;
+            const int px = kk / 8 + lh;  // 16-byte pair index within the 64-byte row of 32 k
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int ra_ = (wm * 64 + t * 32 + l31) * SROW + ko;
-                const int rb_ = (wn * 64 + t * 32 + l31) * SROW + ko;
+                const int rowa = wm * 64 + t * 32 + l31, rowb = wn * 64 + t * 32 + l31;
+                const int ra_ = rowa * SROW + (A_KC ? px : (px ^ ((rowa >> 3) & 3))) * 16;
+                const int rb_ = rowb * SROW + (B_KC ? px : (px ^ ((rowb >> 3) & 3))) * 16;
                 ah[t] = *reinterpret_cast<const bf16x8*>(st + ra_);
                 al[t] = *reinterpret_cast<const bf16x8*>(st + SARR + ra_);
                 bh[t] = *reinterpret_cast<const bf16x8*>(st + 2 * SARR + rb_);
@@ -370,7 +372,25 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
                 }
         }
+    };
+    const bool do_mma = !(p.flags & 16), do_st = !(p.flags & 32), do_ld = !(p.flags & 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra0[i] = rb0[i] = ra1[i] = rb1[i] = (f32x4){1.f, 2.f, 3.f, 4.f};
+    if (do_ld) gload(kbeg, ra0, rb0);
+    if (do_ld && kbeg + SBK < kend) gload(kbeg + SBK, ra1, rb1);
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * SBK) {
+        if (do_st) sstore(ra0, rb0);
         __syncthreads();
+        if (do_ld && k0 + 2 * SBK < kend) gload(k0 + 2 * SBK, ra0, rb0);
+        if (do_mma) compute();
+        __syncthreads();
+        if (k0 + SBK < kend) {
+            if (do_st) sstore(ra1, rb1);
+            __syncthreads();
+            if (do_ld && k0 + 3 * SBK < kend) gload(k0 + 3 * SBK, ra1, rb1);
+            if (do_mma) compute();
+            __syncthreads();
+        }
     }
     const bool first = (p.splitk <= 1) || (z == 0);
 #pragma unroll
@@ -432,11 +452,16 @@ extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, c
     p.accumulate = accumulate; p.batch = batch; p.sA = strideA; p.sB = strideB; p.sC = strideC;
     p.kdivA = kdivA; p.kouterA = kouterA; p.kdivB = kdivB; p.kouterB = kouterB;
     p.splitk = 1;
+    p.flags = aas_debug_flags_value();
     dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
     // split-K (atomic epilogue) when the MxN grid cannot fill the 256 CUs and K is deep
     int blocks = grid.x * grid.y;
-    if (batch == 1 && blocks < 192 && K >= 1024) {
-        int want = (256 + blocks - 1) / blocks;
+    const bool split_prec = aas_precision_value() != 0;
+    // TN (weight gradients: tiny MxN, deep K) wants >= 2 blocks per CU to hide the k-step latency; its atomic
+    // epilogue traffic (splitk x MxN x 4 B at ~1.3 TB/s) stays far below the time saved
+    const int target = (split_prec && mode == AAS_GEMM_TN) ? 512 : 256;
+    if (batch == 1 && blocks < (target * 3) / 4 && K >= 1024) {
+        int want = (target + blocks - 1) / blocks;
         int maxs = K / 256;
         int sk = want < maxs ? want : maxs;
         if (sk > 16) sk = 16;

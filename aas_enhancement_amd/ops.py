@@ -71,6 +71,29 @@ def get_precision():
     return _precision[0]
 
 
+# ---- off-critical-path weight gradients --------------------------------------------------------------
+# When a parameter's .grad is pre-bound to a flat gradient buffer (dist.FlatBuffers) and DIRECT_WGRAD is on,
+# the recurrent layers' weight-gradient GEMMs run on a side HIP stream and ACCUMULATE straight into .grad
+# (autograd gets None for those inputs): they are only needed at the optimiser step, so they overlap the next
+# layer's persistent BPTT launch instead of sitting on the backward critical path.  sync_wgrad() joins.
+DIRECT_WGRAD = [False]
+_wgrad_streams = {}
+
+
+def wgrad_stream(dev):
+    s = _wgrad_streams.get(dev)
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        _wgrad_streams[dev] = s
+    return s
+
+
+def sync_wgrad():
+    """Make the current stream wait for every side-stream weight-gradient product issued so far."""
+    for s in _wgrad_streams.values():
+        torch.cuda.current_stream().wait_stream(s)
+
+
 class Profiler:
     """Optional HIP-event timing of individual launches on the launching stream (bench.py roofline).
     `classes` selects which launch classes are bracketed with events: "rnn" and/or "gemm"."""
@@ -305,7 +328,8 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
     return hout, gact, cst
 
 
-def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residual, need_dx=True, need_dw=True, rs=None):
+def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residual, need_dx=True, need_dw=True, rs=None,
+               direct=None):
     T, N, I = x.shape
     G = 4 if kind == "lstm" else 3
     H = w_hh.shape[1]
@@ -335,26 +359,39 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         gemm(NN, R, I, GH, dgx, 2 * GH, w_ih_r, I, dx, I, accumulate=True, a_off=GH)
     if not need_dw:
         return dx, None, None, None, None
-    if rs is not None:  # per-utterance weights on the parameter gradients only (after dx used the unscaled d(gates))
-        scale_rows(dgx, rs, N, out=dgx)
-        if dgh is not dgx:
-            scale_rows(dgh, rs, N, out=dgh)
-    dW_ih = torch.empty((GH, I), device=dev, dtype=torch.float32)
-    dW_ih_r = torch.empty((GH, I), device=dev, dtype=torch.float32)
-    gemm(TN, GH, I, R, dgx, 2 * GH, x2, I, dW_ih, I)
-    gemm(TN, GH, I, R, dgx, 2 * GH, x2, I, dW_ih_r, I, a_off=GH)
-    dW_hh = torch.empty((GH, H), device=dev, dtype=torch.float32)
-    dW_hh_r = torch.empty((GH, H), device=dev, dtype=torch.float32)
-    if T > 1:
-        Rm = (T - 1) * N
-        # forward direction: sum_{t>=1} dg[t,:,0,:]^T h_f[t-1]
-        gemm(TN, GH, H, Rm, dgh, 2 * GH, hout, H, dW_hh, H, a_off=N * 2 * GH)
-        # reverse direction: sum_{t<=T-2} dg[t,:,1,:]^T h_r[t+1]
-        gemm(TN, GH, H, Rm, dgh, 2 * GH, hout, H, dW_hh_r, H, a_off=GH, b_off=T * N * H + N * H)
-    else:
-        dW_hh.zero_()
-        dW_hh_r.zero_()
-    return dx, dW_ih, dW_hh, dW_ih_r, dW_hh_r
+
+    def wgrads(out, acc):
+        if rs is not None:  # per-utterance weights on the parameter gradients only (dx used the unscaled d(gates))
+            scale_rows(dgx, rs, N, out=dgx)
+            if dgh is not dgx:
+                scale_rows(dgh, rs, N, out=dgh)
+        gemm(TN, GH, I, R, dgx, 2 * GH, x2, I, out[0], I, accumulate=acc)
+        gemm(TN, GH, I, R, dgx, 2 * GH, x2, I, out[2], I, a_off=GH, accumulate=acc)
+        if T > 1:
+            Rm = (T - 1) * N
+            # forward direction: sum_{t>=1} dg[t,:,0,:]^T h_f[t-1]
+            gemm(TN, GH, H, Rm, dgh, 2 * GH, hout, H, out[1], H, a_off=N * 2 * GH, accumulate=acc)
+            # reverse direction: sum_{t<=T-2} dg[t,:,1,:]^T h_r[t+1]
+            gemm(TN, GH, H, Rm, dgh, 2 * GH, hout, H, out[3], H, a_off=GH, b_off=T * N * H + N * H, accumulate=acc)
+        elif not acc:
+            out[1].zero_()
+            out[3].zero_()
+
+    if direct is not None:
+        main = torch.cuda.current_stream()
+        side = wgrad_stream(dev)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            wgrads(direct, True)
+        for t_ in (dgx, dgh, x, hout):
+            t_.record_stream(side)
+        return dx, None, None, None, None
+    outs = [torch.empty((GH, I), device=dev, dtype=torch.float32), torch.empty((GH, H), device=dev, dtype=torch.float32),
+            torch.empty((GH, I), device=dev, dtype=torch.float32), torch.empty((GH, H), device=dev, dtype=torch.float32)]
+    wgrads(outs, False)
+    return dx, outs[0], outs[1], outs[2], outs[3]
 
 
 class _BiRNNLayer(torch.autograd.Function):
@@ -365,6 +402,7 @@ class _BiRNNLayer(torch.autograd.Function):
     def forward(ctx, x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual, rs=None):
         require_cuda(x, w_ih, w_hh)
         ctx.rs = rs
+        ctx.params = (w_ih, w_hh, w_ih_r, w_hh_r)  # the nn.Parameters themselves (for the direct-accumulate path)
         x = _c(x)
         w_ih, w_hh, w_ih_r, w_hh_r = _c(w_ih), _c(w_hh), _c(w_ih_r), _c(w_hh_r)
         hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r)
@@ -376,8 +414,14 @@ class _BiRNNLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst = ctx.saved_tensors
+        direct = None
+        if DIRECT_WGRAD[0] and all(ctx.needs_input_grad[1:5]):
+            gr = [getattr(p_, "grad", None) for p_ in ctx.params]
+            if all(g is not None and g.is_contiguous() and g.shape == p_.shape for g, p_ in zip(gr, ctx.params)):
+                direct = gr
         dx, a, b, c, d = _birnn_bwd(ctx.kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, ctx.residual,
-                                    need_dx=ctx.needs_input_grad[0], need_dw=any(ctx.needs_input_grad[1:5]), rs=ctx.rs)
+                                    need_dx=ctx.needs_input_grad[0], need_dw=any(ctx.needs_input_grad[1:5]), rs=ctx.rs,
+                                    direct=direct)
         return dx, a, b, c, d, None, None, None
 
 

@@ -106,10 +106,12 @@ class Trainer(object):
             self._flat["A"] = FlatBuffers(self.ASR)
         mk = lambda f: FlatAdam(f, lr=c.lr, betas=(self.beta1, self.beta2), amsgrad=True)
         self._opts = (mk(self._flat["G"]), mk(self._flat["A"]) if "A" in self._flat else None, mk(self._flat["D"]))
+        ops.DIRECT_WGRAD[0] = True  # recurrent-layer weight gradients accumulate into the flat buffers on a side stream
         return self._opts
 
     def zero_grad_all(self):
         if getattr(self, "_flat", None):
+            ops.sync_wgrad()
             for f in self._flat.values():
                 f.zero_grad()
         else:
@@ -118,6 +120,7 @@ class Trainer(object):
     def get_gradient_norm(self, model):
         """sqrt(sum_p sum grad^2) (:353-361): fp64 device accumulator, one launch on the flat buffer."""
         dev = next(model.parameters()).device
+        ops.sync_wgrad()
         acc = torch.zeros((1,), device=dev, dtype=torch.float64)
         flat = getattr(self, "_flat", None)
         key = "G" if model is self.G else ("D" if model is self.D else "A")
@@ -167,6 +170,7 @@ class Trainer(object):
             l_adv_ny_G.backward(retain_graph=True)
             if log_norms:
                 g_adv = self.get_gradient_norm(self.G)
+            ops.sync_wgrad()
             self._flat["D"].zero_grad()   # == self.D.zero_grad() (:152)
             ae_ny_D = self.D(enhanced_D)
             l_adv_ny_D, _ = self.diffLoss(ae_ny_D, enhanced_D, mask)
@@ -209,6 +213,7 @@ class Trainer(object):
                 l_adv_ny_G, _ = self.diffLoss(ae_ny_G, leaf, mask)
                 l_adv_ny_G = l_adv_ny_G * c.w_adversarial
                 l_adv_ny_G.backward()
+                ops.sync_wgrad()
                 ops.axpby_(self._flat["D"].flat_g, self._flat["D"].flat_g, -float(self.kt), 0.0)
                 ae_cl = self.D(cl_inputs)
                 l_adv_cl, _ = self.diffLoss(ae_cl, cl_inputs, cl_mask)
@@ -219,6 +224,7 @@ class Trainer(object):
                 g_adv = self.get_gradient_norm(self.G)
                 leaf.grad = None
             if dp.active:  # D's all-reduce overlaps the acoustic branch and E's backward
+                ops.sync_wgrad()
                 handle_d = dp.allreduce_sum_(self._flat["D"].flat_g, async_op=True)
             # CTC loss (:163-172).  The acoustic branch A(enhanced) -> CTC -> backward is independent of the
             # D branch above: it was enqueued on a second HIP stream BEFORE the D branch (see _acoustic_branch),
@@ -231,6 +237,7 @@ class Trainer(object):
             enhanced.backward(gsum)
             if log_norms:
                 g_ctc_adv = self.get_gradient_norm(self.G)
+        ops.sync_wgrad()  # join the side-stream weight-gradient products before the gradients are consumed
         # data parallel: SUM all-reduce of the flat gradient buffers (RCCL over xGMI)
         if dp.active:
             if handle_d is None:

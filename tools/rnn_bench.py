@@ -50,11 +50,13 @@ def main():
     ap.add_argument("--flags", default="0")
     ap.add_argument("--gemm", action="store_true")
     ap.add_argument("--precision", type=int, default=1)
+    ap.add_argument("--gflags", default="0")
+    ap.add_argument("--skip-rnn", action="store_true")
     a = ap.parse_args()
     L = _lib.lib()
     L.aas_set_precision(a.precision)
     cases = [("lstm", 200, 30, 500), ("gru", 85, 30, 1000), ("lstm", 200, 60, 500)]
-    for kind, T, N, H in cases:
+    for kind, T, N, H in ([] if a.skip_rnn else cases):
         f, b = rnn_case(kind, T, N, H)
         for fl in [int(v) for v in a.flags.split(",")]:
             L.aas_set_debug_flags(fl)
@@ -75,8 +77,13 @@ def main():
             else:
                 A, B = torch.randn(K, M, device="cuda"), torch.randn(K, N, device="cuda"); lda, ldb = M, N
             C = torch.empty(M, N, device="cuda")
-            t = timeit(lambda: ops.gemm(mode, M, N, K, A, lda, B, ldb, C, N), n=10)
-            print("gemm %-12s M=%5d N=%5d K=%5d  %.3f ms  %.1f TFLOP/s" % (name, M, N, K, t, 2.0 * M * N * K / t / 1e9), flush=True)
+            res = []
+            for fl in [int(v) for v in a.gflags.split(",")]:
+                L.aas_set_debug_flags(fl)
+                res.append("f%d %.3f" % (fl, timeit(lambda: ops.gemm(mode, M, N, K, A, lda, B, ldb, C, N), n=10)))
+            L.aas_set_debug_flags(0)
+            t = float(res[0].split()[1])
+            print("gemm %-12s M=%5d N=%5d K=%5d  %.3f ms  %.1f TFLOP/s  | %s" % (name, M, N, K, t, 2.0 * M * N * K / t / 1e9, "  ".join(res)), flush=True)
 
 
 if __name__ == "__main__":
