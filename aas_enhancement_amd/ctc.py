@@ -17,12 +17,17 @@ class CTCLoss(nn.Module):
         super().__init__()
         self.size_average, self.length_average, self.blank = size_average, length_average, blank
 
-    def forward(self, acts, labels, act_lens, label_lens):
+    def prepare(self, labels, act_lens, label_lens, device):
+        """Optional: upload labels/lengths ahead of the forward pass (see ops.ctc_prepare); pass the result as
+        ``prepared=`` to forward so the loss itself issues no host->device copy."""
+        return ops.ctc_prepare(labels, act_lens, label_lens, device)
+
+    def forward(self, acts, labels, act_lens, label_lens, prepared=None):
         if labels.dim() != 1 or act_lens.dim() != 1 or label_lens.dim() != 1:
             raise ValueError("CTCLoss: labels / act_lens / label_lens must be 1-D")
         if act_lens.numel() != acts.size(1) or label_lens.numel() != acts.size(1):
             raise ValueError("CTCLoss: lengths must have one entry per utterance")
-        cost = ops.ctc_sum(acts, labels, act_lens, label_lens, self.blank)
+        cost = ops.ctc_sum(acts, labels, act_lens, label_lens, self.blank, prepared)
         if self.size_average:
             cost = cost / acts.size(1)
         if self.length_average:

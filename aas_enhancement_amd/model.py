@@ -255,6 +255,13 @@ class DeepSpeech(nn.Module):
         self.fc = nn.Sequential(SequenceWise(_BNLinear(_BNParams(rnn_hidden_size), _FCWeights(rnn_hidden_size, num_classes))))
         self.inference_softmax = InferenceBatchSoftmax()
 
+    def output_length(self, T):
+        """Number of output frames T' for T input frames (two un-padded temporal convolutions, model.py:288-301)."""
+        t = T
+        for i in range(0, len(self.conv), 3):
+            t = (t - self.conv[i].kernel_size) // self.conv[i].stride + 1
+        return t
+
     def forward(self, x):  # [N,nFreq,T] -> [N,T',C]
         h = ops.layout(x, "nct_ntc")                                     # channels-last [N,T,F]
         for i in range(0, len(self.conv), 3):

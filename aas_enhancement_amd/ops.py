@@ -555,23 +555,35 @@ def l1_sum(a, b):
     return _L1Sum.apply(a, b)
 
 
+def ctc_prepare(labels, act_lens, label_lens, device):
+    """Upload the CTC metadata (flat labels, label offsets, label lengths, act lengths) in ONE host->device copy.
+    Call it BEFORE queueing the forward pass: a pageable-memory H2D copy blocks the host until the stream has
+    drained, so doing it lazily inside the loss would serialise the host behind the whole acoustic model."""
+    N = int(label_lens.numel())
+    lab_lens_h = label_lens.to("cpu", torch.int32)
+    max_l = int(lab_lens_h.max().item()) if N > 0 else 0
+    offs_h = torch.zeros(N, dtype=torch.int32)
+    if N > 1:
+        offs_h[1:] = torch.cumsum(lab_lens_h, 0)[:-1].to(torch.int32)
+    nl = int(labels.numel())
+    meta = torch.cat([labels.to("cpu", torch.int32).view(-1), offs_h, lab_lens_h, act_lens.to("cpu", torch.int32)])
+    meta = meta.to(device, non_blocking=True)
+    return dict(meta=meta, nl=nl, N=N, max_l=max_l)
+
+
 class _CTC(torch.autograd.Function):
     """sum_n -log p(l_n | softmax(acts[:len_n, n])); gradient wrt pre-softmax acts (warp-ctc semantics)."""
 
     @staticmethod
-    def forward(ctx, acts, labels, act_lens, label_lens, blank):
+    def forward(ctx, acts, labels, act_lens, label_lens, blank, prepared):
         require_cuda(acts)
         acts = _c(acts)
         T, N, C = acts.shape
         dev = acts.device
-        lab_lens_h = label_lens.to("cpu", torch.int32)
-        max_l = int(lab_lens_h.max().item()) if N > 0 else 0
-        offs_h = torch.zeros(N, dtype=torch.int32)
-        if N > 1:
-            offs_h[1:] = torch.cumsum(lab_lens_h, 0)[:-1].to(torch.int32)
-        meta = torch.cat([labels.to("cpu", torch.int32).view(-1), offs_h, lab_lens_h,
-                          act_lens.to("cpu", torch.int32)]).to(dev, non_blocking=True)
-        nl = labels.numel()
+        pr = prepared if prepared is not None else ctc_prepare(labels, act_lens, label_lens, dev)
+        if pr["N"] != N:
+            raise ValueError("CTC: %d length entries for %d utterances" % (pr["N"], N))
+        meta, nl, max_l = pr["meta"], pr["nl"], pr["max_l"]
         d_lab, d_off, d_ll, d_al = meta[:nl], meta[nl:nl + N], meta[nl + N:nl + 2 * N], meta[nl + 2 * N:]
         smax = 2 * max_l + 1
         ws = torch.empty((N * (T * smax + T),), device=dev, dtype=torch.float64)
@@ -592,11 +604,11 @@ class _CTC(torch.autograd.Function):
         (grads,) = ctx.saved_tensors
         g = _c(g.reshape(-1)[:1].to(torch.float32))
         check(lib().aas_scale_dev_f32(stream(), ptr(grads), ptr(grads), ptr(g), 1.0, grads.numel()), "aas_scale_dev_f32")
-        return grads, None, None, None, None
+        return grads, None, None, None, None, None
 
 
-def ctc_sum(acts, labels, act_lens, label_lens, blank=0):
-    return _CTC.apply(acts, labels, act_lens, label_lens, blank)
+def ctc_sum(acts, labels, act_lens, label_lens, blank=0, prepared=None):
+    return _CTC.apply(acts, labels, act_lens, label_lens, blank, prepared)
 
 
 # --------------------------------------------------------------------------------------- reductions / optimiser

@@ -153,6 +153,11 @@ class Trainer(object):
             attach_n_valid(cl_mask)
         cl_inputs, cl_mask = _get_variable_nograd(cl_inputs), _get_variable_nograd(cl_mask)
         N = inputs.size(0)
+        # CTC metadata goes to the device before any kernel is queued (a pageable H2D copy blocks the host until the
+        # stream drains; done lazily inside the loss it would stall the host behind the whole acoustic model)
+        t_out = self.ASR.output_length(inputs.size(2))
+        sizes = input_percentages.clone().mul_(int(t_out)).int()
+        ctc_meta = self.CTCLoss.prepare(targets, sizes, target_sizes, inputs.device)
         if dp.active:
             nv = lambda m: getattr(m, "n_valid", None) or (int(m.numel()) - int(m.sum().item()))
             N_glob, nv_ny, nv_cl = dp.global_counts([N, nv(mask), nv(cl_mask)])
@@ -178,8 +183,8 @@ class Trainer(object):
             l_adv_ny_D.backward()
             del l_adv_ny_D
             prob = self.ASR(enhanced).transpose(0, 1)
-            sizes = input_percentages.clone().mul_(int(prob.size(0))).int()
-            l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes) / N_glob
+            assert prob.size(0) == t_out
+            l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / N_glob
             l_CTC.backward()
             if log_norms:
                 g_ctc_adv = self.get_gradient_norm(self.G)
@@ -193,7 +198,7 @@ class Trainer(object):
             # iterations g_adv needs E's adversarial-only gradients, so E is back-propagated per loss.
             leaf = enhanced.detach().requires_grad_(True)
             Nn = leaf.size(0)
-            acoustic = self._acoustic_branch(enhanced, targets, input_percentages, target_sizes, N_glob)
+            acoustic = self._acoustic_branch(enhanced, targets, sizes, target_sizes, N_glob, ctc_meta)
             if tuple(cl_inputs.shape[1:]) == tuple(leaf.shape[1:]):
                 # D(enhanced) and D(clean) share ONE batched pass (rows are independent: D has no batch
                 # statistics).  The D-step gradients of the enhanced half are (-kt) x its G-step parameter
@@ -264,7 +269,7 @@ class Trainer(object):
         return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, kt=self.kt,
                     conv_measure=conv_measure, g_adv=g_adv, g_ctc_adv=g_ctc_adv, enhanced=enhanced, prob=prob)
 
-    def _acoustic_branch(self, enhanced, targets, input_percentages, target_sizes, N_glob):
+    def _acoustic_branch(self, enhanced, targets, sizes, target_sizes, N_glob, ctc_meta):
         """A(enhanced) -> CTC/N -> backward down to a private leaf, on the side stream."""
         c = self.config
         if getattr(self, "_side", None) is None:
@@ -282,8 +287,7 @@ class Trainer(object):
                 leaf_a = enhanced.detach().requires_grad_(True)
                 enhanced.record_stream(self._side)
                 prob = self.ASR(leaf_a).transpose(0, 1)
-                sizes = input_percentages.clone().mul_(int(prob.size(0))).int()
-                l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes) / N_glob
+                l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / N_glob
                 l_CTC.backward()
             finally:
                 ops.set_precision(prev)
