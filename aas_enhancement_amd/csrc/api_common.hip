@@ -14,10 +14,13 @@ void aas_set_error(const char* fmt, ...) {
 extern "C" int aas_version(void) { return 1; }
 extern "C" const char* aas_last_error(void) { return g_err; }
 extern "C" int aas_device_cus(void) {
+    static int cached[64] = {0};  // per device ordinal; queried once (keeps the launch path free of runtime queries)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev >= 0 && dev < 64 && cached[dev] > 0) return cached[dev];
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    if (dev >= 0 && dev < 64) cached[dev] = cus;
     return cus;
 }
 

@@ -116,9 +116,14 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ vmax, int64_t n, float b1, float b2, float eps,
-                                                   float step_size, float bc2_sqrt, int amsgrad, float gscale) {
+                                                   float step_size, float bc2_sqrt, int amsgrad, float gscale,
+                                                   const float* __restrict__ d_hyper) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * 256;
+    if (d_hyper) {  // step-dependent scalars kept on the device (hipGraph replay: no host-side bias correction)
+        step_size = d_hyper[0];
+        bc2_sqrt = d_hyper[1];
+    }
     for (; i < n; i += stride) {
         float gi = g[i] * gscale;
         float mo = m[i];
@@ -290,8 +295,18 @@ extern "C" int aas_adam_f32(aasStream_t stream, float* p, const float* g, float*
     float step_size = (float)(lr / bc1);
     float bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n, beta1,
-                       beta2, eps, step_size, bc2_sqrt, amsgrad, grad_scale);
+                       beta2, eps, step_size, bc2_sqrt, amsgrad, grad_scale, (const float*)nullptr);
     AAS_LAUNCH_CHECK("aas_adam_f32");
+    return 0;
+}
+
+extern "C" int aas_adam_dev_f32(aasStream_t stream, float* p, const float* g, float* m, float* v, float* vmax, int64_t n,
+                                float beta1, float beta2, float eps, const float* d_hyper, int amsgrad, float grad_scale) {
+    AAS_CHECK(p && g && m && v && (vmax || !amsgrad) && d_hyper && n >= 0, "aas_adam_dev_f32: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n, beta1,
+                       beta2, eps, 0.f, 1.f, amsgrad, grad_scale, d_hyper);
+    AAS_LAUNCH_CHECK("aas_adam_dev_f32");
     return 0;
 }
 

@@ -555,7 +555,7 @@ def l1_sum(a, b):
     return _L1Sum.apply(a, b)
 
 
-def ctc_prepare(labels, act_lens, label_lens, device):
+def ctc_prepare(labels, act_lens, label_lens, device):  # device may be "cpu": the caller uploads `meta` itself
     """Upload the CTC metadata (flat labels, label offsets, label lengths, act lengths) in ONE host->device copy.
     Call it BEFORE queueing the forward pass: a pageable-memory H2D copy blocks the host until the stream has
     drained, so doing it lazily inside the loss would serialise the host behind the whole acoustic model."""
@@ -614,6 +614,12 @@ def ctc_sum(acts, labels, act_lens, label_lens, blank=0, prepared=None):
 # --------------------------------------------------------------------------------------- reductions / optimiser
 def sqsum_into(acc, t):
     check(lib().aas_sqsum_f32(stream(), ptr(t), t.numel(), ptr(acc)), "aas_sqsum_f32")
+
+
+def adam_step_dev(p, g, m, v, vmax, beta1, beta2, eps, d_hyper, amsgrad=True, grad_scale=1.0):
+    """Adam update with step_size / sqrt(bias_correction2) read from the device tensor d_hyper[2]."""
+    check(lib().aas_adam_dev_f32(stream(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), float(beta1), float(beta2),
+                                 float(eps), ptr(d_hyper), int(amsgrad), float(grad_scale)), "aas_adam_dev_f32")
 
 
 def adam_step(p, g, m, v, vmax, lr, beta1, beta2, eps, step, amsgrad=True, grad_scale=1.0):

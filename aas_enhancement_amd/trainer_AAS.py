@@ -269,6 +269,130 @@ class Trainer(object):
         return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, kt=self.kt,
                     conv_measure=conv_measure, g_adv=g_adv, g_ctc_adv=g_ctc_adv, enhanced=enhanced, prob=prob)
 
+    # ---- hipGraph path ----------------------------------------------------------------------------------
+    # The whole fused iteration (zero-grad .. Adam .. kt update) as ONE device-only launch sequence: kt, the Adam
+    # bias corrections and the loss scalars stay on the device, so the sequence is identical every step and is
+    # captured once per batch signature and replayed (the ~300 launches of a step otherwise cost more host time
+    # than GPU time).  Same kernels, same order, same results as train_step(schedule='fused', log_norms=False).
+    def _device_core(self, inputs, cl_inputs, nv_ny, nv_cl, ctc_meta, capturing=False):
+        c = self.config
+        optimizer_g, optimizer_asr, optimizer_d = self._opts
+        if not capturing:
+            ops.sync_wgrad()
+        for f in self._flat.values():
+            f.flat_g.zero_()
+        N = inputs.size(0)
+        enhanced = self.G(inputs)
+        leaf = enhanced.detach().requires_grad_(True)
+        acoustic = self._acoustic_branch(enhanced, None, None, None, N, ctc_meta)
+        rs = torch.empty(N + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
+        rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
+        rs[N:] = 1.0
+        ae = self.D(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
+        l_adv_ny_G = ops.l1_sum(ae[:N], leaf) * (c.w_adversarial / nv_ny)
+        l_adv_cl = ops.l1_sum(ae[N:], cl_inputs) * (c.w_adversarial / nv_cl)
+        (l_adv_ny_G + l_adv_cl).backward()
+        prob, l_CTC, leaf_a = acoustic
+        torch.cuda.current_stream().wait_stream(self._side)
+        leaf_a.grad.record_stream(torch.cuda.current_stream())
+        enhanced.backward(ops.add3(leaf.grad, leaf_a.grad))
+        ops.sync_wgrad()
+        optimizer_g.step_dev()
+        optimizer_d.step_dev()
+        if optimizer_asr is not None:
+            optimizer_asr.step_dev()
+        packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), l_CTC.detach().reshape(())]).double()
+        # Proportional Control Theory (:190-194) on the device
+        bal = self.gamma * packed[1] - packed[0]
+        self._kt_dev.copy_(torch.clamp(self._kt_dev + self.lb * bal, 0.0, 1.0))
+        self._g_out[:3].copy_(packed)
+        self._g_out[3:4].copy_(self._kt_dev)
+        return enhanced, prob
+
+    def train_step_graph(self, data_list, data_list_cl, iter):
+        """Graph-replayed fused iteration (single GPU, no gradient-norm logging).  Falls back to train_step when the
+        configuration needs host decisions inside the step."""
+        if self._opts is None:
+            self.make_optimizers()
+        c = self.config
+        asr_steps = self._opts[1] is not None
+        # (a trainable A is not captured yet: capture_end faults in the HIP runtime with A's weight-gradient
+        #  side-stream work in the graph - the frozen-A configuration of the benchmark is what is graphed)
+        if self.dp.active or self.schedule != "fused" or asr_steps:
+            return self.train_step(data_list, data_list_cl, iter, log_norms=False)
+        inputs, targets, input_percentages, target_sizes, mask = self._prep(data_list)
+        cl_inputs, cl_mask = data_list_cl[0], data_list_cl[4]
+        if not cl_mask.is_cuda:
+            attach_n_valid(cl_mask)
+        nv = lambda m: getattr(m, "n_valid", None) or (int(m.numel()) - int(m.sum().item()))
+        nv_ny, nv_cl = nv(mask), nv(cl_mask)
+        if tuple(cl_inputs.shape) != tuple(inputs.shape):
+            return self.train_step(data_list, data_list_cl, iter, log_norms=False)
+        t_out = self.ASR.output_length(inputs.size(2))
+        sizes = input_percentages.clone().mul_(int(t_out)).int()
+        meta = ops.ctc_prepare(targets, sizes, target_sizes, "cpu")
+        sig = (tuple(inputs.shape), nv_ny, nv_cl, meta["nl"], meta["max_l"])
+        dev = next(self.G.parameters()).device
+        if getattr(self, "_kt_dev", None) is None:
+            self._kt_dev = torch.zeros(1, device=dev, dtype=torch.float64)
+            self._g_out = torch.zeros(4, device=dev, dtype=torch.float64)
+            self._graphs = {}
+        self._kt_dev.fill_(float(self.kt))
+        g = self._graphs.get(sig)
+        if g is None:
+            st = dict(inputs=torch.empty(inputs.shape, device=dev), cl=torch.empty(cl_inputs.shape, device=dev),
+                      meta=dict(meta=torch.empty(meta["meta"].shape, dtype=torch.int32, device=dev), nl=meta["nl"],
+                                N=meta["N"], max_l=meta["max_l"]))
+            st["inputs"].copy_(inputs); st["cl"].copy_(cl_inputs); st["meta"]["meta"].copy_(meta["meta"])
+            # warm-up on a side stream (allocator pools, lazily created scratch), restoring the state it advances
+            pairs = [(self._flat["G"], self._opts[0]), (self._flat["D"], self._opts[2])]
+            if asr_steps:
+                pairs.append((self._flat["A"], self._opts[1]))
+            snap = [(f.flat_p.clone(), o.m.clone(), o.v.clone(), o.vmax.clone() if o.vmax is not None else None, o.step_count)
+                    for f, o in pairs]
+            bn_snap = {k: v.clone() for k, v in self.ASR.state_dict().items() if "running_" in k or "num_batches" in k}
+            ws = torch.cuda.Stream()
+            ws.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ws):
+                self._device_core(st["inputs"], st["cl"], nv_ny, nv_cl, st["meta"])
+            torch.cuda.current_stream().wait_stream(ws)
+            torch.cuda.synchronize()
+
+            def restore():
+                for (f, o), (p_, m_, v_, vm_, sc) in zip(pairs, snap):
+                    f.flat_p.copy_(p_); o.m.copy_(m_); o.v.copy_(v_)
+                    if vm_ is not None:
+                        o.vmax.copy_(vm_)
+                    o.step_count = sc
+                    o._t_dev.fill_(float(sc))
+                sd = self.ASR.state_dict()
+                for k, v in bn_snap.items():
+                    sd[k].copy_(v)
+                self._kt_dev.fill_(float(self.kt))
+
+            restore()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                enh, prob = self._device_core(st["inputs"], st["cl"], nv_ny, nv_cl, st["meta"], capturing=True)
+            for (f, o), sn in zip(pairs, snap):
+                o.step_count = sn[4]  # capture only recorded the launches; nothing ran
+            g = dict(graph=graph, st=st, enh=enh, prob=prob)
+            self._graphs[sig] = g
+        else:
+            g["st"]["inputs"].copy_(inputs, non_blocking=True)
+            g["st"]["cl"].copy_(cl_inputs, non_blocking=True)
+            g["st"]["meta"]["meta"].copy_(meta["meta"], non_blocking=True)
+        g["graph"].replay()
+        for o in (self._opts[0], self._opts[2]) + ((self._opts[1],) if asr_steps else ()):
+            o.step_count += 1
+        l_adv_ny_G_data, l_adv_cl_data, l_ctc_data, kt = self._g_out.tolist()
+        self.ctc_tr_local.update(l_ctc_data, inputs.size(0))
+        g_d_balance = self.gamma * l_adv_cl_data - l_adv_ny_G_data
+        self.kt = kt
+        return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, kt=self.kt,
+                    conv_measure=l_adv_cl_data + abs(g_d_balance), g_adv=None, g_ctc_adv=None, enhanced=g["enh"], prob=g["prob"])
+
     def _acoustic_branch(self, enhanced, targets, sizes, target_sizes, N_glob, ctc_meta):
         """A(enhanced) -> CTC/N -> backward down to a private leaf, on the side stream."""
         c = self.config
@@ -287,7 +411,10 @@ class Trainer(object):
                 leaf_a = enhanced.detach().requires_grad_(True)
                 enhanced.record_stream(self._side)
                 prob = self.ASR(leaf_a).transpose(0, 1)
-                l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / N_glob
+                if targets is None:  # graph path: labels live only in the pre-uploaded device metadata
+                    l_CTC = c.w_acoustic * ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) / N_glob
+                else:
+                    l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / N_glob
                 l_CTC.backward()
             finally:
                 ops.set_precision(prev)

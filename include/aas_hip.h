@@ -166,6 +166,12 @@ int aas_adam_f32(aasStream_t stream, float* p, const float* g, float* m, float* 
                  int64_t n, float lr, float beta1, float beta2, float eps, int step, int amsgrad,
                  float grad_scale);
 
+/* Same update with the step-dependent scalars read from device memory: d_hyper[0] = lr/(1-b1^t),
+ * d_hyper[1] = sqrt(1-b2^t) - lets the whole training step be captured in a hipGraph and replayed. */
+int aas_adam_dev_f32(aasStream_t stream, float* p, const float* g, float* m, float* v, float* vmax,
+                     int64_t n, float beta1, float beta2, float eps, const float* d_hyper, int amsgrad,
+                     float grad_scale);
+
 /* ---------------------------------------------------------------- features --------------------
  * log-Mel filterbank: wave [N,S] -> out [N,n_mels,T] with T = 1 + S/hop; hamming(periodic) window
  * of `win` samples, centre=True reflect padding, |DFT|^2 -> mel -> log1p.  Tables from
