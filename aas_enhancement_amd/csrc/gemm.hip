@@ -492,7 +492,7 @@ extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, c
             if (split) rc = launch_split<true, true>(p, va, vb, grid, s);
             else launch<true, true>(p, va, vb, grid, s);
         } else {
-            vb = al16(B) && ldb % 4 == 0 && N % 4 == 0 && strideB % 4 == 0;
+            vb = al16(B) && ldb % 4 == 0 && N % 4 == 0 && strideB % 4 == 0 && (kdivB == 0 || kouterB % 4 == 0);
             if (split) rc = launch_split<true, false>(p, va, vb, grid, s);
             else launch<true, false>(p, va, vb, grid, s);
         }

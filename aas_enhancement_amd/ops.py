@@ -308,8 +308,14 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
     dev = x.device
     pre = torch.empty((T, N, 2, G * H), device=dev, dtype=torch.float32)
     x2 = x.view(T * N, I)
-    gemm(NT, T * N, G * H, I, x2, I, w_ih, I, pre, 2 * G * H)
-    gemm(NT, T * N, G * H, I, x2, I, w_ih_r, I, pre, 2 * G * H, c_off=G * H)
+    dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4  # element distance between the two directions' W_ih
+    if dw > 0 and dw % 4 == 0:
+        # both directions in ONE batched launch: same A, B strided by the distance between the two weight tensors
+        # (they live in one flat parameter buffer), C = the two column halves of `pre`
+        gemm(NT, T * N, G * H, I, x2, I, w_ih, I, pre, 2 * G * H, batch=2, sA=0, sB=dw, sC=G * H)
+    else:
+        gemm(NT, T * N, G * H, I, x2, I, w_ih, I, pre, 2 * G * H)
+        gemm(NT, T * N, G * H, I, x2, I, w_ih_r, I, pre, 2 * G * H, c_off=G * H)
     hout = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
     gact = torch.empty((2, T, N, 4 * H), device=dev, dtype=torch.float32)
     sync = _sync_buf(dev)
@@ -355,8 +361,13 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     dx = None
     if need_dx:
         dx = torch.empty((T, N, I), device=dev, dtype=torch.float32)
-        gemm(NN, R, I, GH, dgx, 2 * GH, w_ih, I, dx, I, addend=dy if residual else None, ldd=I)
-        gemm(NN, R, I, GH, dgx, 2 * GH, w_ih_r, I, dx, I, accumulate=True, a_off=GH)
+        dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4
+        if dw > 0 and dw % 4 == 0:
+            # dx = [dg_fwd | dg_rev] (K = 2GH) x [W_ih ; W_ih_rev]: one launch, B rows addressed two-level
+            gemm(NN, R, I, 2 * GH, dgx, 2 * GH, w_ih, I, dx, I, addend=dy if residual else None, ldd=I, kdivB=GH, kouterB=dw)
+        else:
+            gemm(NN, R, I, GH, dgx, 2 * GH, w_ih, I, dx, I, addend=dy if residual else None, ldd=I)
+            gemm(NN, R, I, GH, dgx, 2 * GH, w_ih_r, I, dx, I, accumulate=True, a_off=GH)
     if not need_dw:
         return dx, None, None, None, None
 
