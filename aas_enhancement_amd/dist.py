@@ -43,15 +43,30 @@ class DPContext(object):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return [int(round(v)) for v in t.tolist()]
 
+    def _staged(self, tensor):
+        """gloo cannot reduce device tensors on every build: stage through the host (tests only; the RCCL path
+        reduces in place on the device)."""
+        return tensor.is_cuda and dist.get_backend(self.group) == "gloo"
+
     def allreduce_sum_(self, tensor, async_op=False):
         """In-place SUM all-reduce of a (flat gradient) buffer; returns a work handle if async."""
         if not self.active:
             return None
+        if self._staged(tensor):
+            host = tensor.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            tensor.copy_(host)
+            return _Done()
         return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def reduce_scalars(self, tensor):
         if self.active:
-            dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+            if self._staged(tensor):
+                host = tensor.detach().cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                tensor.copy_(host)
+            else:
+                dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
         return tensor
 
     # ---- batch sharding ----------------------------------------------------------------------
@@ -72,6 +87,11 @@ class DPContext(object):
         m = mask.index_select(0, idx.to(mask.device))
         m.n_valid = int(m.numel()) - int(m.sum().item())
         return (inputs.index_select(0, idx.to(inputs.device)), tg, pct.index_select(0, idx), tsz.index_select(0, idx), m)
+
+
+class _Done(object):
+    def wait(self):
+        return True
 
 
 class FlatBuffers(object):
