@@ -23,7 +23,8 @@ namespace {
 
 constexpr int SYNC_WORDS = 1024;  // 4 KiB of arrival counters, zeroed per launch
 constexpr int ERR_WORD = 1024;    // sticky timeout flag, after the counters (caller zero-initialises once)
-constexpr int SYNC_BYTES = (SYNC_WORDS + 16) * 4;
+constexpr int SYNC_BYTES = (SYNC_WORDS + 64) * 4;
+constexpr int STAMP_WORD = 1040;   // 8 x u64 phase totals of workgroup (0,0,0) wave 0 when debug flag 64 is set
 constexpr int CNT_STRIDE = 16;  // one 64-B line per counter
 
 enum Mode { LSTM_FWD = 0, LSTM_BWD = 1, GRU_FWD = 2, GRU_BWD = 3 };

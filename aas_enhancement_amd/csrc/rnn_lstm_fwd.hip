@@ -3,7 +3,7 @@
 extern "C" size_t aas_rnn_sync_bytes(void) { return SYNC_BYTES; }
 // hi + lo arrays of the widest exchanged vector (BPTT: 2*T*N rows x G*Hp bf16, Hp <= H + 15)
 extern "C" size_t aas_rnn_xchg_bytes(int T, int N, int H, int gates) {
-    return (size_t)2 * 2 * T * N * (size_t)gates * (H + 16) * 2;
+    return (size_t)8 * T * N * ((size_t)gates * (H + 16) + 32);
 }
 
 extern "C" int aas_lstm_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh, const float* w_hh_rev, float* hout,

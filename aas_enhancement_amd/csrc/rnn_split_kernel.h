@@ -17,6 +17,8 @@
 // no drain, no arrival atomic, no poll of a separate flag - one store->load trip per step instead of
 // three dependent round trips.  Spins are bounded (0.5 s) and set the sticky error word.
 #pragma once
+#include <type_traits>
+
 #include "rnn_kernel.h"
 
 namespace {
@@ -99,17 +101,20 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 
     // exchange arrays: hi then lo, each rows x (Kxp/2) 32-bit words
     const int64_t xrows = (int64_t)2 * T * N;           // fwd: [2][T][N]; bwd: [T][N][2]
-    const int64_t xhalf_words = xrows * (Kxp / 2);
-    unsigned* xhi = p.xchg;
-    unsigned* xlo = p.xchg + xhalf_words;
-    auto rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)xhi, 0, (int)(xhalf_words * 4), 0x00020000);
-    auto rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)xlo, 0, (int)(xhalf_words * 4), 0x00020000);
+    // row = KC chunks of 128 bytes; chunk c holds elements [32c, 32c+32): 64 B of bf16 hi then 64 B of bf16 lo, so the
+    // hi and lo fragments of a chunk share one 128-byte line (half as many distinct lines per step as two arrays)
+    const int KC = (Kxp + 31) / 32;
+    unsigned* xq = p.xchg;
+    auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xq, 0, (int)(xrows * KC * 128), 0x00020000);
 
     float carry[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; ++i) carry[i] = 0.f;
 
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    const bool stamp = (p.flags & 64) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     for (int s = 0; s < T; ++s) {
+        unsigned long long st0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull, st1 = st0, st2 = st0, st3 = st0;
         const int fwd_order = (d == 0) ? s : T - 1 - s;
         const int t = FWD ? fwd_order : (T - 1 - fwd_order);
         const int tp = FWD ? (d == 0 ? t - 1 : t + 1) : (d == 0 ? t + 1 : t - 1);
@@ -167,24 +172,36 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             for (int mt = 0; mt < MT; ++mt) {
                 const int gr = q0 + mt * 16 + m;
                 const int64_t xr = FWD ? ((int64_t)d * T + tp) * N + gr : ((int64_t)tp * N + gr) * 2 + d;
-                roff[mt] = (gr < NB && !(p.flags & 1)) ? (unsigned)((xr * Kxp + kb + q * 8) * 2) : OOB;
+                roff[mt] = (gr < NB && !(p.flags & 1)) ? (unsigned)((xr * KC + wave * KS) * 128 + q * 16) : OOB;
             }
             const int klane = kb + q * 8;
             constexpr int CH = KS >= 2 ? 2 : 1;
             constexpr int NCH = KS / CH;
             constexpr int DEPTH = NCH >= 3 ? 2 : (NCH >= 2 ? 1 : 0);
             u32x4 ahb[DEPTH + 1][CH][MT], alb[DEPTH + 1][CH][MT];
-            auto issue = [&](int c, u32x4 (&dh)[CH][MT], u32x4 (&dl)[CH][MT]) {
+            // First attempt: PLAIN (cacheable) loads, so the workgroups of one XCD that stream the same rows share
+            // them through that XCD's L2 instead of each fetching them from the Infinity Cache.  This is safe
+            // because the data is its own flag: every word goes poison -> data exactly once per launch, so a stale
+            // L1/L2 copy can only show POISON in a word, never wrong data; a fragment that still shows poison is
+            // re-fetched with sc1 loads (L1/L2-bypassing, always fresh).
+            auto issue_aux = [&](int c, u32x4 (&dh)[CH][MT], u32x4 (&dl)[CH][MT], auto AUX) {
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     const int ks = c * CH + j;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        const unsigned off = (klane + ks * 32 < Kxp) ? roff[mt] + (unsigned)(ks * 64) : OOB;
-                        dh[j][mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_hi, (int)off, 0, 16));
-                        dl[j][mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_lo, (int)off, 0, 16));
+                        const unsigned off = (klane + ks * 32 < Kxp) ? roff[mt] + (unsigned)(ks * 128) : OOB;
+                        dh[j][mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, decltype(AUX)::value));
+                        dl[j][mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off + 64u), 0, decltype(AUX)::value));
                     }
                 }
+            };
+            auto issue = [&](int c, u32x4 (&dh)[CH][MT], u32x4 (&dl)[CH][MT]) {
+                if (p.flags & 32) issue_aux(c, dh, dl, std::integral_constant<int, 16>{});
+                else issue_aux(c, dh, dl, std::integral_constant<int, 0>{});
+            };
+            auto issue_fresh = [&](int c, u32x4 (&dh)[CH][MT], u32x4 (&dl)[CH][MT]) {
+                issue_aux(c, dh, dl, std::integral_constant<int, 16>{});
             };
             // a fragment is complete when none of its words is the poison word
             auto poisoned = [&](const u32x4 (&dh)[CH][MT], const u32x4 (&dl)[CH][MT]) -> bool {
@@ -208,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                 const int64_t xr0 = FWD ? ((int64_t)d * T + tp) * N + q0 : ((int64_t)tp * N + q0) * 2 + d;
                 const int kprobe = kb + lane * U;
                 const bool probe = lane < nprod && kprobe < Kxp && !(p.flags & 1);
-                const unsigned* wp = xhi + xr0 * (Kxp / 2) + kprobe / 2;
+                const unsigned* wp = xq + (xr0 * KC + kprobe / 32) * 32 + (kprobe % 32) / 2;
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
                 while (true) {
@@ -224,6 +241,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     }
                 }
             }
+            if (stamp) st1 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
             for (int c = 0; c < DEPTH && c < NCH; ++c) issue(c, ahb[c % (DEPTH + 1)], alb[c % (DEPTH + 1)]);
 #pragma unroll
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                         unsigned spins = 0;
                         do {
-                            issue(c, ahb[c % (DEPTH + 1)], alb[c % (DEPTH + 1)]);
+                            issue_fresh(c, ahb[c % (DEPTH + 1)], alb[c % (DEPTH + 1)]);
                             if ((++spins & 63u) == 0) {
                                 if (ld_cnt(err) != 0) break;
                                 if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
@@ -262,6 +280,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                 }
             }
         }
+        if (stamp) st2 = __builtin_amdgcn_s_memrealtime();
         float (*red)[ROWS][LDR] = red2[DB ? (s & 1) : 0];
         // ---- cross-wave reduction through LDS ---------------------------------------------------
         {
@@ -275,6 +294,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
         }
         __syncthreads();
 
+        if (stamp) st3 = __builtin_amdgcn_s_memrealtime();
         // ---- gate math: one (row, unit) per thread slot; lanes l and l^1 (adjacent units) pair up to publish
         //      one hi word and one lo word ---------------------------------------------------------------
 #pragma unroll
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             // publish: even-unit lanes store {own, partner} packed hi and lo words (pad units publish zeros)
             constexpr int GX = FWD ? 1 : G;
             const int64_t xr = FWD ? ((int64_t)d * T + t) * N + gr : ((int64_t)t * N + gr) * 2 + d;
-            const int64_t wbase = xr * (Kxp / 2) + (unit >> 1);
+            const int64_t rbase_w = xr * KC * 32;  // row start in 32-bit words
 #pragma unroll
             for (int g = 0; g < GX; ++g) {
                 unsigned h0, l0;
@@ -359,12 +379,22 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                 const unsigned mine = h0 | (l0 << 16);
                 const unsigned other = __shfl_xor(mine, 1, 64);
                 if (rowok && !(u & 1) && s + 1 < T && !(p.flags & 8)) {  // the last step's output is not exchanged
-                    st_sc1_u32(xhi + wbase + g * (Hp / 2), (mine & 0xFFFFu) | (other << 16));
-                    st_sc1_u32(xlo + wbase + g * (Hp / 2), (mine >> 16) | (other & 0xFFFF0000u));
+                    const int k = g * Hp + unit;  // element index of the even unit of the pair within the exchanged row
+                    unsigned* wq = xq + rbase_w + (k / 32) * 32 + (k % 32) / 2;
+                    st_sc1_u32(wq, (mine & 0xFFFFu) | (other << 16));
+                    st_sc1_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
                 }
             }
         }
         if (!DB) __syncthreads();  // single reduction buffer: readers must finish before the next step's writes
+        if (stamp) {
+            const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
+            ph[0] += st1 - st0; ph[1] += st2 - st1; ph[2] += st3 - st2; ph[3] += st4 - st3; ph[4] += st4 - st0;
+        }
+    }
+    if (stamp && tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.sync + STAMP_WORD);
+        for (int i = 0; i < 5; ++i) o[i] = ph[i];
     }
 }
 
@@ -408,8 +438,8 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
     const int Hp = p.P * C::U;
     const int kxp = FWD ? Hp : C::G * Hp;
     const int ks_need = cdiv(kxp, 128);
-    const int64_t half_bytes = (int64_t)2 * p.T * p.N * kxp * 2;
-    if (half_bytes >= 0x7fffffffLL) return -1;
+    const int64_t xbytes = (int64_t)2 * p.T * p.N * ((kxp + 31) / 32) * 128;  // rows x chunks x (64 B hi + 64 B lo)
+    if (xbytes >= 0x7fffffffLL) return -1;
     int mt, rpg;
     pick_groups(p.P, p.N, cus, mt, rpg);
     p.rpg = rpg;
@@ -420,7 +450,7 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
         p.n1 = n0 + rows;
         p.Q = cdiv(rows, rpg);
         // poison the exchange arrays (hi | lo): a word is valid data once it is no longer 0xFFFFFFFF
-        AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)2 * half_bytes, s));
+        AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes, s));
         int rc = (mt == 1) ? launch_split_mt<MODE, 1>(p, ks_need, s) : launch_split_mt<MODE, 2>(p, ks_need, s);
         if (rc != 0) return -1;
         AAS_LAUNCH_CHECK(name);

@@ -62,6 +62,11 @@ def main():
             L.aas_set_debug_flags(fl)
             tf, tb = timeit(f), timeit(b)
             print("%s T=%d N=%d H=%d flags=%2d  fwd %.3f ms (%.2f us/step)  bwd %.3f ms (%.2f us/step)" % (kind, T, N, H, fl, tf, 1e3 * tf / T, tb, 1e3 * tb / T), flush=True)
+            if fl & 64:
+                for nm, fn in (("fwd", f), ("bwd", b)):
+                    fn(); torch.cuda.synchronize()
+                    st = ops._sync_buf(torch.device("cuda", 0)).view(torch.int64)[520:525].tolist()  # word 1040 = int64 index 520
+                    print("   %s phases (us/step, WG0 wave0): wait %.2f  load+mfma %.2f  lds+barrier %.2f  gate+publish %.2f  total %.2f" % ((nm,) + tuple(v * 0.01 / T for v in st)), flush=True)
         L.aas_set_debug_flags(0)
     torch.cuda.synchronize()
     assert not ops.rnn_timeout_flag() or a.flags != "0", "timeout flag set"
