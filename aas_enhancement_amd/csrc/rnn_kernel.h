@@ -178,9 +178,8 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
                     for (int g = 0; g < G; ++g) pin[i][g] = pp[g * H];
                 } else {
                     pin[i][0] = p.dy[tn * H + unit];
-                    const float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) sav[i][g] = ga[g * H];
+                    const f32x4 ga4 = *reinterpret_cast<const f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4);
+                    sav[i][0] = ga4.x; sav[i][1] = ga4.y; sav[i][2] = ga4.z; sav[i][3] = ga4.w;
                     // state at the previous time step IN FORWARD ORDER: t-1 for d=0, t+1 for d=1 (zero at the start)
                     const int tq = (d == 0) ? t - 1 : t + 1;
                     const bool hasq = (tq >= 0 && tq < T);
@@ -313,8 +312,7 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
                 carry[i] = c;
                 const float h = og * tanhf_(c);
                 st_sc1(p.hout + ((int64_t)d * T * N + tn) * H + unit, h);
-                float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
-                ga[0] = ig; ga[H] = fg; ga[2 * H] = gg; ga[3 * H] = og;
+                                *reinterpret_cast<f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4) = (f32x4){ig, fg, gg, og};
                 p.cst[((int64_t)d * T * N + tn) * H + unit] = c;
             } else if (MODE == GRU_FWD) {
                 const float rg = sigmoidf_(pin[i][0] + rs[0]);
@@ -324,8 +322,7 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
                 const float h = (1.f - zg) * ng + zg * carry[i];
                 carry[i] = h;
                 st_sc1(p.hout + ((int64_t)d * T * N + tn) * H + unit, h);
-                float* ga = p.gact + ((int64_t)d * T * N + tn) * 4 * H + unit;
-                ga[0] = rg; ga[H] = zg; ga[2 * H] = ng; ga[3 * H] = hn;
+                                *reinterpret_cast<f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4) = (f32x4){rg, zg, ng, hn};
             } else if (MODE == LSTM_BWD) {
                 const float dh = pin[i][0] + rs[0];
                 const float ig = sav[i][0], fg = sav[i][1], gg = sav[i][2], og = sav[i][3];

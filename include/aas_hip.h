@@ -86,7 +86,7 @@ int aas_sqsum_f32(aasStream_t stream, const float* x, int64_t n, double* acc);
  *                     gate order i,f,g,o (PyTorch)
  *   w_hh, w_hh_rev  [4H,H] each (weight_hh_l0, weight_hh_l0_reverse)
  *   hout  [2,T,N,H]   h_t per direction (time index = position in the sequence, both directions)
- *   gact  [2,T,N,4H]  post-nonlinearity gates (saved for backward);  cst [2,T,N,H] cell states
+ *   gact  [2,T,N,H,4]  post-nonlinearity gates i,f,g,o per unit (saved for backward); cst [2,T,N,H] cell states
  *   sync  >= aas_rnn_sync_bytes() bytes of zero-initialisable device scratch (zeroed by the call)
  * Persistent kernel: one workgroup per (unit slice, batch group, direction); W_hh slices stay
  * in registers for all T steps; h_t is exchanged through L2 with write-through stores and an
@@ -106,7 +106,7 @@ int aas_lstm_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const
 
 /* Bidirectional bias-free GRU (cuDNN RNN under model.py:73-74,83), gate order r,z,n:
  *   pre [T,N,2,3H]; w_hh, w_hh_rev [3H,H]; hout [2,T,N,H];
- *   gact [2,T,N,4H] saves r, z, n and hn = (W_hn h_{t-1}) for backward. */
+ *   gact [2,T,N,H,4] saves r, z, n and hn = (W_hn h_{t-1}) per unit for backward. */
 int aas_gru_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh,
                 const float* w_hh_rev, float* hout, float* gact, void* sync, void* xchg);
 /* dgx [T,N,2,3H] = d/d(pre) (for dW_ih, dx); dgh [T,N,2,3H] = d/d(W_hh h) (for dW_hh). */
