@@ -397,7 +397,8 @@ class Trainer(object):
         """A(enhanced) -> CTC/N -> backward down to a private leaf, on the side stream."""
         c = self.config
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream()
+            # AAS_SERIAL_ASR=1: run the acoustic branch on the main stream (no second chain of persistent kernels)
+            self._side = torch.cuda.current_stream() if os.environ.get("AAS_SERIAL_ASR", "0") == "1" else torch.cuda.Stream()
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
         exact_a = getattr(c, "asr_exact_fp32", None)

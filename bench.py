@@ -179,6 +179,17 @@ def main():
         value = world * N_PER * T / (dt / a.steps)
         dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
         name, d = dom
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot
+        # share a pass, and counters cannot be read from inside the process): the committed summary of those passes
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))
+            key = {"lstm_bwd": "rnn_split_kernel<1, 1, 16>", "lstm_fwd": "rnn_split_kernel<0, 1, 4>",
+                   "gru_bwd": "rnn_split_kernel<3, 1, 24>", "gru_fwd": "rnn_split_kernel<2, 1, 8>"}.get(name)
+            if key and key in pmc["kernels"]:
+                traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            traffic = None
         achieved = d["flops_per_launch"] / (d["avg_ms"] * 1e-3) / 1e12
         out = {
             "metric": "AAS train-step frames/sec (80-dim LMFB, batch 30 per GPU)", "value": value, "unit": "frames/s",
@@ -189,7 +200,9 @@ def main():
                        "global_batch": world * N_PER, "frames_per_utt": T, "parallelism": "dp%d" % world,
                        "last_losses": {k: r[k] for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt")}},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_note": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes "
+                                         "(profiles/r01b_pmc_traffic.json); algorithmic bytes per launch 0.26 GB (N=30) / 0.53 GB (N=60)",
                          "timing": ("HIP events around each launch on its launch stream, %d eager steps run right after the "
                                     "timed graph-replayed region" % psteps) if use_graph else "HIP events around each launch inside the timed region",
                          "avg_launch_ms": d["avg_ms"], "launches_per_step": d["count"] / psteps,
