@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             const bool ok = rowok && unit < H;
             const int64_t tn = (int64_t)t * N + gr;
             float xv[4] = {0.f, 0.f, 0.f, 0.f};  // published values: fwd [0] = h; bwd [g] = exchanged gate gradients
+            float kp[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // values only this layer's later GEMMs / BPTT need (stored after the publish)
             if (ok) {
                 float rs[G];
                 if (FWD) {
@@ -323,9 +324,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     carry[i] = c;
                     const float h = og * tanhf_(c);
                     xv[0] = h;
-                    p.hout[((int64_t)d * T * N + tn) * H + unit] = h;
-                                        *reinterpret_cast<f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4) = (f32x4){ig, fg, gg, og};
-                    p.cst[((int64_t)d * T * N + tn) * H + unit] = c;
+                    kp[0] = ig; kp[1] = fg; kp[2] = gg; kp[3] = og; kp[4] = c;
                 } else if (MODE == GRU_FWD) {
                     const float rg = sigmoidf_(pin[i][0] + rs[0]);
                     const float zg = sigmoidf_(pin[i][1] + rs[1]);
@@ -334,8 +333,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     const float h = (1.f - zg) * ng + zg * carry[i];
                     carry[i] = h;
                     xv[0] = h;
-                    p.hout[((int64_t)d * T * N + tn) * H + unit] = h;
-                                        *reinterpret_cast<f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4) = (f32x4){rg, zg, ng, hn};
+                    kp[0] = rg; kp[1] = zg; kp[2] = ng; kp[3] = hn;
                 } else if (MODE == LSTM_BWD) {
                     const float dh = pin[i][0] + rs[0];
                     const float ig = sav[i][0], fg = sav[i][1], gg = sav[i][2], og = sav[i][3];
@@ -347,9 +345,6 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     xv[1] = dc * cp * fg * (1.f - fg);
                     xv[2] = dc * ig * (1.f - gg * gg);
                     xv[3] = dh * tc * og * (1.f - og);
-                    float* dg = p.dg1 + (tn * 2 + d) * GH + unit;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) dg[g * H] = xv[g];
                 } else {  // GRU_BWD
                     const float dh = pin[i][0] + rs[0] + carry[i];
                     const float rg = sav[i][0], zg = sav[i][1], ng = sav[i][2], hn = sav[i][3];
@@ -359,10 +354,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     const float dzp = dh * (hp - ng) * zg * (1.f - zg);
                     const float drp = dnp * hn * rg * (1.f - rg);
                     xv[0] = drp; xv[1] = dzp; xv[2] = dnp * rg;
-                    float* dh_ = p.dg1 + (tn * 2 + d) * GH + unit;
-                    dh_[0] = drp; dh_[H] = dzp; dh_[2 * H] = dnp * rg;
-                    float* dx_ = p.dg2 + (tn * 2 + d) * GH + unit;
-                    dx_[0] = drp; dx_[H] = dzp; dx_[2 * H] = dnp;
+                    kp[0] = dnp;
                 }
             }
             // publish: even-unit lanes store {own, partner} packed hi and lo words (pad units publish zeros)
@@ -380,6 +372,22 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     unsigned* wq = xq + rbase_w + (k / 32) * 32 + (k % 32) / 2;
                     st_sc1_u32(wq, (mine & 0xFFFFu) | (other << 16));
                     st_sc1_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
+                }
+            }
+            // fp32 results for the rest of the layer (plain stores, off the exchange critical path)
+            if (ok) {
+                if (FWD) {
+                    p.hout[((int64_t)d * T * N + tn) * H + unit] = xv[0];
+                    *reinterpret_cast<f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4) = (f32x4){kp[0], kp[1], kp[2], kp[3]};
+                    if (LSTM) p.cst[((int64_t)d * T * N + tn) * H + unit] = kp[4];
+                } else {
+                    float* dg = p.dg1 + (tn * 2 + d) * GH + unit;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) dg[g * H] = xv[g];
+                    if (!LSTM) {
+                        float* dx_ = p.dg2 + (tn * 2 + d) * GH + unit;
+                        dx_[0] = xv[0]; dx_[H] = xv[1]; dx_[2 * H] = kp[0];
+                    }
                 }
             }
         }
