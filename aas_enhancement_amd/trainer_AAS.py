@@ -394,11 +394,18 @@ class Trainer(object):
                     conv_measure=l_adv_cl_data + abs(g_d_balance), g_adv=None, g_ctc_adv=None, enhanced=g["enh"], prob=g["prob"])
 
     def _acoustic_branch(self, enhanced, targets, sizes, target_sizes, N_glob, ctc_meta):
-        """A(enhanced) -> CTC/N -> backward down to a private leaf, on the side stream."""
+        """A(enhanced) -> CTC/N -> backward down to a private leaf (optionally on a second stream)."""
         c = self.config
-        if getattr(self, "_side", None) is None:
-            # AAS_SERIAL_ASR=1: run the acoustic branch on the main stream (no second chain of persistent kernels)
-            self._side = torch.cuda.current_stream() if os.environ.get("AAS_SERIAL_ASR", "0") == "1" else torch.cuda.Stream()
+        # Default: the acoustic branch runs on the CURRENT (main) stream.  Two chains of persistent recurrent kernels on
+        # two streams measured no faster (both are bound by the same memory-side bandwidth: 29.7 vs 29.7 ms / step), and
+        # keeping ONE persistent kernel in flight at a time means its grid is always fully resident.  AAS_OVERLAP_ASR=1
+        # puts the branch on a second stream (weight-gradient GEMMs always run on their own side stream).
+        if os.environ.get("AAS_OVERLAP_ASR", "0") == "1":
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream()
+            self._side = self._side_stream
+        else:
+            self._side = torch.cuda.current_stream()
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
         exact_a = getattr(c, "asr_exact_fp32", None)
