@@ -253,6 +253,26 @@ def test_am_step_golden(gpu):
         assert rel_err(v.double(), z["am.final." + k]) < 2e-3, k
 
 
+def test_am_trainer_class_golden(gpu):
+    """aas_enhancement_amd.am_train.AMTrainer (flat buffers, fused Adam, side-stream wgrads) on the F5 AM vectors."""
+    from aas_enhancement_amd import prng
+    from aas_enhancement_amd.am_train import AMTrainer
+    from aas_enhancement_amd.model import DeepSpeech
+    z = load("f5_fsegan_am.npz")
+    A = DeepSpeech(nn.GRU, LABELS, 12, 3, True, 11, 2, 8, 2, nFreq=8)
+    load_sd(A, {k: torch.from_numpy(v) for k, v in prng.fill_state_dict(A.state_dict(), 8001, conv_std=0.1).items()}, strict=False)
+    tr = AMTrainer(A.cuda(), lr=1e-3)
+    for it in range(2):
+        b = make_batch(3, 8, [60, 50, 38], 8100 + it, [4, 3, 2], 8200 + it)
+        r = tr.train_step((torch.from_numpy(b["inputs"]), torch.from_numpy(b["targets"]), torch.from_numpy(b["pct"]), torch.from_numpy(b["target_sizes"])))
+        assert r["loss"] == pytest.approx(float(z["am.it%d.loss" % it]), rel=REL_LOSS)
+        assert rel_err(r["logits"], z["am.it%d.logits" % it]) < REL_OUT
+    for k, v in A.state_dict().items():
+        if k in NOISE_PARAMS:
+            continue
+        assert rel_err(v.double(), z["am.final." + k]) < 2e-3, k
+
+
 def test_round_trip_properties_full_size(gpu):
     """Size-independent properties at BASELINE config-2 sizes: (i) linearity of backward in the upstream
     gradient, (ii) fused and as-executed schedules agree, (iii) the step is deterministic run to run
