@@ -1,0 +1,370 @@
+// BPTT of the persistent recurrent kernels as a per-step REDUCE-SCATTER (split-bf16 products).
+//
+// rnn_split_kernel.h runs BPTT as an all-gather: every workgroup reads the full d(gates)_{t+1} row (G*H values) of
+// each of its batch rows and multiplies it with its column slice of W_hh - P-fold redundant reads of the widest
+// vector of the layer (2000 values per row for the 500-unit LSTM, 3000 for the 1000-unit GRU) bound the step.
+// Here the product is split along K instead.  The workgroup that owns units [u0, u0+16) already holds its own
+// d(gates) slice (G*16 values per row, just computed by its gate math), so it multiplies that slice with the
+// matching G*16 ROWS of W_hh (resident in VGPRs as MFMA B-fragments) and gets a partial dh for ALL H units;
+// the partial destined for units [16c, 16c+16) is written to consumer c's block of the exchange ring, and each
+// consumer sums the P partials of its own 16 units.  Exchanged per batch row and step: H fp32 written + H fp32
+// read per workgroup-slice, instead of G*H read - 4x (LSTM) / 3x (GRU) fewer bytes through the fabric, and
+// every block has exactly one reader.
+//
+// Hand-off: "data is the flag" with a 2-bit step tag.  A partial is published with the two low mantissa bits
+// replaced by (step mod 3); the ring has two time slots (step parity) and is filled with 0xFFFFFFFF (tag 3) before
+// the launch, so a word carries the tag of step s only once step s's value has been written (slot reuse: the word
+// written two steps earlier carries tag (s-2) mod 3 != s mod 3).  Reuse is safe with two slots because a producer
+// can only reach step s after it has consumed every other workgroup's step s-1 partials, and those were produced
+// after their owners finished reading step s-2.  Consumers mask the tag off before summing (|error| <= 3 ulp of
+// the partial, far below the 2^-18 of the split product).  Loads are sc1 (each block has one reader, nothing to
+// share in L2), every spin is bounded and sets the sticky error word.
+#pragma once
+#include "rnn_split_kernel.h"
+
+namespace {
+
+// MODE = LSTM_BWD or GRU_BWD; U = units per workgroup (16: 256 threads, 32: 512 threads - half as many slices, so
+// half the exchanged bytes chip-wide); NTW = 16-column result tiles per wave (P <= 4*NTW)
+template <int MODE, int U, int NTW>
+__global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
+    using C = Cfg<MODE>;
+    constexpr int G = C::G;
+    constexpr bool LSTM = (MODE == LSTM_BWD);
+    static_assert(U == 16 || U == 32, "16 rows x U units = one (row, unit) per thread");
+    constexpr int THREADS = 16 * U;
+    constexpr int KSTEPS = (G * U + 31) / 32;             // 32-wide k steps over my d(gates) slice (k' = gate*U + unit)
+    constexpr int RS_LDA = KSTEPS * 32 + 8;               // bf16 elements per A-tile row (+8 pad: conflict-free 16-byte reads)
+    constexpr int KPP = NTW;                              // producers per lane in the consumer-side sum (4 lanes share a row)
+    constexpr int UQ = U / 4;                             // 16-byte unit quads per block
+    constexpr int TPC = U / 16;                           // result tiles per consumer slice
+    __shared__ __attribute__((aligned(16))) unsigned short a_hi[2][16][RS_LDA];
+    __shared__ __attribute__((aligned(16))) unsigned short a_lo[2][16][RS_LDA];
+    // the 1000-unit GRU at U = 32 needs 192 VGPRs for its W fragments alone (of 256 at two waves per SIMD): the lo
+    // fragments of its last k-step live in LDS instead (64 KB, re-read once per step) so that nothing spills
+    constexpr int LKS = (!LSTM && U == 32 && NTW == 8) ? 1 : 0;
+    __shared__ u32x4 bl_lds[LKS ? NTW : 1][LKS ? THREADS : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pslice = blockIdx.x, qg = blockIdx.y, d = blockIdx.z;
+    const int T = p.T, N = p.N, H = p.H, GH = G * H, P = p.P;
+    const int u0 = pslice * U;
+    const int q0 = p.n0 + qg * p.rpg;
+    const int NB = min(p.n1, q0 + p.rpg);
+    const int nrows = NB - q0;                            // valid batch rows of this group (<= 16)
+    unsigned* err = p.sync + ERR_WORD;
+
+    // ---- B fragments: rows {g*H + u0 + u} of W_hh (k' = g*16 + u, padded to 64) x all Hp columns --------------
+    const float* W = d == 0 ? p.w_hh : p.w_hh_r;
+    bf16x8 bh[KSTEPS][NTW], bl[KSTEPS][NTW];
+    {
+        const int n = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int col = (wave * NTW + nt) * 16 + n;       // unit whose dh this column feeds
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    unsigned h2[2], l2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int kk = ks * 32 + q * 8 + jj * 2 + e;
+                        const int gate = kk / U, unit = u0 + kk % U;
+                        float v = 0.f;
+                        if (gate < G && unit < H && col < H) v = W[(int64_t)(gate * H + unit) * H + col];
+                        split_bf16(v, h2[e], l2[e]);
+                    }
+                    hw[jj] = h2[0] | (h2[1] << 16);
+                    lw[jj] = l2[0] | (l2[1] << 16);
+                }
+                const u32x4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
+                bh[ks][nt] = __builtin_bit_cast(bf16x8, hv);
+                if (ks >= KSTEPS - LKS) bl_lds[LKS ? nt : 0][LKS ? tid : 0] = lv;
+                else bl[ks][nt] = __builtin_bit_cast(bf16x8, lv);
+            }
+    }
+    // zero both A tiles once: pad rows / pad gate columns stay zero for the whole launch
+    for (int i = tid; i < 2 * 16 * RS_LDA; i += THREADS) {
+        (&a_hi[0][0][0])[i] = 0;
+        (&a_lo[0][0][0])[i] = 0;
+    }
+    __syncthreads();
+
+    // exchange ring: [slot 2][dir 2][N rows][consumer P][producer P][U units] tagged fp32
+    unsigned* ring = p.xchg;
+    const int64_t ring_words = (int64_t)4 * N * P * P * U;
+    auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)ring, 0, (int)(ring_words * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // consumer-side thread role: 4 lanes (ppg) share one (row, unit quad) and split the producers
+    const int ppg = lane & 3, uq = (lane >> 2) & (UQ - 1), rl = lane / (4 * UQ);
+    const int row = wave * (64 / (4 * UQ)) + rl;          // batch row within the group
+    const int unit = uq * 4 + ppg;                        // after the 4-lane reduction each lane keeps one unit
+    const int gr = q0 + row, gunit = u0 + unit;
+    const bool rowok = row < nrows;
+    const bool ok = rowok && gunit < H;
+
+    float carry = 0.f;
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    const bool stamp = (p.flags & 64) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    for (int s = 0; s < T; ++s) {
+        unsigned long long st0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull, st1 = st0, st2 = st0, st3 = st0;
+        const int t = (d == 0) ? T - 1 - s : s;           // BPTT runs against the direction's forward order
+        const int64_t tn = (int64_t)t * N + gr;
+
+        // ---- private inputs of the step ---------------------------------------------------------
+        float dyv = 0.f, sav[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            dyv = p.dy[tn * H + gunit];
+            const f32x4 ga4 = *reinterpret_cast<const f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + gunit) * 4);
+            sav[0] = ga4.x; sav[1] = ga4.y; sav[2] = ga4.z; sav[3] = ga4.w;
+            const int tq = (d == 0) ? t - 1 : t + 1;
+            const bool hasq = (tq >= 0 && tq < T);
+            const int64_t qn = ((int64_t)d * T * N + (int64_t)tq * N + gr) * H + gunit;
+            if (LSTM) {
+                sav[4] = p.cst[((int64_t)d * T * N + tn) * H + gunit];
+                sav[5] = hasq ? p.cst[qn] : 0.f;
+            } else {
+                sav[5] = hasq ? p.hout[qn] : 0.f;
+            }
+        }
+
+        // ---- recurrent term: sum over producers of the partial dh of my 16 units -----------------
+        float rec = 0.f;
+        if (s > 0) {
+            const unsigned tag = (unsigned)((s - 1) % 3);
+            const int slot = (s - 1) & 1;
+            const int64_t blk0 = (((int64_t)(slot * 2 + d) * N + q0) * P + pslice) * P;   // (row q0, consumer me, producer 0), in blocks of U words
+            if (!(p.flags & 4)) {
+                // poll one word per producer (last valid row of the group) before streaming the block
+                const bool probe = lane < P && !(p.flags & 1);
+                const unsigned* wp = ring + (blk0 + (int64_t)(nrows - 1) * P * P + lane) * U + (U - 1);
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0;
+                while (true) {
+                    const unsigned w = probe ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+                    if (!__any((w & 3u) != tag)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 255u) == 0) {
+                        if (ld_cnt(err) != 0) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
+                            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+            }
+            if (stamp) st1 = __builtin_amdgcn_s_memrealtime();
+            // lane (rl, uq, ppg) loads units [4uq, 4uq+4) of producers pp = 4k + ppg: 256 contiguous bytes per row and k
+            const unsigned rbase = (rowok && !(p.flags & 1)) ? (unsigned)(((blk0 + (int64_t)row * P * P) * U + uq * 4) * 4) : OOB;
+            u32x4 v[KPP];
+            unsigned spins = 0;
+            unsigned long long t0 = 0;
+            while (true) {
+                unsigned bad = 0u;
+#pragma unroll
+                for (int k = 0; k < KPP; ++k) {
+                    const int pp = k * 4 + ppg;
+                    const unsigned off = (pp < P) ? rbase + (unsigned)(pp * U * 4) : OOB;
+                    v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 16));
+                }
+#pragma unroll
+                for (int k = 0; k < KPP; ++k) {
+                    const int pp = k * 4 + ppg;
+                    const unsigned m = ((v[k].x ^ tag) | (v[k].y ^ tag) | (v[k].z ^ tag) | (v[k].w ^ tag)) & 3u;
+                    bad |= (pp < P && rbase != OOB) ? m : 0u;
+                }
+                if ((p.flags & 4) || !__any(bad != 0u)) break;
+                if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
+                if ((++spins & 63u) == 0) {
+                    if (ld_cnt(err) != 0) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
+                        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KPP; ++k) {
+                s4[0] += __uint_as_float(v[k].x & ~3u);
+                s4[1] += __uint_as_float(v[k].y & ~3u);
+                s4[2] += __uint_as_float(v[k].z & ~3u);
+                s4[3] += __uint_as_float(v[k].w & ~3u);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s4[j] += __shfl_xor(s4[j], 1, 64);
+                s4[j] += __shfl_xor(s4[j], 2, 64);
+            }
+            rec = ppg == 0 ? s4[0] : (ppg == 1 ? s4[1] : (ppg == 2 ? s4[2] : s4[3]));
+        }
+        if (stamp) st2 = __builtin_amdgcn_s_memrealtime();
+
+        // ---- gate math -----------------------------------------------------------------------------
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        float dn_keep = 0.f;
+        if (ok) {
+            if (LSTM) {
+                const float dh = dyv + rec;
+                const float ig = sav[0], fg = sav[1], gg = sav[2], og = sav[3];
+                const float c = sav[4], cp = sav[5];
+                const float tc = tanhf_(c);
+                const float dc = dh * og * (1.f - tc * tc) + carry;
+                carry = dc * fg;
+                xv[0] = dc * gg * ig * (1.f - ig);
+                xv[1] = dc * cp * fg * (1.f - fg);
+                xv[2] = dc * ig * (1.f - gg * gg);
+                xv[3] = dh * tc * og * (1.f - og);
+            } else {
+                const float dh = dyv + rec + carry;
+                const float rg = sav[0], zg = sav[1], ng = sav[2], hn = sav[3];
+                const float hp = sav[5];
+                carry = dh * zg;
+                const float dnp = dh * (1.f - zg) * (1.f - ng * ng);
+                const float dzp = dh * (hp - ng) * zg * (1.f - zg);
+                const float drp = dnp * hn * rg * (1.f - rg);
+                xv[0] = drp; xv[1] = dzp; xv[2] = dnp * rg;
+                dn_keep = dnp;
+            }
+        }
+        const int par = s & 1;
+        if (rowok && s + 1 < T) {  // my d(gates) slice as the split-bf16 A tile of the partial product
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                unsigned h16, l16;
+                split_bf16(xv[g], h16, l16);
+                a_hi[par][row][g * U + unit] = (unsigned short)h16;
+                a_lo[par][row][g * U + unit] = (unsigned short)l16;
+            }
+        }
+        // fp32 d(gates) for the layer's GEMMs (plain stores)
+        if (ok) {
+            float* dg = p.dg1 + (tn * 2 + d) * GH + gunit;
+#pragma unroll
+            for (int g = 0; g < G; ++g) dg[g * H] = xv[g];
+            if (!LSTM) {
+                float* dx_ = p.dg2 + (tn * 2 + d) * GH + gunit;
+                dx_[0] = xv[0]; dx_[H] = xv[1]; dx_[2 * H] = dn_keep;
+            }
+        }
+        __syncthreads();
+        if (stamp) st3 = __builtin_amdgcn_s_memrealtime();
+
+        // ---- partial dh for all units: [16 rows x 64] x [64 x Hp], published to the consumers' blocks ---
+        if (s + 1 < T) {
+            const int m = lane & 15, q = lane >> 4;
+            bf16x8 ah[KSTEPS], al[KSTEPS];
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                ah[ks] = *reinterpret_cast<const bf16x8*>(&a_hi[par][m][ks * 32 + q * 8]);
+                al[ks] = *reinterpret_cast<const bf16x8*>(&a_lo[par][m][ks * 32 + q * 8]);
+            }
+            const unsigned tag = (unsigned)(s % 3);
+            const int slot = s & 1;
+            // Transposed product (W fragment as the A operand, my d(gates) tile as B): the 16x16 result tile is
+            // [unit][batch row], so a lane holds 4 CONSECUTIVE units of one row - one 16-byte write-through store
+            // per tile and lane, 64 contiguous bytes per row, instead of four 4-byte stores.
+            const int prow = lane & 15, u4 = (lane >> 4) * 4;
+            const int64_t rblk = ((int64_t)(slot * 2 + d) * N + q0 + prow) * P;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (!(p.flags & 2)) {
+#pragma unroll
+                    for (int ks = 0; ks < KSTEPS; ++ks) {
+                        bf16x8 blv;
+                        if (ks >= KSTEPS - LKS) blv = __builtin_bit_cast(bf16x8, bl_lds[LKS ? nt : 0][LKS ? tid : 0]);
+                        else blv = bl[ks][nt];
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks][nt], al[ks], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blv, ah[ks], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks][nt], ah[ks], acc, 0, 0, 0);
+                    }
+                }
+                const int tile = wave * NTW + nt;
+                const int c = tile / TPC, half = tile % TPC;   // consumer slice, 16-unit half of its block
+                if (c < P && prow < nrows && !(p.flags & 8)) {
+                    u32x4 o;
+                    o.x = (__float_as_uint(acc[0]) & ~3u) | tag;
+                    o.y = (__float_as_uint(acc[1]) & ~3u) | tag;
+                    o.z = (__float_as_uint(acc[2]) & ~3u) | tag;
+                    o.w = (__float_as_uint(acc[3]) & ~3u) | tag;
+                    const unsigned boff = (unsigned)((((rblk + c) * P + pslice) * U + half * 16 + u4) * 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 16);  // sc1: agent-scope write-through
+                }
+            }
+        }
+        if (stamp) {
+            const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
+            ph[0] += st1 - st0; ph[1] += st2 - st1; ph[2] += st3 - st2; ph[3] += st4 - st3; ph[4] += st4 - st0;
+        }
+    }
+    if (stamp && tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.sync + STAMP_WORD);
+        for (int i = 0; i < 5; ++i) o[i] = ph[i];
+    }
+}
+
+inline size_t rs_ring_bytes(int N, int H, int U) {
+    const size_t P = (size_t)cdiv(H, U);
+    return (size_t)4 * N * P * P * U * 4;
+}
+
+template <int MODE, int U>
+int launch_rs(const RnnP& p, hipStream_t s) {
+    dim3 grid(p.P, p.Q, 2), block(16 * U);
+    if (p.P <= 8) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 2>), grid, block, 0, s, p);
+    else if (p.P <= 16) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 4>), grid, block, 0, s, p);
+    else if (p.P <= 32) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 8>), grid, block, 0, s, p);
+    else if (U == 16 && p.P <= 64) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, 16, 16>), grid, block, 0, s, p);
+    else return -1;
+    return 0;
+}
+
+template <int MODE>
+int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
+    AAS_CHECK(p.T >= 1 && p.N >= 1 && p.H >= 1, "%s: bad sizes T=%d N=%d H=%d", name, p.T, p.N, p.H);
+    const int cus = aas_device_cus();
+    AAS_CHECK(cus > 0, "%s: no HIP device", name);
+    p.flags = aas_debug_flags_value();
+    // 32-unit slices (512-thread workgroups) halve the number of slices and with it the bytes every step moves
+    // through the fabric; small layers keep 16-unit slices so that enough workgroups share the work
+    const int U = (p.H >= 256 && !(p.flags & 512)) ? 32 : 16;
+    p.P = cdiv(p.H, U);
+    if (p.P > (U == 16 ? 64 : 32)) return -1;              // one poll lane per producer, <= 8/16 tiles per wave
+    AAS_CHECK(p.P * 2 <= cus, "%s: H=%d needs %d resident workgroups, device has %d CUs", name, p.H, p.P * 2, cus);
+    const size_t rbytes = rs_ring_bytes(p.N, p.H, U);
+    if (rbytes >= 0x7fffffffULL) return -1;
+    // rows per group: the smallest of 4 / 8 / 16 whose grid is still resident (fewest bytes per workgroup and step);
+    // larger batches run as consecutive launches over row chunks
+    int rpg = 16;
+    for (int cand = 4; cand < 16; cand *= 2)
+        if (p.P * cdiv(p.N, cand) * 2 <= cus) { rpg = cand; break; }
+    p.rpg = rpg;
+    const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
+    AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, rbytes, s));      // tag 3 = "no step's value yet"
+    for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {
+        p.n0 = n0;
+        const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
+        p.n1 = n0 + rows;
+        p.Q = cdiv(rows, rpg);
+        const int rc = (U == 32) ? launch_rs<MODE, 32>(p, s) : launch_rs<MODE, 16>(p, s);
+        if (rc != 0) return -1;
+        AAS_LAUNCH_CHECK(name);
+    }
+    return 0;
+}
+
+// BPTT entry: reduce-scatter kernel by default, the all-gather split kernel under debug flag 256, exact fp32 otherwise
+template <int MODE>
+int run_bwd_any(const char* name, RnnP p, hipStream_t s) {
+    if (p.xchg && aas_precision_value() != 0 && !(aas_debug_flags_value() & 256)) {
+        const int rc = run_bwd_rs<MODE>(name, p, s);
+        if (rc >= 0) return rc;
+    }
+    return run_any<MODE>(name, p, s);
+}
+
+}  // namespace

@@ -1,4 +1,4 @@
-#include "rnn_split_kernel.h"
+#include "rnn_bwd_rs_kernel.h"
 
 extern "C" int aas_lstm_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
                             const float* gact, const float* cst, float* dgates, void* sync, void* xchg) {
@@ -6,6 +6,6 @@ extern "C" int aas_lstm_bwd(aasStream_t stream, int T, int N, int H, const float
     RnnP p = {};
     p.T = T; p.N = N; p.H = H; p.dy = dy; p.w_hh = w_hh; p.w_hh_r = w_hh_rev; p.gact = (float*)gact; p.cst = (float*)cst; p.dg1 = dgates;
     p.sync = (unsigned*)sync; p.xchg = (unsigned*)xchg;
-    return run_any<LSTM_BWD>("aas_lstm_bwd", p, (hipStream_t)stream);
+    return run_bwd_any<LSTM_BWD>("aas_lstm_bwd", p, (hipStream_t)stream);
 }
 

@@ -1,9 +1,13 @@
 #include "rnn_split_kernel.h"
 
 extern "C" size_t aas_rnn_sync_bytes(void) { return SYNC_BYTES; }
-// hi + lo arrays of the widest exchanged vector (BPTT: 2*T*N rows x G*Hp bf16, Hp <= H + 15)
+// the larger of: hi + lo arrays of the widest all-gathered vector (2*T*N rows x G*Hp bf16, Hp <= H + 15), and the
+// BPTT reduce-scatter ring (2 slots x 2 directions x N rows x P consumers x P producers x 64 B)
 extern "C" size_t aas_rnn_xchg_bytes(int T, int N, int H, int gates) {
-    return (size_t)8 * T * N * ((size_t)gates * (H + 16) + 32);
+    const size_t gather = (size_t)8 * T * N * ((size_t)gates * (H + 16) + 32);
+    const size_t P = (size_t)(H + 15) / 16;                // 16-unit slices: the larger of the two ring shapes
+    const size_t ring = (size_t)4 * N * P * P * 64;
+    return gather > ring ? gather : ring;
 }
 
 extern "C" int aas_lstm_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh, const float* w_hh_rev, float* hout,
