@@ -24,8 +24,13 @@ SIGNATURES = {
     "aas_device_cus": [],
     "aas_set_debug_flags": [c_int],
     "aas_set_precision": [c_int],
+    "aas_set_rnn_cu_limit": [c_int],
     "aas_gemm_f32": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                      c_int, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_i64],
+    "aas_gemm_planes": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
+                        c_int, c_i64, c_i64, c_i64],
+    "aas_split_planes": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_int],
+    "aas_split_planes_t": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
     "aas_transpose_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64],
     "aas_swap01_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "aas_add3_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64],

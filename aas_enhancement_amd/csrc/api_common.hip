@@ -42,3 +42,19 @@ extern "C" int aas_set_precision(int mode) {
     g_precision = mode;
     return 0;
 }
+
+// Upper bound on the CUs one persistent recurrent launch may occupy (0 = the whole device).  Two independent chains of
+// recurrent launches on two streams (discriminator and acoustic branch of the AAS step) each take half the chip.
+static int g_rnn_cu_limit = 0;
+int aas_rnn_cus() {
+    const int cus = aas_device_cus();
+    return (g_rnn_cu_limit > 0 && g_rnn_cu_limit < cus) ? g_rnn_cu_limit : cus;
+}
+extern "C" int aas_set_rnn_cu_limit(int cus) {
+    if (cus < 0) {
+        aas_set_error("aas_set_rnn_cu_limit: negative limit");
+        return 1;
+    }
+    g_rnn_cu_limit = cus;
+    return 0;
+}

@@ -1,0 +1,374 @@
+// Split-bf16 GEMM on PRE-SPLIT operand planes (gfx950).
+//
+// gemm.hip's split kernel converts fp32 tiles to bf16 hi/lo while staging them (VALU work and VGPR staging inside
+// the k-loop, fp32 bytes through the L1/L2 path).  Here every operand already lives in HBM as two bf16 planes,
+// hi = rne(x) and lo = rne(x - hi), laid out k-contiguous [rows][Kp] with Kp a multiple of 32 and the pad zero-filled
+// (aas_split_planes / aas_split_planes_t write them, with the transpose and the per-utterance row weights folded
+// into that HBM-bound pass).  The product is then a plain NT bf16 GEMM with three MFMAs per fragment pair,
+//     C[m][n] (+)= sum_k  A_hi*B_hi + A_lo*B_hi + A_hi*B_lo        (fp32 accumulate, dropped term lo*lo ~ 2^-18),
+// whose k-loop contains nothing but LDS-DMA loads (global_load_lds_dwordx4), ds_read_b128 and MFMA.
+//
+// Tile 128 x 128 x 32, 256 threads (2 x 2 waves, 64 x 64 per wave as 4 x 4 v_mfma_f32_16x16x32_bf16 tiles), two LDS
+// stages of 4 planes x 128 rows x 64 B (64 KB), one workgroup barrier per k-step.  The LDS image is lane-linear
+// (LDS-DMA: wave base + 16*lane), so the bank swizzle is applied to the SOURCE chunk a lane fetches and undone by
+// the fragment reads: slot = chunk ^ g[(row >> 2) & 3], g = {0,2,3,1}, which makes every ds_read_b128 lane group of
+// the 16x16x32 operand (MI355X_MICROARCH.md LDS table) hit 16 distinct 16-byte slots.  The MFMA operands are
+// swapped (B fragment first), so a lane ends up with 4 consecutive columns of one C row: 16-byte epilogue stores.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct PG {
+    const char *A, *B;      // interleaved planes: row r, k-block b (32 k): 64 B of bf16 hi then 64 B of bf16 lo at r*ld*4 + b*128
+    float* C;
+    const float* bias;      // [N] or null
+    const float* addend;    // [M][ldd] or null
+    int M, N, K;            // K: multiple of 32 (planes are zero-padded)
+    int64_t lda, ldb, ldc, ldd;
+    int accumulate, splitk, batch;
+    int64_t sA, sB, sC;     // batch strides (elements)
+    int flags;
+};
+
+constexpr int TK = 32;
+
+__device__ __forceinline__ int swz(int r4) { return (0x78 >> (2 * r4)) & 3; }  // g = {0, 2, 3, 1}
+
+__device__ __forceinline__ void glds16(const void* g, char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// BM x BN tile, WM x WN waves (wave tile (BM/WM) x (BN/WN) as MI x NJ 16x16 MFMA tiles).  SWAP: MFMA operands swapped
+// so that a lane owns 4 consecutive columns of a C row (16-byte stores); !SWAP: a lane owns one column of 4 rows,
+// the form whose 4-byte atomics coalesce (split-K epilogue).
+template <int BM, int BN, int WM, int WN, bool SWAP>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_planes_kernel(PG p) {
+    constexpr int NW = WM * WN, THREADS = 64 * NW;
+    constexpr int MI = BM / WM / 16, NJ = BN / WN / 16;
+    constexpr int A_B = BM * 128, B_B = BN * 128;             // bytes of one A / B tile (rows x 32 k x (hi + lo))
+    constexpr int STAGE_B = A_B + B_B;
+    static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile rows must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A_hi, A_lo, B_hi, B_lo)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+    int kbeg = 0, kend = p.K;
+    const int bz = z / p.splitk, kz = z - bz * p.splitk;
+    if (p.splitk > 1) {
+        const int ktiles = p.K / TK;
+        const int per = (ktiles + p.splitk - 1) / p.splitk;
+        kbeg = kz * per * TK;
+        kend = min(p.K, (kz + 1) * per * TK);
+        if (kbeg >= kend) return;
+    }
+    const char* Ap = p.A + bz * p.sA * 4;
+    const char* Bp = p.B + bz * p.sB * 4;
+    float* C = p.C + bz * p.sC;
+    const float* addend = p.addend ? p.addend + bz * p.sC : nullptr;
+    if (p.flags & 128) kend = kbeg;  // ablation: epilogue only
+
+    // ---- LDS-DMA: one instruction moves 8 rows x 128 B (hi | lo of one 32-k block: full lines); a 16-row piece of a
+    // tile is two instructions, piece pc = j*NW + wave.  lane -> (row = lane>>3, LDS slot = lane&7) and the lane fetches
+    // source slot (slot ^ f(row)), f(row) = (row>>1)&7 over the 16 rows of the piece: the LDS image is lane-linear, the
+    // XOR makes every ds_read_b128 lane group of the 16x16x32 operand hit 16 distinct 16-byte slots.
+    constexpr int PA = BM / (16 * NW), PB = BN / (16 * NW);
+    const int r8 = lane >> 3, sl = lane & 7;
+    int64_t aoff[PA][2], boff[PB][2];
+#pragma unroll
+    for (int j = 0; j < PA; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = h * 8 + r8;
+            aoff[j][h] = (int64_t)min(m0 + (j * NW + wave) * 16 + r, p.M - 1) * p.lda * 4 + ((sl ^ ((r >> 1) & 7)) << 4);
+        }
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = h * 8 + r8;
+            boff[j][h] = (int64_t)min(n0 + (j * NW + wave) * 16 + r, p.N - 1) * p.ldb * 4 + ((sl ^ ((r >> 1) & 7)) << 4);
+        }
+    auto stage = [&](int st, int k0) {
+        char* base = smem + st * STAGE_B + wave * 2048;
+        const int64_t kb = (int64_t)k0 * 4;   // byte offset of the k-block inside a row
+#pragma unroll
+        for (int j = 0; j < PA; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) glds16(Ap + aoff[j][h] + kb, base + j * NW * 2048 + h * 1024);
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) glds16(Bp + boff[j][h] + kb, base + A_B + j * NW * 2048 + h * 1024);
+    };
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets inside a tile: row (lane&15) of a 16-row piece, hi chunk q = lane>>4, lo chunk 4+q
+    const int fr = lane & 15, q = lane >> 4;
+    const int fx = (fr >> 1) & 7;
+    const int fhi = fr * 128 + ((q ^ fx) << 4), flo = fr * 128 + (((4 + q) ^ fx) << 4);
+    const int ab = (wm * MI) * 2048, bb = A_B + (wn * NJ) * 2048;
+
+    if (kbeg < kend) stage(0, kbeg);
+    int st = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += TK, st ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // stage st has landed for every wave; everyone is done reading stage st^1
+        if (k0 + TK < kend && !(p.flags & 64)) stage(st ^ 1, k0 + TK);
+        if (!(p.flags & 16)) {
+            const char* sb = smem + st * STAGE_B;
+            bf16x8 ah[MI], al[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(sb + ab + i * 2048 + fhi);
+                al[i] = *reinterpret_cast<const bf16x8*>(sb + ab + i * 2048 + flo);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sb + bb + j * 2048 + fhi);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(sb + bb + j * 2048 + flo);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    if (SWAP) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[i], acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    const bool first = (p.splitk <= 1) || (kz == 0);
+    if (SWAP) {
+        // lane holds C[m][n .. n+3], m = tile row (lane&15), n = 4*(lane>>4)
+        const bool vec = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                         (!p.bias || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) &&
+                         (!addend || (((p.ldd & 3) == 0) && ((reinterpret_cast<uintptr_t>(addend) & 15) == 0)));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + (wm * MI + i) * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + (wn * NJ + j) * 16 + q * 4;
+                if (n >= p.N) continue;
+                f32x4 v = acc[i][j];
+                float* cp = C + (int64_t)m * p.ldc + n;
+                if (n + 3 < p.N && vec) {
+                    if (p.bias) { const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n); v += b; }
+                    if (addend) { const f32x4 a = *reinterpret_cast<const f32x4*>(addend + (int64_t)m * p.ldd + n); v += a; }
+                    if (p.accumulate) {
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(cp);
+                        *reinterpret_cast<f32x4*>(cp) = o + v;
+                    } else {
+                        *reinterpret_cast<f32x4*>(cp) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (n + r >= p.N) break;
+                        float x = v[r];
+                        if (p.bias) x += p.bias[n + r];
+                        if (addend) x += addend[(int64_t)m * p.ldd + n + r];
+                        if (p.accumulate) cp[r] += x;
+                        else cp[r] = x;
+                    }
+                }
+            }
+        }
+    } else {
+        // lane holds C[m .. m+3][n], n = tile column (lane&15), m = 4*(lane>>4): 64-byte runs per atomic instruction
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + (wn * NJ + j) * 16 + fr;
+            if (n >= p.N) continue;
+            const float bv = (p.bias && first) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + (wm * MI + i) * 16 + q * 4 + r;
+                    if (m >= p.M) continue;
+                    float x = acc[i][j][r] + bv;
+                    if (addend && first) x += addend[(int64_t)m * p.ldd + n];
+                    float* cp = C + (int64_t)m * p.ldc + n;
+                    if (p.splitk > 1) atomicAdd(cp, x);
+                    else if (p.accumulate) *cp += x;
+                    else *cp = x;
+                }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool SWAP>
+int launch_planes(const PG& p, dim3 grid, hipStream_t s) {
+    constexpr int LDS = 2 * (BM * 128 + BN * 128);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_kernel<BM, BN, WM, WN, SWAP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_planes_kernel<BM, BN, WM, WN, SWAP>), grid, dim3(64 * WM * WN), LDS, s, p);
+    return 0;
+}
+
+__device__ __forceinline__ void split2(float x, unsigned short& h, unsigned short& l) {
+    const __bf16 hb = (__bf16)x;
+    h = __builtin_bit_cast(unsigned short, hb);
+    const __bf16 lb = (__bf16)(x - __uint_as_float((unsigned)h << 16));
+    l = __builtin_bit_cast(unsigned short, lb);
+}
+
+// planes[r][k] = split(src[r*ld + k] * (rs ? rs[r % nb] : 1)), k < K; zero for K <= k < Kp.  8 elements per thread.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int64_t ld, int64_t R, int K, int Kp,
+                                                         char* __restrict__ planes, const float* __restrict__ rs, int nb) {
+    const int cpr = Kp / 8;  // 16-byte output chunks per row
+    const int64_t total = R * cpr;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int k = (int)(i - r * cpr) * 8;
+        float v[8];
+        const float* s = src + r * ld + k;
+        if (vec && k + 8 <= K) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (k + e < K) ? s[e] : 0.f;
+        }
+        const float sc = rs ? rs[r % nb] : 1.f;
+        unsigned short h[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split2(v[e] * sc, h[e], l[e]);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 hv = {h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16)};
+        const u32x4 lv = {l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16)};
+        char* o = planes + r * (int64_t)Kp * 4 + (k >> 5) * 128 + (k & 31) * 2;
+        *reinterpret_cast<u32x4*>(o) = hv;
+        *reinterpret_cast<u32x4*>(o + 64) = lv;
+    }
+}
+
+// Transposing split of a time-major matrix: src[(t*nb + n)*ld + c] -> planes[c][t*nbp + n] for c < Cc (plane rows, pitch
+// Kp); the pad columns (n >= nb inside a time block, and everything from T*nbp to Kp) are written as zeros.  One
+// workgroup transposes a 64 (k positions) x 64 (source columns) tile through LDS, so both the fp32 reads and the bf16
+// writes are full 128-byte lines; rs[n] scales source row (t, n).
+__global__ __launch_bounds__(256) void split_rows_t_kernel(const float* __restrict__ src, int64_t ld, int T, int nb, int nbp, int Cc,
+                                                           int64_t Kp, char* __restrict__ planes, const float* __restrict__ rs) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64;
+    const int64_t k0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int64_t kpos = k0 + rr;
+        const int t = (int)(kpos / nbp), n = (int)(kpos - (int64_t)t * nbp);
+        const int c = c0 + tx;
+        float v = 0.f;
+        if (t < T && n < nb && c < Cc) v = src[((int64_t)t * nb + n) * ld + c] * (rs ? rs[n] : 1.f);
+        tile[rr][tx] = v;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc;
+        const int64_t kpos = k0 + tx;
+        if (c < Cc && kpos < Kp) {
+            unsigned short h, l;
+            split2(tile[tx][cc], h, l);
+            char* o = planes + (int64_t)c * Kp * 4 + (kpos >> 5) * 128 + (kpos & 31) * 2;
+            *reinterpret_cast<unsigned short*>(o) = h;
+            *reinterpret_cast<unsigned short*>(o + 64) = l;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                               float* C, int64_t ldc, const float* bias, const float* addend, int64_t ldd, int accumulate, int batch,
+                               int64_t strideA, int64_t strideB, int64_t strideC) {
+    AAS_CHECK(M >= 0 && N >= 0 && K >= 0 && batch >= 1, "aas_gemm_planes: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    AAS_CHECK(A && B && C, "aas_gemm_planes: null operand");
+    AAS_CHECK(K % 32 == 0 && lda % 32 == 0 && ldb % 32 == 0 && strideA % 32 == 0 && strideB % 32 == 0,
+              "aas_gemm_planes: K, lda, ldb and the batch strides must be multiples of 32 (K=%d lda=%lld ldb=%lld)", K,
+              (long long)lda, (long long)ldb);
+    AAS_CHECK(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 127) == 0, "aas_gemm_planes: planes must be 128-byte aligned");
+    if (M == 0 || N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    PG p;
+    p.A = (const char*)A; p.B = (const char*)B;
+    p.C = C; p.bias = bias; p.addend = addend; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldd = ldd;
+    p.accumulate = accumulate; p.batch = batch; p.sA = strideA; p.sB = strideB; p.sC = strideC; p.splitk = 1;
+    p.flags = aas_debug_flags_value();
+    // 256 x 256 tiles (8 waves) halve the operand bytes per flop that the 128 x 128 kernel pulls through L2 (its bound);
+    // they are used when they still give every CU about a tile, else 128 x 128 with split-K when K is deep
+    const int64_t big_tiles = (int64_t)cdiv(M, 256) * cdiv(N, 256) * batch;
+    const bool big = big_tiles >= 192 && !(p.flags & 1024);
+    const int bm = big ? 256 : 128, bn = big ? 256 : 128;
+    dim3 grid(cdiv(N, bn), cdiv(M, bm), batch);
+    const int blocks = grid.x * grid.y * batch;
+    if (!big && blocks < 384 && K >= 1024) {
+        int want = (512 + blocks - 1) / blocks;
+        const int maxs = K / 256;
+        int sk = want < maxs ? want : maxs;
+        if (sk > 16) sk = 16;
+        if (sk > 1) {
+            p.splitk = sk;
+            grid.z = batch * sk;
+            if (!accumulate) {
+                for (int b = 0; b < batch; ++b) {
+                    float* cb = C + (int64_t)b * strideC;
+                    if (ldc == N) { AAS_HIP(hipMemsetAsync(cb, 0, sizeof(float) * (size_t)M * N, s)); }
+                    else { AAS_HIP(hipMemset2DAsync(cb, sizeof(float) * ldc, 0, sizeof(float) * N, M, s)); }
+                }
+            }
+        }
+    }
+    int rc;
+    if (big) rc = launch_planes<256, 256, 4, 2, true>(p, grid, s);
+    else if (p.splitk > 1) rc = launch_planes<128, 128, 2, 2, false>(p, grid, s);
+    else rc = launch_planes<128, 128, 2, 2, true>(p, grid, s);
+    AAS_CHECK(rc == 0, "aas_gemm_planes: could not raise the dynamic LDS limit");
+    AAS_LAUNCH_CHECK("aas_gemm_planes");
+    return 0;
+}
+
+extern "C" int aas_split_planes(aasStream_t stream, const float* src, int64_t ld, int64_t rows, int K, int Kp, void* planes,
+                                const float* row_scale, int nb) {
+    AAS_CHECK(src && planes && rows >= 0 && K >= 0 && Kp >= K && Kp % 32 == 0, "aas_split_planes: bad arguments (K=%d Kp=%d)", K, Kp);
+    AAS_CHECK(!row_scale || nb > 0, "aas_split_planes: row_scale needs nb > 0");
+    if (rows == 0 || Kp == 0) return 0;
+    const int64_t total = rows * (Kp / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, ld, rows, K, Kp,
+                       (char*)planes, row_scale, nb > 0 ? nb : 1);
+    AAS_LAUNCH_CHECK("aas_split_planes");
+    return 0;
+}
+
+extern "C" int aas_split_planes_t(aasStream_t stream, const float* src, int64_t ld, int T, int nb, int nbp, int C, int64_t Kp, void* planes,
+                                  const float* row_scale) {
+    AAS_CHECK(src && planes && T >= 1 && nb >= 1 && nbp >= nb && nbp % 8 == 0 && C >= 1 && Kp >= (int64_t)T * nbp && Kp % 32 == 0,
+              "aas_split_planes_t: bad arguments (T=%d nb=%d nbp=%d C=%d Kp=%lld)", T, nb, nbp, C, (long long)Kp);
+    hipLaunchKernelGGL(split_rows_t_kernel, dim3(cdiv(C, 64), (unsigned)((Kp + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src, ld, T, nb, nbp,
+                       C, Kp, (char*)planes, row_scale);
+    AAS_LAUNCH_CHECK("aas_split_planes_t");
+    return 0;
+}

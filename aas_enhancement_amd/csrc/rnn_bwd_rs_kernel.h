@@ -326,7 +326,7 @@ int launch_rs(const RnnP& p, hipStream_t s) {
 template <int MODE>
 int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
     AAS_CHECK(p.T >= 1 && p.N >= 1 && p.H >= 1, "%s: bad sizes T=%d N=%d H=%d", name, p.T, p.N, p.H);
-    const int cus = aas_device_cus();
+    const int cus = aas_rnn_cus();
     AAS_CHECK(cus > 0, "%s: no HIP device", name);
     p.flags = aas_debug_flags_value();
     // 32-unit slices (512-thread workgroups) halve the number of slices and with it the bytes every step moves

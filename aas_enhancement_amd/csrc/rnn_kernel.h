@@ -400,7 +400,7 @@ int run(const char* name, RnnP p, hipStream_t s) {
     using C = Cfg<MODE>;
     constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD);
     AAS_CHECK(p.T >= 1 && p.N >= 1 && p.H >= 1, "%s: bad sizes T=%d N=%d H=%d", name, p.T, p.N, p.H);
-    const int cus = aas_device_cus();
+    const int cus = aas_rnn_cus();
     AAS_CHECK(cus > 0, "%s: no HIP device", name);
     p.flags = aas_debug_flags_value();
     p.P = cdiv(p.H, C::U);

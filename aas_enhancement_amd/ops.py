@@ -5,6 +5,8 @@ modules (model.py) participate in autograd.  All tensors are fp32 CUDA (HIP) ten
 Layouts used internally:  sequences [T,N,H] row-major ("TNH"); conv front-end
 channels-last [N,T,C]; the module boundary keeps the reference's [N,C,T].
 """
+import os
+
 import torch
 
 from . import _lib
@@ -71,19 +73,37 @@ def get_precision():
     return _precision[0]
 
 
+def set_rnn_cu_limit(cus):
+    """Cap the CUs of every persistent recurrent launch queued from now on (0 = whole device)."""
+    check(lib().aas_set_rnn_cu_limit(int(cus)), "aas_set_rnn_cu_limit")
+
+
+def device_cus():
+    return int(lib().aas_device_cus())
+
+
 # ---- off-critical-path weight gradients --------------------------------------------------------------
 # When a parameter's .grad is pre-bound to a flat gradient buffer (dist.FlatBuffers) and DIRECT_WGRAD is on,
 # the recurrent layers' weight-gradient GEMMs run on a side HIP stream and ACCUMULATE straight into .grad
 # (autograd gets None for those inputs): they are only needed at the optimiser step, so they overlap the next
 # layer's persistent BPTT launch instead of sitting on the backward critical path.  sync_wgrad() joins.
 DIRECT_WGRAD = [False]
+_SKIP_WGRAD = bool(int(__import__('os').environ.get('AAS_SKIP_WGRAD', '0')))
 _wgrad_streams = {}
 
 
 def wgrad_stream(dev):
     s = _wgrad_streams.get(dev)
     if s is None:
-        s = torch.cuda.Stream(device=dev)
+        # lowest priority: when a persistent recurrent launch and queued weight-gradient blocks compete for CUs, the
+        # recurrent grid (which must become fully resident) is dispatched first
+        prio = 0
+        if os.environ.get("AAS_WGRAD_PRIO", "1") == "1":
+            try:
+                prio = max(torch.cuda.Stream.priority_range())
+            except Exception:  # noqa: BLE001
+                prio = 0
+        s = torch.cuda.Stream(device=dev, priority=prio)
         _wgrad_streams[dev] = s
     return s
 
@@ -153,6 +173,56 @@ def _gemm_raw(mode, M, N, K, A, lda, B, ldb, C, ldc, bias, addend, ldd, accumula
     check(lib().aas_gemm_f32(stream(), mode, M, N, K, A.data_ptr() + 4 * a_off, lda, B.data_ptr() + 4 * b_off, ldb,
                              C.data_ptr() + 4 * c_off, ldc, ptr(bias), ptr(addend), ldd, int(accumulate),
                              batch, sA, sB, sC, kdivA, kouterA, kdivB, kouterB), "aas_gemm_f32")
+
+
+# ---- pre-split operand planes (split-bf16 GEMM with the fp32 -> hi/lo split hoisted out of the k-loop) ----------
+class Planes(object):
+    """Interleaved bf16 hi/lo planes of a [rows, K] operand (include/aas_hip.h: aas_gemm_planes): `buf` is
+    [rows, Kp/32, 2, 32] bf16, pitch Kp (multiple of 32, zero pad)."""
+    __slots__ = ("buf", "rows", "K", "Kp")
+
+    def __init__(self, buf, rows, K, Kp):
+        self.buf, self.rows, self.K, self.Kp = buf, rows, K, Kp
+
+    def to_float(self):
+        """[rows, Kp] fp32 reconstruction hi + lo (tests)."""
+        b = self.buf.view(self.rows, self.Kp // 32, 2, 32).float()
+        return (b[:, :, 0, :] + b[:, :, 1, :]).reshape(self.rows, self.Kp)
+
+
+def _kp(K):
+    return (K + 31) // 32 * 32
+
+
+def split_planes(x2d, rows, K, ld=None, row_scale=None, nb=0, off=0):
+    """planes of x2d[r*ld + off + k] (* row_scale[r % nb])."""
+    Kp = _kp(K)
+    buf = torch.empty((rows, 2 * Kp), device=x2d.device, dtype=torch.bfloat16)
+    check(lib().aas_split_planes(stream(), x2d.data_ptr() + 4 * off, ld if ld is not None else K, rows, K, Kp, ptr(buf),
+                                 ptr(row_scale), nb), "aas_split_planes")
+    return Planes(buf, rows, K, Kp)
+
+
+def split_planes_t(x3d, T, nb, C, ld=None, row_scale=None, off=0, extra=0):
+    """Transposed planes of a time-major [T*nb, C] matrix: planes[c][t*nbp + n], nbp = nb rounded up to 8; `extra` more
+    zero k positions behind T*nbp (room for a shifted k window)."""
+    nbp = (nb + 7) // 8 * 8
+    Kp = _kp(T * nbp + extra)
+    buf = torch.empty((C, 2 * Kp), device=x3d.device, dtype=torch.bfloat16)
+    check(lib().aas_split_planes_t(stream(), x3d.data_ptr() + 4 * off, ld if ld is not None else C, T, nb, nbp, C, Kp, ptr(buf),
+                                   ptr(row_scale)), "aas_split_planes_t")
+    return Planes(buf, C, T * nbp, Kp), nbp
+
+
+def gemm_planes(M, N, K, A, B, C, ldc, bias=None, addend=None, ldd=0, accumulate=False, batch=1, sA=0, sB=0, sC=0,
+                a_off=0, b_off=0, c_off=0, lda=None, ldb=None):
+    """C[M,N] (+)= A[M,K] B[N,K]^T on Planes operands; K is the k extent actually multiplied (multiple of 32);
+    a_off/b_off are offsets in elements (multiples of 32 within a row, or whole rows), c_off in elements."""
+    with _timed("gemm", "gemm_planes", 2.0 * M * N * K * batch):
+        check(lib().aas_gemm_planes(stream(), M, N, K, A.buf.data_ptr() + 4 * a_off, lda if lda is not None else A.Kp,
+                                    B.buf.data_ptr() + 4 * b_off, ldb if ldb is not None else B.Kp,
+                                    C.data_ptr() + 4 * c_off, ldc, ptr(bias), ptr(addend), ldd, int(accumulate), batch, sA, sB, sC),
+              "aas_gemm_planes")
 
 
 def linear_fwd(x2d, W, bias=None):
@@ -372,6 +442,8 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         return dx, None, None, None, None
 
     def wgrads(out, acc):
+        if _SKIP_WGRAD:  # timing experiment only (AAS_SKIP_WGRAD=1): how much of the step the weight-gradient products hold
+            return
         if rs is not None:  # per-utterance weights on the parameter gradients only (dx used the unscaled d(gates))
             scale_rows(dgx, rs, N, out=dgx)
             if dgh is not dgx:

@@ -198,7 +198,11 @@ class Trainer(object):
             # iterations g_adv needs E's adversarial-only gradients, so E is back-propagated per loss.
             leaf = enhanced.detach().requires_grad_(True)
             Nn = leaf.size(0)
-            acoustic = self._acoustic_branch(enhanced, targets, sizes, target_sizes, N_glob, ctc_meta)
+            overlap = self._overlap_asr()
+            acoustic = None
+            if overlap:  # two chains of persistent launches side by side, half the chip each
+                ops.set_rnn_cu_limit(ops.device_cus() // 2)
+                acoustic = self._acoustic_branch(enhanced, targets, sizes, target_sizes, N_glob, ctc_meta)
             if tuple(cl_inputs.shape[1:]) == tuple(leaf.shape[1:]):
                 # D(enhanced) and D(clean) share ONE batched pass (rows are independent: D has no batch
                 # statistics).  The D-step gradients of the enhanced half are (-kt) x its G-step parameter
@@ -231,11 +235,14 @@ class Trainer(object):
             if dp.active:  # D's all-reduce overlaps the acoustic branch and E's backward
                 ops.sync_wgrad()
                 handle_d = dp.allreduce_sum_(self._flat["D"].flat_g, async_op=True)
-            # CTC loss (:163-172).  The acoustic branch A(enhanced) -> CTC -> backward is independent of the
-            # D branch above: it was enqueued on a second HIP stream BEFORE the D branch (see _acoustic_branch),
-            # so the two chains of persistent recurrent launches overlap on the 256 CUs.
+            # CTC loss (:163-172).  The acoustic branch A(enhanced) -> CTC -> backward is independent of the D branch
+            # above: with AAS_OVERLAP_ASR=1 it was queued on a second stream before it, else it follows it here.
+            if acoustic is None:
+                acoustic = self._acoustic_branch(enhanced, targets, sizes, target_sizes, N_glob, ctc_meta)
             prob, l_CTC, leaf_a = acoustic
             torch.cuda.current_stream().wait_stream(self._side)
+            if overlap:
+                ops.set_rnn_cu_limit(0)
             leaf_a.grad.record_stream(torch.cuda.current_stream())
             # (on logging iterations the adversarial part was already back-propagated for g_adv)
             gsum = ops.add3(leaf.grad, leaf_a.grad) if leaf.grad is not None else leaf_a.grad
@@ -284,7 +291,11 @@ class Trainer(object):
         N = inputs.size(0)
         enhanced = self.G(inputs)
         leaf = enhanced.detach().requires_grad_(True)
-        acoustic = self._acoustic_branch(enhanced, None, None, None, N, ctc_meta)
+        overlap = self._overlap_asr()
+        acoustic = None
+        if overlap:  # two chains of persistent launches side by side, half the chip each
+            ops.set_rnn_cu_limit(ops.device_cus() // 2)
+            acoustic = self._acoustic_branch(enhanced, None, None, None, N, ctc_meta)
         rs = torch.empty(N + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
         rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
         rs[N:] = 1.0
@@ -292,8 +303,12 @@ class Trainer(object):
         l_adv_ny_G = ops.l1_sum(ae[:N], leaf) * (c.w_adversarial / nv_ny)
         l_adv_cl = ops.l1_sum(ae[N:], cl_inputs) * (c.w_adversarial / nv_cl)
         (l_adv_ny_G + l_adv_cl).backward()
+        if acoustic is None:
+            acoustic = self._acoustic_branch(enhanced, None, None, None, N, ctc_meta)
         prob, l_CTC, leaf_a = acoustic
         torch.cuda.current_stream().wait_stream(self._side)
+        if overlap:
+            ops.set_rnn_cu_limit(0)
         leaf_a.grad.record_stream(torch.cuda.current_stream())
         enhanced.backward(ops.add3(leaf.grad, leaf_a.grad))
         ops.sync_wgrad()
@@ -393,14 +408,19 @@ class Trainer(object):
         return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, kt=self.kt,
                     conv_measure=l_adv_cl_data + abs(g_d_balance), g_adv=None, g_ctc_adv=None, enhanced=g["enh"], prob=g["prob"])
 
+    @staticmethod
+    def _overlap_asr():
+        return os.environ.get("AAS_OVERLAP_ASR", "1") == "1"
+
     def _acoustic_branch(self, enhanced, targets, sizes, target_sizes, N_glob, ctc_meta):
         """A(enhanced) -> CTC/N -> backward down to a private leaf (optionally on a second stream)."""
         c = self.config
-        # Default: the acoustic branch runs on the CURRENT (main) stream.  Two chains of persistent recurrent kernels on
-        # two streams measured no faster (both are bound by the same memory-side bandwidth: 29.7 vs 29.7 ms / step), and
-        # keeping ONE persistent kernel in flight at a time means its grid is always fully resident.  AAS_OVERLAP_ASR=1
-        # puts the branch on a second stream (weight-gradient GEMMs always run on their own side stream).
-        if os.environ.get("AAS_OVERLAP_ASR", "0") == "1":
+        # Default (AAS_OVERLAP_ASR=1): the acoustic branch runs on a second stream, queued BEFORE the discriminator pass, and
+        # every persistent recurrent launch of the two chains is capped at half the CUs (ops.set_rnn_cu_limit), so a launch of
+        # each chain is always fully resident next to one of the other.  The recurrent kernels are latency- not throughput-
+        # bound, so two chains side by side finish sooner than one after the other (27.2 -> 24.0 ms / step); without the cap
+        # (each launch sized for the whole chip) the overlap measured nothing.  AAS_OVERLAP_ASR=0: one chain on the main stream.
+        if self._overlap_asr():
             if getattr(self, "_side_stream", None) is None:
                 self._side_stream = torch.cuda.Stream()
             self._side = self._side_stream

@@ -36,6 +36,9 @@ int aas_set_debug_flags(int flags);
  * carried as bf16 hi + bf16 lo and the product as hi*hi + lo*hi + hi*lo with fp32 accumulation (~1e-5 relative,
  * fp32-class; 3 bf16 MFMAs instead of 16 fp32-MFMA issue slots). */
 int aas_set_precision(int mode);
+/* cap on the CUs one persistent recurrent launch occupies (0 = whole device): lets two independent chains of recurrent
+ * launches (trainer_AAS.py:153-172: discriminator pass and acoustic pass) run side by side on two streams */
+int aas_set_rnn_cu_limit(int cus);
 
 /* ---------------------------------------------------------------- dense linear algebra --------
  * fp32 MFMA GEMM  C = op(A) op(B) [+ bias broadcast over rows] [+ addend] [+ C if accumulate].
@@ -57,6 +60,24 @@ int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K,
                  const float* bias, const float* addend, int64_t ldd, int accumulate,
                  int batch, int64_t strideA, int64_t strideB, int64_t strideC,
                  int kdivA, int64_t kouterA, int kdivB, int64_t kouterB);
+
+/* Split-bf16 GEMM on pre-split operand planes (same products as aas_gemm_f32 under aas_set_precision(1), with the
+ * fp32 -> (hi, lo) bf16 split hoisted out of the k-loop into one HBM-bound pass per operand):
+ *   C[M,N] (+)= A[M,K] B[N,K]^T (+ bias[N]) (+ addend[M,N]),  A/B given as interleaved bf16 planes: row r, 32-wide
+ *   k-block b = 64 B of hi = rne(x) then 64 B of lo = rne(x - hi) at byte r*ld*4 + b*128 (one 128-byte line per block),
+ *   K % 32 == 0 with zero-filled pad, lda/ldb/strides in elements and multiples of 32, 128-byte aligned.
+ * aas_split_planes:   planes[r][k] = split(src[r*ld + k] * row_scale[r % nb]), k < K; zeros for K <= k < Kp.
+ * aas_split_planes_t: planes[c][t*nbp + n] = split(src[(t*nb + n)*ld + c] * row_scale[n]) for c < C, time-major src
+ *                     [T*nb rows]; pads (n >= nb, and [T*nbp, Kp)) are written as zeros.  This is the operand form of the
+ *                     weight-gradient products dW = d(gates)^T x (model.py:73-74 backward), with the per-utterance loss
+ *                     weights of the batched discriminator pass (trainer_AAS.py:153-167) folded into the split. */
+int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                    float* C, int64_t ldc, const float* bias, const float* addend, int64_t ldd, int accumulate,
+                    int batch, int64_t strideA, int64_t strideB, int64_t strideC);
+int aas_split_planes(aasStream_t stream, const float* src, int64_t ld, int64_t rows, int K, int Kp, void* planes,
+                     const float* row_scale, int nb);
+int aas_split_planes_t(aasStream_t stream, const float* src, int64_t ld, int T, int nb, int nbp, int C, int64_t Kp,
+                       void* planes, const float* row_scale);
 
 /* ---------------------------------------------------------------- layout / elementwise --------
  * out[b, c, r] = in[b, r, c]  with element strides (in: isb, isr, c contiguous; out: osb, osc, r
