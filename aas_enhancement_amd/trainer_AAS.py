@@ -246,7 +246,9 @@ class Trainer(object):
             leaf_a.grad.record_stream(torch.cuda.current_stream())
             # (on logging iterations the adversarial part was already back-propagated for g_adv)
             gsum = ops.add3(leaf.grad, leaf_a.grad) if leaf.grad is not None else leaf_a.grad
+            ops.set_rnn_cu_limit(int(os.environ.get("AAS_EBWD_CUS", "128")))  # leave CUs to E's weight-gradient GEMMs
             enhanced.backward(gsum)
+            ops.set_rnn_cu_limit(0)
             if log_norms:
                 g_ctc_adv = self.get_gradient_norm(self.G)
         ops.sync_wgrad()  # join the side-stream weight-gradient products before the gradients are consumed
@@ -307,10 +309,12 @@ class Trainer(object):
             acoustic = self._acoustic_branch(enhanced, None, None, None, N, ctc_meta)
         prob, l_CTC, leaf_a = acoustic
         torch.cuda.current_stream().wait_stream(self._side)
-        if overlap:
-            ops.set_rnn_cu_limit(0)
+        # E's BPTT launches are capped too: the CUs they leave free run E's weight-gradient GEMMs (side stream), which would
+        # otherwise wait for each fully-resident 512-thread launch to retire
+        ops.set_rnn_cu_limit(int(os.environ.get("AAS_EBWD_CUS", "128")))
         leaf_a.grad.record_stream(torch.cuda.current_stream())
         enhanced.backward(ops.add3(leaf.grad, leaf_a.grad))
+        ops.set_rnn_cu_limit(0)
         ops.sync_wgrad()
         optimizer_g.step_dev()
         optimizer_d.step_dev()
