@@ -370,6 +370,10 @@ def linear_rows(x, W, b=None, rs=None):
 
 
 # --------------------------------------------------------------------------------------- RNN layers
+PLANES_PRE = [os.environ.get("AAS_PLANES_PRE", "1") == "1"]   # input projections of the recurrent layers on the plane GEMM
+_frozen_planes = {}
+
+
 def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
     """x [T,N,I] -> (pre, hout[2,T,N,H], gact, cst)."""
     T, N, I = x.shape
@@ -379,7 +383,24 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
     pre = torch.empty((T, N, 2, G * H), device=dev, dtype=torch.float32)
     x2 = x.view(T * N, I)
     dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4  # element distance between the two directions' W_ih
-    if dw > 0 and dw % 4 == 0:
+    if _precision[0] == 1 and PLANES_PRE[0] and T * N >= 1024 and I >= 64:
+        # plane GEMM: x and [W_ih; W_ih_rev] as pre-split bf16 planes (one HBM-bound pass each; frozen weights are
+        # split once), then one LDS-DMA-staged launch for both directions: pre[tn, d*GH + g]
+        GH = G * H
+        xa = split_planes(x2, T * N, I)
+        frozen = not (w_ih.requires_grad or w_ih_r.requires_grad)
+        key = (w_ih.data_ptr(), w_ih_r.data_ptr(), GH, I)
+        wb = _frozen_planes.get(key) if frozen else None
+        if wb is None:
+            Kp = _kp(I)
+            buf = torch.empty((2 * GH, 2 * Kp), device=dev, dtype=torch.bfloat16)
+            check(lib().aas_split_planes(stream(), ptr(w_ih), I, GH, I, Kp, ptr(buf), None, 0), "aas_split_planes")
+            check(lib().aas_split_planes(stream(), ptr(w_ih_r), I, GH, I, Kp, buf.data_ptr() + GH * Kp * 4, None, 0), "aas_split_planes")
+            wb = Planes(buf, 2 * GH, I, Kp)
+            if frozen and not torch.cuda.is_current_stream_capturing():
+                _frozen_planes[key] = wb
+        gemm_planes(T * N, 2 * GH, xa.Kp, xa, wb, pre, 2 * GH)
+    elif dw > 0 and dw % 4 == 0:
         # both directions in ONE batched launch: same A, B strided by the distance between the two weight tensors
         # (they live in one flat parameter buffer), C = the two column halves of `pre`
         gemm(NT, T * N, G * H, I, x2, I, w_ih, I, pre, 2 * G * H, batch=2, sA=0, sB=dw, sC=G * H)

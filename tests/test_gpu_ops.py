@@ -254,6 +254,79 @@ def test_birnn_layer_vs_cpu_at_size(ops, precision, kind, T, N, H):
         assert rel_err(wg.grad, getattr(ref, k).grad) < 2 * gt, k
 
 
+@pytest.mark.parametrize("variant", ["rs_u32", "rs_u16", "allgather", "half_chip"])
+def test_bptt_kernel_variants_agree(ops, variant):
+    """The BPTT formulations (reduce-scatter with 32- / 16-unit slices, all-gather, CU-capped grid) give the same
+    gradients as the exact-fp32 kernels to split-bf16 accuracy."""
+    from aas_enhancement_amd import _lib
+    L = _lib.lib()
+    outs = {}
+    for kind, T, N, H in (("lstm", 50, 30, 500), ("gru", 20, 30, 300), ("lstm", 7, 5, 24)):
+        torch.manual_seed(1)
+        w = [(torch.randn((4 if kind == "lstm" else 3) * H, H) / H ** 0.5).cuda().requires_grad_(True) for _ in range(4)]
+        x = (R(T, N, H, seed=3) * 0.5).cuda()
+        gy = R(T, N, H, seed=4).cuda()
+        res = []
+        for mode in ("ref", variant):
+            for t in w:
+                t.grad = None
+            xg = x.clone().requires_grad_(True)
+            ops.set_precision(0 if mode == "ref" else 1)
+            L.aas_set_debug_flags({"rs_u16": 512, "allgather": 256}.get(mode, 0))
+            ops.set_rnn_cu_limit(128 if mode == "half_chip" else 0)
+            try:
+                y = ops.birnn_layer(xg, *w, kind=kind, residual=False)
+                y.backward(gy)
+                torch.cuda.synchronize()
+            finally:
+                L.aas_set_debug_flags(0)
+                ops.set_rnn_cu_limit(0)
+                ops.set_precision(1)
+            assert not ops.rnn_timeout_flag()
+            res.append([xg.grad.clone()] + [t.grad.clone() for t in w])
+        for a, b in zip(*res):
+            assert rel_err(b, a) < 2e-4, (kind, variant)
+
+
+@pytest.mark.parametrize("M,N,K", [(6000, 4000, 500), (300, 520, 96), (333, 77, 100), (1, 5, 32), (2000, 500, 6016), (129, 257, 1056)])
+def test_gemm_planes_vs_fp64(ops, M, N, K):
+    """aas_gemm_planes (pre-split operands, LDS-DMA staging; 256x256, 128x128 and split-K paths) against fp64, with
+    bias / addend / accumulate; the split is exact to 2^-18 per element."""
+    A, B = R(M, K, seed=5).cuda(), R(N, K, seed=6).cuda()
+    bias, add = R(N, seed=7).cuda(), R(M, N, seed=8).cuda()
+    pa, pb = ops.split_planes(A, M, K), ops.split_planes(B, N, K)
+    assert (pa.to_float()[:, :K] - A).abs().max() <= 2.0 ** -17 * A.abs().max()
+    assert pa.Kp == K or pa.to_float()[:, K:].abs().max() == 0
+    ref = A.double() @ B.double().t()
+    C = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm_planes(M, N, pa.Kp, pa, pb, C, N)
+    assert rel_err(C, ref) < 2e-5
+    ops.gemm_planes(M, N, pa.Kp, pa, pb, C, N, bias=bias, addend=add, ldd=N)
+    assert rel_err(C, ref + bias.double() + add.double()) < 2e-5
+    C0 = C.clone()
+    ops.gemm_planes(M, N, pa.Kp, pa, pb, C, N, accumulate=True)
+    assert rel_err(C, C0.double() + ref) < 2e-5
+
+
+def test_split_planes_transposed(ops):
+    """aas_split_planes_t: time-major [T*nb, C] -> planes[c][t*nbp + n] with per-utterance weights and zero pads; used as
+    both operands of a weight-gradient product dW = (rs * dg)^T x."""
+    T, nb, C1, C2 = 9, 30, 200, 72
+    dg, x = R(T * nb, C1, seed=9).cuda(), R(T * nb, C2, seed=10).cuda()
+    rs = (torch.rand(nb) + 0.5).cuda()
+    pa, nbp = ops.split_planes_t(dg, T, nb, C1, row_scale=rs, extra=32)
+    pb, _ = ops.split_planes_t(x, T, nb, C2, extra=32)
+    full = pa.to_float()
+    want = (dg.view(T, nb, C1) * rs.view(1, nb, 1)).permute(2, 0, 1)
+    got = full[:, :T * nbp].view(C1, T, nbp)
+    assert (got[:, :, :nb] - want).abs().max() <= 2.0 ** -17 * want.abs().max()
+    assert got[:, :, nb:].abs().max() == 0 and full[:, T * nbp:].abs().max() == 0
+    dW = torch.empty(C1, C2, device="cuda")
+    ops.gemm_planes(C1, C2, pa.Kp, pa, pb, dW, C2)
+    ref = (dg.double() * rs.double().repeat(T).view(-1, 1)).t() @ x.double()
+    assert rel_err(dW, ref) < 2e-5
+
+
 def test_ctc_vs_numpy_and_torch(ops):
     from aas_enhancement_amd.ctc import CTCLoss
     from oracle import ctc_np
