@@ -183,11 +183,12 @@ def main():
         # share a pass, and counters cannot be read from inside the process): the committed summary of those passes
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))
-            key = {"lstm_bwd": "rnn_split_kernel<1, 1, 16>", "lstm_fwd": "rnn_split_kernel<0, 1, 4>",
-                   "gru_bwd": "rnn_split_kernel<3, 1, 24>", "gru_fwd": "rnn_split_kernel<2, 1, 8>"}.get(name)
-            if key and key in pmc["kernels"]:
-                traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")))
+            keys = {"lstm_bwd": ["rnn_bwd_rs_kernel<1, 32, 4>"], "lstm_fwd": ["rnn_split_kernel<0, 1, 4>", "rnn_split_kernel<0, 2, 4>"],
+                    "gru_bwd": ["rnn_bwd_rs_kernel<3, 32, 8>"], "gru_fwd": ["rnn_split_kernel<2, 2, 8>"]}.get(name, [])
+            ks = [pmc["kernels"][k] for k in keys if k in pmc["kernels"]]
+            if ks:  # dispatch-weighted mean over the kernel's instantiations
+                traffic = sum(k["hbm_bytes_per_launch"] * k["dispatches"] for k in ks) / sum(k["dispatches"] for k in ks)
         except Exception:  # noqa: BLE001
             traffic = None
         achieved = d["flops_per_launch"] / (d["avg_ms"] * 1e-3) / 1e12
@@ -202,7 +203,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_note": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes "
-                                         "(profiles/r01b_pmc_traffic.json); algorithmic bytes per launch 0.26 GB (N=30) / 0.53 GB (N=60)",
+                                         "(profiles/r01c_pmc_traffic.json; L2<->fabric bytes, i.e. including the in-launch exchange ring that the Infinity Cache absorbs); "
+                                         "algorithmic bytes per launch 0.26 GB (N=30) / 0.53 GB (N=60)",
                          "timing": ("HIP events around each launch on its launch stream, %d eager steps run right after the "
                                     "timed graph-replayed region" % psteps) if use_graph else "HIP events around each launch inside the timed region",
                          "avg_launch_ms": d["avg_ms"], "launches_per_step": d["count"] / psteps,

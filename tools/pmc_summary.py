@@ -1,0 +1,49 @@
+"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM bytes per launch.
+
+    python tools/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> "<command that was profiled>"
+
+Units (MI355X_MICROARCH.md, HBM / rocprofv3 section): both counters are in KiB per dispatch; on gfx950 FETCH_SIZE reports
+half of the bytes of wide (16 B/lane) coalesced reads, so fetched bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact."""
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def collect(d, counter):
+    acc = {}
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+            name = re.sub(r"^void ", "", name).split("(")[0]
+            key = (name, r.get("Dispatch_Id"))
+            acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"])   # one row per XCD / dimension instance: sum them
+    per = {}
+    for (name, _), v in acc.items():
+        per.setdefault(name, []).append(v)
+    return per
+
+
+def main():
+    fdir, wdir, out, cmd = sys.argv[1:5]
+    fe, wr = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
+    kernels = {}
+    for name in sorted(set(fe) | set(wr)):
+        f = fe.get(name, [])
+        w = wr.get(name, [])
+        fa = sum(f) / len(f) if f else 0.0
+        wa = sum(w) / len(w) if w else 0.0
+        kernels[name] = {"FETCH_SIZE_KiB_avg": fa, "WRITE_SIZE_KiB_avg": wa, "dispatches": max(len(f), len(w)),
+                         "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `%s`" % cmd,
+               "units": "KiB per dispatch; fetched bytes = 2 x FETCH_SIZE x 1024 (gfx950 wide-read correction), written bytes = WRITE_SIZE x 1024",
+               "kernels": kernels}, open(out, "w"), indent=1)
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
+        print("%-60s x%-4d %8.1f MB / launch" % (k[:60], v["dispatches"], v["hbm_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
