@@ -1,0 +1,315 @@
+// Forward persistent recurrent kernel with 32-unit slices (512-thread workgroups), split-bf16 products.
+//
+// Same algorithm and exchange format as the forward modes of rnn_split_kernel.h (all-gather of h_t through poison-tagged
+// 128-byte hi|lo lines), with twice the units per workgroup: half as many slices P, so half as many producers to poll
+// and half the bytes that the chip moves per step (every workgroup still reads rows x H, but there are half as many
+// workgroups per batch group - or, at a fixed CU budget, half as many rows per workgroup).  8 waves split K eight ways
+// (a quarter of the fragment loads per wave of the 4-wave kernel), the W_hh slice [H x G*32] stays in VGPRs as bf16 hi/lo
+// B-fragments; for the 1000-unit GRU (192 of 256 VGPRs) the lo fragments of the last LKS k-steps live in LDS.
+#pragma once
+#include "rnn_split_kernel.h"
+
+namespace {
+
+// MODE = LSTM_FWD or GRU_FWD; KS = 32-wide k chunks per wave (Hp = 256*KS); LKS = k-steps whose lo fragments are in LDS
+template <int MODE, int KS, int LKS>
+__global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
+    using C = Cfg<MODE>;
+    constexpr int G = C::G, U = 32, NW = 8;
+    constexpr bool LSTM = (MODE == LSTM_FWD);
+    constexpr int NT = G * U / 16;                       // 16-column tiles of the workgroup's G*U gate columns
+    constexpr int LDR = NT * 16 + 16;
+    constexpr bool DB = LSTM;                            // parity-double-buffered reduction (one barrier per step)
+    __shared__ __attribute__((aligned(16))) float red2[DB ? 2 : 1][NW][16][LDR];
+    __shared__ u32x4 bl_lds[LKS ? LKS * NT : 1][LKS ? 512 : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pslice = blockIdx.x, qg = blockIdx.y, d = blockIdx.z;
+    const int T = p.T, N = p.N, H = p.H, GH = G * H;
+    const int Hp = p.P * U;                              // padded unit pitch of the exchange rows
+    const int u0 = pslice * U;
+    const int q0 = p.n0 + qg * p.rpg;
+    const int NB = min(p.n1, q0 + p.rpg);
+    const int kb = wave * KS * 32;
+    unsigned* err = p.sync + ERR_WORD;
+
+    // ---- B fragments (hi / lo) of this workgroup's W_hh slice: rows {gate*H + unit}, this wave's k range ------------
+    const float* W = d == 0 ? p.w_hh : p.w_hh_r;
+    bf16x8 bh[KS][NT], bl[KS][NT];
+    {
+        const int n = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = nt * 16 + n;                    // gate column c = u*G + gate: a unit's G gates are adjacent
+                const int gate = c % G, unit = u0 + c / G;
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    unsigned h2[2], l2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int k = kb + ks * 32 + q * 8 + jj * 2 + e;
+                        float v = 0.f;
+                        if (unit < H && k < H) v = W[(int64_t)(gate * H + unit) * H + k];
+                        split_bf16(v, h2[e], l2[e]);
+                    }
+                    hw[jj] = h2[0] | (h2[1] << 16);
+                    lw[jj] = l2[0] | (l2[1] << 16);
+                }
+                const u32x4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
+                bh[ks][nt] = __builtin_bit_cast(bf16x8, hv);
+                if (ks >= KS - LKS) bl_lds[LKS ? (ks - (KS - LKS)) * NT + nt : 0][LKS ? tid : 0] = lv;
+                else bl[ks][nt] = __builtin_bit_cast(bf16x8, lv);
+            }
+    }
+
+    // exchange rows: [2][T][N] rows of KC 128-byte chunks (32 units: 64 B bf16 hi | 64 B bf16 lo)
+    const int KC = Hp / 32;
+    unsigned* xq = p.xchg;
+    auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xq, 0, (int)((int64_t)2 * T * N * KC * 128), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr unsigned POISON = 0xFFFFFFFFu;
+
+    // gate-math role: one (row, unit) per thread
+    const int row = tid >> 5, u = tid & 31;
+    const int gr = q0 + row, unit = u0 + u;
+    const bool rowok = gr < NB;
+    const bool ok = rowok && unit < H;
+
+    float carry = 0.f;
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    const bool stamp = (p.flags & 64) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    for (int s = 0; s < T; ++s) {
+        unsigned long long st0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull, st1 = st0, st2 = st0, st3 = st0;
+        const int t = (d == 0) ? s : T - 1 - s;
+        const int tp = (d == 0) ? t - 1 : t + 1;
+        const int64_t tn = (int64_t)t * N + gr;
+
+        // ---- private inputs: pre-activations of my (row, unit) --------------------------------------
+        float pin[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) pin[g] = 0.f;
+        if (ok) {
+            const float* pp = p.pre + (tn * 2 + d) * GH + unit;
+#pragma unroll
+            for (int g = 0; g < G; ++g) pin[g] = pp[g * H];
+        }
+
+        // ---- recurrent product: this wave's k range of h_{t-1} x W slice ------------------------------
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            const int m = lane & 15, q = lane >> 4;
+            const int64_t xr0 = ((int64_t)d * T + tp) * N + q0;
+            if (!(p.flags & 4)) {
+                // poll one word per producer slice of my k range (first row of the group)
+                const int nprod = (KS * 32) / U;
+                const int kprobe = kb + lane * U;
+                const bool probe = lane < nprod && kprobe < Hp && !(p.flags & 1);
+                const unsigned* wp = xq + (xr0 * KC + kprobe / 32) * 32 + (kprobe % 32) / 2;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0;
+                while (true) {
+                    const unsigned w = probe ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    if (!__any(w == POISON)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 255u) == 0) {
+                        if (ld_cnt(err) != 0) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
+                            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+            }
+            if (stamp) st1 = __builtin_amdgcn_s_memrealtime();
+            const int grm = q0 + m;
+            const unsigned roff = (grm < NB && !(p.flags & 1)) ? (unsigned)(((xr0 + m) * KC + wave * KS) * 128 + q * 16) : OOB;
+            u32x4 ah[KS], al[KS];
+            unsigned spins = 0;
+            unsigned long long t0 = 0;
+            bool fresh = (p.flags & 32) != 0;
+            while (true) {
+                // first attempt with plain loads (workgroups of an XCD share the rows through its L2: a stale line can only
+                // show POISON, never wrong data), retries with sc1
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const unsigned off = (kb + ks * 32 + q * 8 < Hp) ? roff + (unsigned)(ks * 128) : OOB;
+                    if (fresh) {
+                        ah[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 16));
+                        al[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off + 64u), 0, 16));
+                    } else {
+                        ah[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
+                        al[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off + 64u), 0, 0));
+                    }
+                }
+                unsigned mx = 0u;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    mx = max(mx, max(max(ah[ks].x, ah[ks].y), max(ah[ks].z, ah[ks].w)));
+                    mx = max(mx, max(max(al[ks].x, al[ks].y), max(al[ks].z, al[ks].w)));
+                }
+                if ((p.flags & 4) || !__any(mx == POISON)) break;
+                fresh = true;
+                if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
+                if ((++spins & 63u) == 0) {
+                    if (ld_cnt(err) != 0) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
+                        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            if (!(p.flags & 2)) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[ks]), a_l = __builtin_bit_cast(bf16x8, al[ks]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        bf16x8 blv;
+                        if (ks >= KS - LKS) blv = __builtin_bit_cast(bf16x8, bl_lds[LKS ? (ks - (KS - LKS)) * NT + nt : 0][LKS ? tid : 0]);
+                        else blv = bl[ks][nt];
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, bh[ks][nt], acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, blv, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, bh[ks][nt], acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (stamp) st2 = __builtin_amdgcn_s_memrealtime();
+        float (*red)[16][LDR] = red2[DB ? (s & 1) : 0];
+        {
+            const int col = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][rq + r][nt * 16 + col] = acc[nt][r];
+        }
+        __syncthreads();
+        if (stamp) st3 = __builtin_amdgcn_s_memrealtime();
+
+        // ---- gate math ----------------------------------------------------------------------------------
+        float hval = 0.f, kp[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            float rs[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) rs[g] = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                if (G == 4) {  // one 16-byte LDS read per wave partial
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&red[w][row][u * 4]);
+                    rs[0] += v[0]; rs[1] += v[1]; rs[2] += v[2]; rs[G - 1] += v[3];
+                } else {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) rs[g] += red[w][row][u * G + g];
+                }
+            }
+            if (LSTM) {
+                const float ig = sigmoidf_(pin[0] + rs[0]);
+                const float fg = sigmoidf_(pin[1] + rs[1]);
+                const float gg = tanhf_(pin[2] + rs[2]);
+                const float og = sigmoidf_(pin[G - 1] + rs[G - 1]);
+                const float c = fg * carry + ig * gg;
+                carry = c;
+                hval = og * tanhf_(c);
+                kp[0] = ig; kp[1] = fg; kp[2] = gg; kp[3] = og; kp[4] = c;
+            } else {
+                const float rg = sigmoidf_(pin[0] + rs[0]);
+                const float zg = sigmoidf_(pin[1] + rs[1]);
+                const float hn = rs[2];
+                const float ng = tanhf_(pin[2] + rg * hn);
+                hval = (1.f - zg) * ng + zg * carry;
+                carry = hval;
+                kp[0] = rg; kp[1] = zg; kp[2] = ng; kp[3] = hn;
+            }
+        }
+        // publish: even-unit lanes store {own, partner} packed hi and lo words (pad units publish zeros)
+        {
+            unsigned h0, l0;
+            split_bf16(hval, h0, l0);
+            const unsigned mine = h0 | (l0 << 16);
+            const unsigned other = __shfl_xor(mine, 1, 64);
+            if (rowok && !(u & 1) && s + 1 < T && !(p.flags & 8)) {
+                const int64_t xr = ((int64_t)d * T + t) * N + gr;
+                unsigned* wq = xq + xr * KC * 32 + (unit / 32) * 32 + (unit % 32) / 2;
+                st_sc1_u32(wq, (mine & 0xFFFFu) | (other << 16));
+                st_sc1_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
+            }
+        }
+        if (ok) {
+            p.hout[((int64_t)d * T * N + tn) * H + unit] = hval;
+            *reinterpret_cast<f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4) = (f32x4){kp[0], kp[1], kp[2], kp[3]};
+            if (LSTM) p.cst[((int64_t)d * T * N + tn) * H + unit] = kp[4];
+        }
+        if (!DB) __syncthreads();
+        if (stamp) {
+            const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
+            ph[0] += st1 - st0; ph[1] += st2 - st1; ph[2] += st3 - st2; ph[3] += st4 - st3; ph[4] += st4 - st0;
+        }
+    }
+    if (stamp && tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.sync + STAMP_WORD);
+        for (int i = 0; i < 5; ++i) o[i] = ph[i];
+    }
+}
+
+// 32-unit forward launches: H >= 256 (smaller layers keep the 16-unit kernel so that enough workgroups share the work),
+// Hp = 32*P a multiple of... any; KS = ceil(Hp / 256) <= 4.  Returns -1 when the shape is not covered.
+template <int MODE>
+int run_fwd32(const char* name, RnnP p, hipStream_t s) {
+    constexpr bool LSTM = (MODE == LSTM_FWD);
+    p.flags = aas_debug_flags_value();
+    if (p.H < 256 || (p.flags & 512)) return -1;
+    const int cus = aas_rnn_cus();
+    AAS_CHECK(cus > 0, "%s: no HIP device", name);
+    // measured: while 16-unit slices still get <= 8 rows per workgroup on this CU budget they are as fast or faster
+    // (500-unit LSTM, N=30, whole chip: 2.87 vs 3.01 us / step); beyond that the 32-unit kernel wins clearly (N=60 on
+    // 128 CUs: 3.6 vs 5.1 us / step; 1000-unit GRU on 128 CUs: 4.5 vs 7.1)
+    if (cdiv(p.H, 16) * cdiv(p.N, 8) * 2 <= cus) return -1;
+    p.P = cdiv(p.H, 32);
+    if (p.P * 2 > cus) return -1;
+    const int Hp = p.P * 32;
+    const int ks = cdiv(Hp, 256);
+    if (ks > 4) return -1;
+    const int64_t xbytes = (int64_t)2 * p.T * p.N * (Hp / 32) * 128;
+    if (xbytes >= 0x7fffffffLL) return -1;
+    int rpg = 16;
+    for (int cand = 4; cand < 16; cand *= 2)
+        if (p.P * cdiv(p.N, cand) * 2 <= cus) { rpg = cand; break; }
+    p.rpg = rpg;
+    const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
+    AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes, s));
+    for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {
+        p.n0 = n0;
+        const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
+        p.n1 = n0 + rows;
+        p.Q = cdiv(rows, rpg);
+        dim3 grid(p.P, p.Q, 2), block(512);
+        if constexpr (LSTM) {
+            if (ks == 1) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 1, 0>), grid, block, 0, s, p);
+            else if (ks == 2) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0>), grid, block, 0, s, p);
+            else return -1;   // 128 gate columns x more than 512 k do not fit the register file
+        } else {
+            if (ks == 1) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 1, 0>), grid, block, 0, s, p);
+            else if (ks == 2) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0>), grid, block, 0, s, p);
+            else if (ks == 3) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 3, 1>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 4, 2>), grid, block, 0, s, p);
+        }
+        AAS_LAUNCH_CHECK(name);
+    }
+    return 0;
+}
+
+template <int MODE>
+int run_fwd_any(const char* name, RnnP p, hipStream_t s) {
+    if (p.xchg && aas_precision_value() != 0) {
+        const int rc = run_fwd32<MODE>(name, p, s);
+        if (rc >= 0) return rc;
+    }
+    return run_any<MODE>(name, p, s);
+}
+
+}  // namespace

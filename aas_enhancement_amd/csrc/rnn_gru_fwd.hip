@@ -1,4 +1,4 @@
-#include "rnn_split_kernel.h"
+#include "rnn_fwd32_kernel.h"
 
 extern "C" int aas_gru_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh, const float* w_hh_rev, float* hout,
                            float* gact, void* sync, void* xchg) {
@@ -6,6 +6,6 @@ extern "C" int aas_gru_fwd(aasStream_t stream, int T, int N, int H, const float*
     RnnP p = {};
     p.T = T; p.N = N; p.H = H; p.pre = pre; p.w_hh = w_hh; p.w_hh_r = w_hh_rev; p.hout = hout; p.gact = gact;
     p.sync = (unsigned*)sync; p.xchg = (unsigned*)xchg;
-    return run_any<GRU_FWD>("aas_gru_fwd", p, (hipStream_t)stream);
+    return run_fwd_any<GRU_FWD>("aas_gru_fwd", p, (hipStream_t)stream);
 }
 

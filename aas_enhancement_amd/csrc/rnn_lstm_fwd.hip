@@ -1,4 +1,4 @@
-#include "rnn_split_kernel.h"
+#include "rnn_fwd32_kernel.h"
 
 extern "C" size_t aas_rnn_sync_bytes(void) { return SYNC_BYTES; }
 // the larger of: hi + lo arrays of the widest all-gathered vector (2*T*N rows x G*Hp bf16, Hp <= H + 15), and the
@@ -16,6 +16,6 @@ extern "C" int aas_lstm_fwd(aasStream_t stream, int T, int N, int H, const float
     RnnP p = {};
     p.T = T; p.N = N; p.H = H; p.pre = pre; p.w_hh = w_hh; p.w_hh_r = w_hh_rev; p.hout = hout; p.gact = gact; p.cst = cst;
     p.sync = (unsigned*)sync; p.xchg = (unsigned*)xchg;
-    return run_any<LSTM_FWD>("aas_lstm_fwd", p, (hipStream_t)stream);
+    return run_fwd_any<LSTM_FWD>("aas_lstm_fwd", p, (hipStream_t)stream);
 }
 
