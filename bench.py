@@ -188,8 +188,8 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")))
-            keys = {"lstm_bwd": ["rnn_bwd_rs_kernel<1, 32, 4>"], "lstm_fwd": ["rnn_split_kernel<0, 1, 4>", "rnn_split_kernel<0, 2, 4>"],
-                    "gru_bwd": ["rnn_bwd_rs_kernel<3, 32, 8>"], "gru_fwd": ["rnn_split_kernel<2, 2, 8>"]}.get(name, [])
+            keys = {"lstm_bwd": ["rnn_bwd_rs_kernel<1, 32, 4>"], "lstm_fwd": ["rnn_split_kernel<0, 1, 4>", "rnn_fwd32_kernel<0, 2, 0>"],
+                    "gru_bwd": ["rnn_bwd_rs_kernel<3, 32, 8>"], "gru_fwd": ["rnn_fwd32_kernel<2, 4, 2>"]}.get(name, [])
             ks = [pmc["kernels"][k] for k in keys if k in pmc["kernels"]]
             if ks:  # dispatch-weighted mean over the kernel's instantiations
                 traffic = sum(k["hbm_bytes_per_launch"] * k["dispatches"] for k in ks) / sum(k["dispatches"] for k in ks)
