@@ -183,6 +183,19 @@ class stackedBRNN(nn.Module):
         out = ops.linear_rows(h, self.final_linear.weight, self.final_linear.bias, wgrad_row_scale)
         return ops.layout(out, "tnc_nct")                                 # [T,N,O] -> [N,O,T]
 
+    def forward_stages(self, input, wgrad_row_scale=None):
+        """forward() as a generator that yields after every layer (None) and finally the output: lets a trainer queue
+        two independent networks layer by layer on two HIP streams (trainer_AAS: discriminator beside acoustic model)."""
+        rs = wgrad_row_scale
+        h = ops.layout(input, "nct_tnc")
+        h = ops.linear_rows(h, self.first_linear.weight, self.first_linear.bias, rs)
+        yield None
+        for l in range(1, self.L + 1):
+            h = getattr(self, "rnn%d" % l)(h, residual=True, wgrad_row_scale=rs)
+            yield None
+        out = ops.linear_rows(h, self.final_linear.weight, self.final_linear.bias, rs)
+        yield ops.layout(out, "tnc_nct")
+
     def forward_paired(self, input, paired):
         return self.forward(torch.cat((input, paired), dim=1))
 
@@ -263,16 +276,27 @@ class DeepSpeech(nn.Module):
         return t
 
     def forward(self, x):  # [N,nFreq,T] -> [N,T',C]
+        out = None
+        for out in self.forward_stages(x):
+            pass
+        return out
+
+    def forward_stages(self, x):
+        """forward() as a generator: yields None after the convolutional front-end and after every recurrent layer,
+        finally the output [N,T',C] (see stackedBRNN.forward_stages)."""
         h = ops.layout(x, "nct_ntc")                                     # channels-last [N,T,F]
         for i in range(0, len(self.conv), 3):
             cv, bn, act = self.conv[i], self.conv[i + 1], self.conv[i + 2]
             h = ops.conv1d_cl(h, cv.weight, cv.bias, cv.stride)
             h = bn(h, slope=float(act.negative_slope))
         h = ops.layout(h, "swap01")                                      # [N,T',M] -> [T',N,M]
-        h = self.rnns(h)
+        yield None
+        for layer in self.rnns:
+            h = layer(h)
+            yield None
         h = self.fc(h)                                                   # [T',N,C]
         h = h.transpose(0, 1)
-        return self.inference_softmax(h)
+        yield self.inference_softmax(h)
 
     # ---- (de)serialisation, same package format as model.py:337-410 ---------------------------
     @classmethod

@@ -200,10 +200,20 @@ class Trainer(object):
             Nn = leaf.size(0)
             overlap = self._overlap_asr()
             acoustic = None
+            same_len = tuple(cl_inputs.shape[1:]) == tuple(leaf.shape[1:])
+            interleave = same_len and not log_norms and self._interleave_ok()
             if overlap:  # two chains of persistent launches side by side, half the chip each
                 ops.set_rnn_cu_limit(ops.device_cus() // 2)
-                acoustic = self._acoustic_branch(enhanced, targets, sizes, target_sizes, N_glob, ctc_meta)
-            if tuple(cl_inputs.shape[1:]) == tuple(leaf.shape[1:]):
+                if not interleave:
+                    acoustic = self._acoustic_branch(enhanced, targets, sizes, target_sizes, N_glob, ctc_meta)
+            if interleave:
+                rs = torch.empty(Nn + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
+                rs[:Nn] = -float(self.kt)
+                rs[Nn:] = 1.0
+                l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, N_glob, ctc_meta, targets, sizes,
+                                                                                target_sizes, mask=mask, cl_mask=cl_mask)
+                acoustic = (prob, l_CTC, leaf_a)
+            elif same_len:
                 # D(enhanced) and D(clean) share ONE batched pass (rows are independent: D has no batch
                 # statistics).  The D-step gradients of the enhanced half are (-kt) x its G-step parameter
                 # gradients (:152-160), applied as per-utterance weights on the weight-gradient products only,
@@ -295,19 +305,24 @@ class Trainer(object):
         leaf = enhanced.detach().requires_grad_(True)
         overlap = self._overlap_asr()
         acoustic = None
-        if overlap:  # two chains of persistent launches side by side, half the chip each
-            ops.set_rnn_cu_limit(ops.device_cus() // 2)
-            acoustic = self._acoustic_branch(enhanced, None, None, None, N, ctc_meta)
         rs = torch.empty(N + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
         rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
         rs[N:] = 1.0
-        ae = self.D(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
-        l_adv_ny_G = ops.l1_sum(ae[:N], leaf) * (c.w_adversarial / nv_ny)
-        l_adv_cl = ops.l1_sum(ae[N:], cl_inputs) * (c.w_adversarial / nv_cl)
-        (l_adv_ny_G + l_adv_cl).backward()
-        if acoustic is None:
-            acoustic = self._acoustic_branch(enhanced, None, None, None, N, ctc_meta)
-        prob, l_CTC, leaf_a = acoustic
+        if overlap:  # two chains of persistent launches side by side, half the chip each
+            ops.set_rnn_cu_limit(ops.device_cus() // 2)
+        if self._interleave_ok():
+            l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, N, ctc_meta, None, None, None,
+                                                                            nv_ny=nv_ny, nv_cl=nv_cl)
+        else:
+            if overlap:
+                acoustic = self._acoustic_branch(enhanced, None, None, None, N, ctc_meta)
+            ae = self.D(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
+            l_adv_ny_G = ops.l1_sum(ae[:N], leaf) * (c.w_adversarial / nv_ny)
+            l_adv_cl = ops.l1_sum(ae[N:], cl_inputs) * (c.w_adversarial / nv_cl)
+            (l_adv_ny_G + l_adv_cl).backward()
+            if acoustic is None:
+                acoustic = self._acoustic_branch(enhanced, None, None, None, N, ctc_meta)
+            prob, l_CTC, leaf_a = acoustic
         torch.cuda.current_stream().wait_stream(self._side)
         # E's BPTT launches are capped too: the CUs they leave free run E's weight-gradient GEMMs (side stream), which would
         # otherwise wait for each fully-resident 512-thread launch to retire
@@ -411,6 +426,62 @@ class Trainer(object):
         self.kt = kt
         return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, kt=self.kt,
                     conv_measure=l_adv_cl_data + abs(g_d_balance), g_adv=None, g_ctc_adv=None, enhanced=g["enh"], prob=g["prob"])
+
+    def _interleaved_DA(self, enhanced, leaf, cl_inputs, rs, N_glob, ctc_meta, targets, sizes, target_sizes, nv_ny=None, nv_cl=None,
+                        mask=None, cl_mask=None):
+        """Discriminator pass and acoustic pass QUEUED layer by layer in alternation on two streams, one combined backward.
+
+        The two chains are independent, but the device only overlaps what the host has queued: queueing one whole chain
+        (forward and backward, ~150 launches) before the other - in Python or as consecutive hipGraph nodes, which are
+        enqueued in creation order at ~30 us apiece - delays the second chain by 5-6 ms (rocprofv3 timeline).  So both
+        forwards are advanced one layer at a time (`forward_stages`), and ONE `torch.autograd.backward` call over both
+        losses lets the engine pop backward nodes in reverse creation order, i.e. alternating between the chains, each
+        on the stream its forward ran on.  Returns (l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a)."""
+        c = self.config
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side = self._side_stream
+        side.wait_stream(main)
+        Nn = leaf.size(0)
+        leaf_a = enhanced.detach().requires_grad_(True)
+        enhanced.record_stream(side)
+        gD = self.D.forward_stages(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
+        gA = self.ASR.forward_stages(leaf_a)
+        ae = out_a = None
+        while ae is None or out_a is None:
+            if ae is None:
+                ae = next(gD)
+            if out_a is None:
+                with torch.cuda.stream(side):
+                    out_a = next(gA)
+        if mask is not None:   # eager path: masked-L1 modules (host-side n_valid)
+            l_adv_ny_G, _ = self.diffLoss(ae[:Nn], leaf, mask)
+            l_adv_cl, _ = self.diffLoss(ae[Nn:], cl_inputs, cl_mask)
+            l_adv_ny_G = l_adv_ny_G * c.w_adversarial
+            l_adv_cl = c.w_adversarial * l_adv_cl
+        else:
+            l_adv_ny_G = ops.l1_sum(ae[:Nn], leaf) * (c.w_adversarial / nv_ny)
+            l_adv_cl = ops.l1_sum(ae[Nn:], cl_inputs) * (c.w_adversarial / nv_cl)
+        with torch.cuda.stream(side):
+            prob = out_a.transpose(0, 1)
+            if targets is None:
+                l_CTC = c.w_acoustic * ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) / N_glob
+            else:
+                l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / N_glob
+        side.wait_stream(main)   # the combined backward is issued from the main stream's context
+        torch.autograd.backward([l_adv_ny_G + l_adv_cl, l_CTC])
+        return l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a
+
+    def _interleave_ok(self):
+        c = self.config
+        exact_a = getattr(c, "asr_exact_fp32", None)
+        if exact_a is None:
+            exact_a = os.environ.get("AAS_ASR_EXACT", "0") == "1"
+        # (not under hipGraph capture: replayed with the nodes of the two chains created alternately, the graph executor
+        #  ran the chains strictly one after the other - 26.4 ms vs 21.7 with one chain captured after the other)
+        return (self._overlap_asr() and not exact_a and os.environ.get("AAS_INTERLEAVE", "1") == "1"
+                and not torch.cuda.is_current_stream_capturing())
 
     @staticmethod
     def _overlap_asr():
