@@ -120,6 +120,52 @@ def test_graph_replay_matches_eager_config2(gpu):
     assert np.allclose(res["eager"], res["graph"], rtol=1e-4), (res["eager"], res["graph"])
 
 
+def test_chain_schedules_agree_config2(gpu, monkeypatch):
+    """The three ways of queueing the discriminator and acoustic passes - one after the other on one stream, on two
+    streams one chain after the other, and layer by layer in alternation with one combined backward - are the same
+    computation: identical scalars, enhanced output and parameters over 2 steps at BASELINE config-2 sizes."""
+    from aas_enhancement_amd import prng
+    from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
+    from aas_enhancement_amd.trainer_AAS import Trainer
+    N, F, T, H, HA, M, L = 30, 80, 200, 500, 1000, 128, 20
+    res = {}
+    for mode, env in (("serial", {"AAS_OVERLAP_ASR": "0"}), ("two_streams", {"AAS_OVERLAP_ASR": "1", "AAS_INTERLEAVE": "0"}),
+                      ("alternating", {"AAS_OVERLAP_ASR": "1", "AAS_INTERLEAVE": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        G, D = stackedBRNN(I=F, H=H, L=4), stackedBRNN(I=F, H=H, L=4)
+        A = DeepSpeech(nn.GRU, LABELS, HA, 5, True, 11, 2, M, 2, nFreq=F)
+        for m, s, cs in ((G, 9001, None), (D, 9002, None), (A, 9003, 0.1)):
+            load_sd(m, {k: torch.from_numpy(v) for k, v in prng.fill_state_dict(m.state_dict(), s, conv_std=cs).items()}, strict=False)
+        tr = Trainer(cfg(nFeat=F, rnn_size=H, allow_ASR_update_iter=10 ** 9), None, models=(G, D, A))
+        out = []
+        for it in range(2):
+            ny = (torch.from_numpy(prng.uniform(123 + it, (N, F, T), 0.0, 6.0)), torch.from_numpy(prng.randint(125 + it, (N * L,), 1, 28).astype(np.int32)),
+                  torch.ones(N), torch.full((N,), L, dtype=torch.int32), torch.zeros(N, 1, T, dtype=torch.uint8))
+            cl = (torch.from_numpy(prng.uniform(124 + it, (N, F, T), 0.0, 6.0)), None, None, None, torch.zeros(N, 1, T, dtype=torch.uint8))
+            r = tr.train_step(ny, cl, it, log_norms=False)
+            out.append([r[k] for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt")] + [float(r["enhanced"].detach().double().abs().sum()), float(r["prob"].detach().double().abs().sum())])
+        torch.cuda.synchronize()
+        from aas_enhancement_amd import ops
+        assert not ops.rnn_timeout_flag()
+        out.append([float(sum(p.double().abs().sum() for p in m.parameters())) for m in (G, D)] + [0.0] * 4)
+        res[mode] = np.asarray(out)
+    assert np.allclose(res["serial"], res["two_streams"], rtol=2e-5), (res["serial"], res["two_streams"])
+    assert np.allclose(res["serial"], res["alternating"], rtol=2e-5), (res["serial"], res["alternating"])
+
+
+def test_forward_stages_equal_forward(gpu):
+    """stackedBRNN / DeepSpeech.forward_stages (the layer-by-layer generators the trainer alternates) give forward()."""
+    from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
+    torch.manual_seed(0)
+    D = stackedBRNN(I=12, H=24, L=3).cuda()
+    A = DeepSpeech(nn.GRU, LABELS, 16, 2, True, 11, 2, 8, 2, nFreq=12).cuda()
+    x = torch.rand(3, 12, 50, device="cuda")
+    for m in (D, A):
+        *_, last = m.forward_stages(x)
+        assert torch.equal(last, m(x))
+
+
 def test_aas_grads_tiny_golden(gpu):
     """F1 iteration 0: every parameter gradient of E, D and A at optimiser-step time (as-executed schedule)."""
     from aas_enhancement_amd.ctc import CTCLoss
