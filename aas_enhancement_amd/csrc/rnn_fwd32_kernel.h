@@ -131,10 +131,8 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
             u32x4 ah[KS], al[KS];
             unsigned spins = 0;
             unsigned long long t0 = 0;
-            bool fresh = (p.flags & 32) != 0;
+            bool fresh = !(p.flags & 32);   // sc1 from the first attempt (see rnn_split_kernel.h); debug flag 32: plain first
             while (true) {
-                // first attempt with plain loads (workgroups of an XCD share the rows through its L2: a stale line can only
-                // show POISON, never wrong data), retries with sc1
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const unsigned off = (kb + ks * 32 + q * 8 < Hp) ? roff + (unsigned)(ks * 128) : OOB;

@@ -178,11 +178,11 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             constexpr int NCH = KS / CH;
             constexpr int DEPTH = NCH >= 3 ? 2 : (NCH >= 2 ? 1 : 0);
             u32x4 ahb[DEPTH + 1][CH][MT], alb[DEPTH + 1][CH][MT];
-            // First attempt: PLAIN (cacheable) loads, so the workgroups of one XCD that stream the same rows share
-            // them through that XCD's L2 instead of each fetching them from the Infinity Cache.  This is safe
-            // because the data is its own flag: every word goes poison -> data exactly once per launch, so a stale
-            // L1/L2 copy can only show POISON in a word, never wrong data; a fragment that still shows poison is
-            // re-fetched with sc1 loads (L1/L2-bypassing, always fresh).
+            // Every exchange load is an sc1 load (MI355X_MICROARCH.md "Valid forms": all loads of the handed-off bytes sc1).
+            // A cacheable (plain) first attempt - so that the workgroups of one XCD share the rows through its L2 - measured no
+            // faster, and its safety rests on "a stale L2 line can only show POISON", which does not cover lines that
+            // survive from the previous launch on this buffer (the previous layer's h at the same positions).  Debug flag 32
+            // (also a GEMM ablation bit) re-enables the plain attempt for experiments.
             auto issue_aux = [&](int c, u32x4 (&dh)[CH][MT], u32x4 (&dl)[CH][MT], auto AUX) {
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                 }
             };
             auto issue = [&](int c, u32x4 (&dh)[CH][MT], u32x4 (&dl)[CH][MT]) {
-                if (p.flags & 32) issue_aux(c, dh, dl, std::integral_constant<int, 16>{});
-                else issue_aux(c, dh, dl, std::integral_constant<int, 0>{});
+                if (p.flags & 32) issue_aux(c, dh, dl, std::integral_constant<int, 0>{});   // experiment only
+                else issue_aux(c, dh, dl, std::integral_constant<int, 16>{});
             };
             auto issue_fresh = [&](int c, u32x4 (&dh)[CH][MT], u32x4 (&dl)[CH][MT]) {
                 issue_aux(c, dh, dl, std::integral_constant<int, 16>{});

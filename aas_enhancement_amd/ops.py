@@ -371,7 +371,6 @@ def linear_rows(x, W, b=None, rs=None):
 
 # --------------------------------------------------------------------------------------- RNN layers
 PLANES_PRE = [os.environ.get("AAS_PLANES_PRE", "1") == "1"]   # input projections of the recurrent layers on the plane GEMM
-_frozen_planes = {}
 
 
 def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
@@ -388,9 +387,13 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
         # split once), then one LDS-DMA-staged launch for both directions: pre[tn, d*GH + g]
         GH = G * H
         xa = split_planes(x2, T * N, I)
+        # frozen weights are split once: the planes hang on the weight tensor itself and are valid while its storage
+        # address and version counter (bumped by every in-place torch write, e.g. load_state_dict) are unchanged.  (Not a
+        # table keyed by address: addresses are reused by other tensors.)
         frozen = not (w_ih.requires_grad or w_ih_r.requires_grad)
-        key = (w_ih.data_ptr(), w_ih_r.data_ptr(), GH, I)
-        wb = _frozen_planes.get(key) if frozen else None
+        sig = (w_ih.data_ptr(), w_ih._version, w_ih_r.data_ptr(), w_ih_r._version, GH, I)
+        ent = getattr(w_ih, "_aas_planes", None) if frozen else None
+        wb = ent[1] if ent is not None and ent[0] == sig else None
         if wb is None:
             Kp = _kp(I)
             buf = torch.empty((2 * GH, 2 * Kp), device=dev, dtype=torch.bfloat16)
@@ -398,7 +401,10 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
             check(lib().aas_split_planes(stream(), ptr(w_ih_r), I, GH, I, Kp, buf.data_ptr() + GH * Kp * 4, None, 0), "aas_split_planes")
             wb = Planes(buf, 2 * GH, I, Kp)
             if frozen and not torch.cuda.is_current_stream_capturing():
-                _frozen_planes[key] = wb
+                try:
+                    w_ih._aas_planes = (sig, wb)
+                except Exception:  # noqa: BLE001  (a tensor type that takes no attributes: just do not cache)
+                    pass
         gemm_planes(T * N, 2 * GH, xa.Kp, xa, wb, pre, 2 * GH)
     elif dw > 0 and dw % 4 == 0:
         # both directions in ONE batched launch: same A, B strided by the distance between the two weight tensors
