@@ -284,6 +284,7 @@ class Trainer(object):
         g_d_balance = self.gamma * l_adv_cl_data - l_adv_ny_G_data
         self.kt += self.lb * g_d_balance
         self.kt = max(min(1, self.kt), 0)
+        self._kt_dev_live = False   # the device-resident copy (train_step_async / graph) is stale now
         conv_measure = l_adv_cl_data + abs(g_d_balance)
         return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, kt=self.kt,
                     conv_measure=conv_measure, g_adv=g_adv, g_ctc_adv=g_ctc_adv, enhanced=enhanced, prob=prob)
@@ -343,6 +344,54 @@ class Trainer(object):
         self._g_out[3:4].copy_(self._kt_dev)
         return enhanced, prob
 
+    def train_step_async(self, data_list, data_list_cl, iter):
+        """The fused iteration queued WITHOUT any host synchronisation: kt, the Adam bias corrections and the loss scalars
+        stay on the device (`_device_core`, the same launch sequence the graph path captures), the CTC metadata goes up
+        from pinned memory, and nothing is read back - so the host queues step i+1 while the GPU is still running step i
+        and the ~10 ms of Python launch overhead per step never leaves a stream dry at a step boundary.  Returns device
+        tensors; `read_scalars()` (one D2H copy) updates `self.kt` and returns the last step's losses - call it when a log
+        line needs them (the reference logs every `log_iter` iterations, trainer_AAS.py:196-215).  Falls back to
+        train_step when the configuration needs host decisions inside the step (data parallel, trainable A, ragged pair)."""
+        if self._opts is None:
+            self.make_optimizers()
+        c = self.config
+        asr_steps = self._opts[1] is not None
+        if self.dp.active or self.schedule != "fused" or asr_steps:
+            return self.train_step(data_list, data_list_cl, iter, log_norms=False)
+        inputs, targets, input_percentages, target_sizes, mask = self._prep(data_list)
+        cl_inputs, cl_mask = data_list_cl[0], data_list_cl[4]
+        if not cl_mask.is_cuda:
+            attach_n_valid(cl_mask)
+        nv = lambda m: getattr(m, "n_valid", None)
+        nv_ny, nv_cl = nv(mask), nv(cl_mask)
+        if nv_ny is None or nv_cl is None or tuple(cl_inputs.shape) != tuple(inputs.shape):
+            return self.train_step(data_list, data_list_cl, iter, log_norms=False)
+        dev = next(self.G.parameters()).device
+        cl_inputs = _get_variable_nograd(cl_inputs)
+        t_out = self.ASR.output_length(inputs.size(2))
+        sizes = input_percentages.clone().mul_(int(t_out)).int()
+        meta = ops.ctc_prepare(targets, sizes, target_sizes, "cpu")
+        meta = dict(meta, meta=meta["meta"].pin_memory().to(dev, non_blocking=True))
+        if getattr(self, "_kt_dev", None) is None:
+            self._kt_dev = torch.zeros(1, device=dev, dtype=torch.float64)
+            self._g_out = torch.zeros(4, device=dev, dtype=torch.float64)
+            self._graphs = {}
+            self._kt_dev.fill_(float(self.kt))
+        elif not getattr(self, "_kt_dev_live", False):
+            self._kt_dev.fill_(float(self.kt))   # another path advanced the host copy since
+        self._kt_dev_live = True
+        enhanced, prob = self._device_core(inputs, cl_inputs, nv_ny, nv_cl, meta)
+        self._async_n = inputs.size(0)
+        return dict(enhanced=enhanced, prob=prob, scalars=self._g_out)
+
+    def read_scalars(self):
+        """One D2H copy of (l_adv_ny_G, l_adv_cl, l_ctc, kt) of the last train_step_async; updates the host-side kt."""
+        l_adv_ny_G, l_adv_cl, l_ctc, kt = self._g_out.tolist()
+        self.kt = kt
+        self.ctc_tr_local.update(l_ctc, getattr(self, "_async_n", 1))
+        bal = self.gamma * l_adv_cl - l_adv_ny_G
+        return dict(l_adv_ny_G=l_adv_ny_G, l_adv_cl=l_adv_cl, l_ctc=l_ctc, kt=kt, conv_measure=l_adv_cl + abs(bal))
+
     def train_step_graph(self, data_list, data_list_cl, iter):
         """Graph-replayed fused iteration (single GPU, no gradient-norm logging).  Falls back to train_step when the
         configuration needs host decisions inside the step."""
@@ -372,6 +421,7 @@ class Trainer(object):
             self._g_out = torch.zeros(4, device=dev, dtype=torch.float64)
             self._graphs = {}
         self._kt_dev.fill_(float(self.kt))
+        self._kt_dev_live = False
         g = self._graphs.get(sig)
         if g is None:
             st = dict(inputs=torch.empty(inputs.shape, device=dev), cl=torch.empty(cl_inputs.shape, device=dev),

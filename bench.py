@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--profile-gemm", action="store_true", help="also bracket every GEMM launch with HIP events")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph of the step instead of eager launches (single GPU)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # the default; kept for older command lines
+    ap.add_argument("--sync-steps", action="store_true", help="read the loss scalars back to the host every step (Trainer.train_step) "
+                                                              "instead of leaving them on the device (Trainer.train_step_async)")
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps bracketed with HIP events for the roofline object")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -156,7 +158,16 @@ def main():
     # (~35 us apiece, 12.6 ms per replay with all kernels stubbed out vs 9.8 ms of host time for the eager step) and ran
     # the two branches one after the other, so the replay is slower (21.7 vs 20.6 ms) - `--graph` still selects it.
     use_graph = a.graph and world == 1
-    step = (lambda it: tr.train_step_graph(ny, cl, it)) if use_graph else (lambda it: tr.train_step(ny, cl, it, log_norms=False))
+    use_async = world == 1 and not use_graph and not a.sync_steps
+    if use_graph:
+        step = lambda it: tr.train_step_graph(ny, cl, it)
+    elif use_async:
+        # no host read-back inside the step (kt and the losses stay on the device; the reference reads them only on logging
+        # iterations): the host queues step i+1 while the GPU runs step i.  The timed region still ends with a barrier +
+        # device synchronisation, and the scalars of the last step are read after it.
+        step = lambda it: tr.train_step_async(ny, cl, it)
+    else:
+        step = lambda it: tr.train_step(ny, cl, it, log_norms=False)
     for it in range(a.warmup):
         step(it)
     barrier()
@@ -165,6 +176,8 @@ def main():
         r = step(a.warmup + it)
     barrier()
     dt = time.perf_counter() - t0
+    if use_async:
+        r = tr.read_scalars()
     # per-launch HIP events for the roofline object: the same step is run (eagerly) right after the timed region with
     # every recurrent launch bracketed by events on its launch stream, so the timed steps carry no instrumentation
     psteps = max(0, a.profile_steps)
@@ -209,7 +222,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "trainer_AAS step, BASELINE configs[1]: E=D=4x500 BiLSTM, frozen A=2xconv1d+5x1000 BiGRU+CTC, "
-                                   "N=30/GPU, T=200, F=80, L=20 labels/utt, schedule=%s, %s" % (a.schedule, "hipGraph replay" if use_graph else "eager launches"),
+                                   "N=30/GPU, T=200, F=80, L=20 labels/utt, schedule=%s, %s" % (a.schedule, "hipGraph replay" if use_graph else ("eager launches, no per-step host read-back" if use_async else "eager launches")),
                        "global_batch": world * N_PER, "frames_per_utt": T, "parallelism": "dp%d" % world,
                        "last_losses": {k: r[k] for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt")}},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -154,6 +154,27 @@ def test_chain_schedules_agree_config2(gpu, monkeypatch):
     assert np.allclose(res["serial"], res["alternating"], rtol=2e-5), (res["serial"], res["alternating"])
 
 
+def test_async_steps_match_synchronous_steps(gpu):
+    """Trainer.train_step_async (kt / losses device-resident, no read-back) == Trainer.train_step over 3 steps (tiny shapes)."""
+    from aas_enhancement_amd.trainer_AAS import Trainer
+    z = load("f1_aas_tiny.npz")
+    res = {}
+    for mode in ("sync", "async"):
+        tr = Trainer(cfg(lr=float(z["cfg_lr"]), schedule="fused", allow_ASR_update_iter=10 ** 9), None, models=build_tiny(z))
+        tr.kt = float(z["kt0"])
+        out = []
+        for it in range(3):
+            ny, cl = batch_from(z, "it%d.ny." % it), batch_from(z, "it%d.cl." % it)
+            if mode == "sync":
+                r = tr.train_step(ny, cl, it, log_norms=False)
+            else:
+                tr.train_step_async(ny, cl, it)
+                r = tr.read_scalars()
+            out.append([r[k] for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt")])
+        res[mode] = np.asarray(out)
+    assert np.allclose(res["sync"], res["async"], rtol=1e-5, atol=1e-9), (res["sync"], res["async"])
+
+
 def test_forward_stages_equal_forward(gpu):
     """stackedBRNN / DeepSpeech.forward_stages (the layer-by-layer generators the trainer alternates) give forward()."""
     from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
