@@ -109,14 +109,19 @@ int aas_sqsum_f32(aasStream_t stream, const float* x, int64_t n, double* acc);
  *   hout  [2,T,N,H]   h_t per direction (time index = position in the sequence, both directions)
  *   gact  [2,T,N,H,4]  post-nonlinearity gates i,f,g,o per unit (saved for backward); cst [2,T,N,H] cell states
  *   sync  >= aas_rnn_sync_bytes() bytes of zero-initialisable device scratch (zeroed by the call)
- * Persistent kernel: one workgroup per (unit slice, batch group, direction); W_hh slices stay
- * in registers for all T steps; h_t is exchanged through L2 with write-through stores and an
- * agent-scope arrival counter per (batch group, direction).
+ * Persistent kernel: one workgroup per (unit slice, batch group, direction); W_hh slices stay in registers for all T
+ * steps.  `sync` holds the arrival counters of the exact-fp32 kernels (re-zeroed per launch) and, at word 1024, a
+ * sticky timeout flag that every bounded spin of every kernel can raise.  With aas_set_precision(1) and an exchange
+ * buffer, the forward launches all-gather h_t through poison-tagged 128-byte hi|lo lines (16- or 32-unit slices per
+ * workgroup, chosen from the CU budget) and the backward launches run BPTT as a per-step reduce-scatter of K-split
+ * partial dh through a tagged two-slot ring (csrc/rnn_bwd_rs_kernel.h); aas_set_rnn_cu_limit() bounds the grid of
+ * the launches queued after it.
  */
 size_t aas_rnn_sync_bytes(void);
-/* bytes of the split-bf16 exchange scratch `xchg` (gates = 4 LSTM / 3 GRU); pass xchg = NULL to force the
- * exact-fp32 kernels.  With aas_set_precision(1) and xchg != NULL the exchanged vector is published as bf16
- * hi/lo pairs and the recurrent product runs as hi*hi + lo*hi + hi*lo on bf16 MFMA (fp32 accumulate). */
+/* bytes of the split-bf16 exchange scratch `xchg` (gates = 4 LSTM / 3 GRU; one buffer per stream that runs recurrent
+ * launches); pass xchg = NULL to force the exact-fp32 kernels.  With aas_set_precision(1) and xchg != NULL the
+ * exchanged values are bf16 hi/lo pairs (forward) or tagged fp32 partial sums (BPTT) and the recurrent products run
+ * as hi*hi + lo*hi + hi*lo on bf16 MFMA (fp32 accumulate). */
 size_t aas_rnn_xchg_bytes(int T, int N, int H, int gates);
 int aas_lstm_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh,
                  const float* w_hh_rev, float* hout, float* gact, float* cst, void* sync, void* xchg);
