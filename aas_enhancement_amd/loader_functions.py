@@ -32,56 +32,52 @@ class FeatDataset(Dataset):
         return self.size
 
 
-def _sorted(batch):
+def _pad_batch(feats, pin=False):
+    """Zero-pad a list of [F, T_i] features (already in batch order) to [N, F, T_max].
+    -> (padded, lengths[N] int64, mask[N,1,T_max] u8 with 1 = padding); mask.n_valid = number of real frames."""
+    lengths = torch.tensor([f.size(1) for f in feats], dtype=torch.int64)
+    t_max = int(lengths.max())
+    padded = torch.zeros(len(feats), feats[0].size(0), t_max, pin_memory=pin)
+    for row, f in zip(padded, feats):
+        row[:, :f.size(1)] = f
+    mask = (torch.arange(t_max)[None, :] >= lengths[:, None]).to(torch.uint8).unsqueeze(1)
+    mask.n_valid = int(lengths.sum())
+    return padded, lengths, mask
+
+
+def _order(batch):
+    """Stable sort by length, longest first (the order `sorted(..., reverse=True)` gives, loader_functions.py:51)."""
     return sorted(batch, key=lambda sample: sample[0].size(1), reverse=True)
 
 
+def _flat_targets(transcripts):
+    sizes = torch.tensor([len(x) for x in transcripts], dtype=torch.int32)
+    flat = torch.tensor([c for x in transcripts for c in x], dtype=torch.int32)
+    return flat, sizes
+
+
 def _collate_fn(batch):
-    """-> (inputs[N,F,T], targets[sum L] i32, input_percentages[N] f32, target_sizes[N] i32, mask[N,1,T] u8)"""
-    batch = _sorted(batch)
-    freq_size, max_seqlength, n = batch[0][0].size(0), batch[0][0].size(1), len(batch)
-    inputs = torch.zeros(n, freq_size, max_seqlength)
-    input_percentages = torch.FloatTensor(n)
-    target_sizes = torch.IntTensor(n)
-    targets = []
-    mask = torch.zeros(n, 1, max_seqlength, dtype=torch.uint8)
-    n_valid = 0
-    for x in range(n):
-        tensor, target = batch[x][0], batch[x][1]
-        seq_length = tensor.size(1)
-        inputs[x].narrow(1, 0, seq_length).copy_(tensor)
-        input_percentages[x] = seq_length / float(max_seqlength)
-        target_sizes[x] = len(target)
-        targets.extend(target)
-        mask[x, :, seq_length:] = 1
-        n_valid += seq_length
-    mask.n_valid = n_valid
-    return inputs, torch.IntTensor(targets), input_percentages, target_sizes, mask
+    """-> (inputs[N,F,T], targets[sum L] i32, input_percentages[N] f32, target_sizes[N] i32, mask[N,1,T] u8)
+    (loader_functions.py:47-73)"""
+    batch = _order(batch)
+    inputs, lengths, mask = _pad_batch([s[0] for s in batch], pin=PIN_MEMORY[0])
+    targets, target_sizes = _flat_targets([s[1] for s in batch])
+    return inputs, targets, (lengths.double() / float(inputs.size(2))).float(), target_sizes, mask
 
 
 def _collate_fn_paired(batch):
-    """-> (inputs, outputs(clean), mask, targets, input_percentages, target_sizes)"""
-    batch = _sorted(batch)
-    freq_size, max_seqlength, n = batch[0][0].size(0), batch[0][0].size(1), len(batch)
-    inputs = torch.zeros(n, freq_size, max_seqlength)
-    outputs = torch.zeros(n, freq_size, max_seqlength)
-    mask = torch.zeros(n, 1, max_seqlength, dtype=torch.uint8)
-    input_percentages = torch.FloatTensor(n)
-    target_sizes = torch.IntTensor(n)
-    targets = []
-    n_valid = 0
-    for x in range(n):
-        tensor, txt, target = batch[x][0], batch[x][1], batch[x][2]
-        seq_length = tensor.size(1)
-        inputs[x].narrow(1, 0, seq_length).copy_(tensor)
-        outputs[x].narrow(1, 0, seq_length).copy_(target)
-        mask[x, :, seq_length:] = 1
-        input_percentages[x] = seq_length / float(max_seqlength)
-        target_sizes[x] = len(txt)
-        targets.extend(txt)
-        n_valid += seq_length
-    mask.n_valid = n_valid
-    return inputs, outputs, mask, torch.IntTensor(targets), input_percentages, target_sizes
+    """-> (inputs, outputs(clean), mask, targets, input_percentages, target_sizes)  (loader_functions.py:75-105)"""
+    batch = _order(batch)
+    inputs, lengths, mask = _pad_batch([s[0] for s in batch], pin=PIN_MEMORY[0])
+    outputs = torch.zeros_like(inputs, pin_memory=PIN_MEMORY[0])
+    for row, s in zip(outputs, batch):
+        row[:, :s[0].size(1)] = s[2][:, :s[0].size(1)]
+    targets, target_sizes = _flat_targets([s[1] for s in batch])
+    return inputs, outputs, mask, targets, (lengths.double() / float(inputs.size(2))).float(), target_sizes
+
+
+# collate straight into pinned host memory (set by data_loader.DataLoader(pin_memory=True) in the loading process)
+PIN_MEMORY = [False]
 
 
 class FeatLoader(DataLoader):

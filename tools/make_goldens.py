@@ -386,14 +386,211 @@ def f5_fsegan_am():
     print("F5", {k: v for k, v in out.items() if np.ndim(v) == 0})
 
 
+def f6_fsegan_config4():
+    """F6: BASELINE config 4 - FSEGAN at size (N=30,T=200,F=80; E 4x500, D I=160 O=80 4x500, w_adversarial 0.01),
+    intended step (DCE back-propagated, trainer_FSEGAN.py:128-182 with the fix list of SURVEY 0.13), 2 iterations:
+    scalars + 256 sampled enhanced elements + sampled gradients."""
+    Fdim, H, N, T = 80, 500, 30, 200
+    G = REF.stackedBRNN(I=Fdim, O=Fdim, H=H, L=4)
+    D = REF.stackedBRNN(I=2 * Fdim, O=Fdim, H=H, L=4)
+    load_weights(G, 9101)
+    load_weights(D, 9102)
+    lr, w, kt = 1e-5, 0.01, 0.1
+    og, od = adam(G, lr), adam(D, lr)
+    diff = REF.L1Loss_mask()
+    out = dict(weight_seed_G=9101, weight_seed_D=9102, lr=lr, w_adversarial=w, kt0=kt, N=N, F=Fdim, T=T, H=H,
+               mixture_seed0=9110, clean_seed0=9120)
+    for it in range(2):
+        mixture = t(prng.uniform(9110 + it, (N, Fdim, T), 0.0, 6.0))
+        cleans = t(prng.uniform(9120 + it, (N, Fdim, T), 0.0, 6.0))
+        mask = torch.zeros(N, 1, T, dtype=torch.bool)
+        G.zero_grad(); D.zero_grad()
+        enhanced = G(mixture)
+        enhanced_D = enhanced.detach()
+        ae = D.forward_paired(enhanced, mixture)
+        l_g, _ = diff(ae, enhanced, mask)
+        l_g = l_g * w
+        l_g_data = l_g.item()
+        l_g.backward(retain_graph=True)
+        D.zero_grad()
+        ae_d = D.forward_paired(enhanced_D, mixture)
+        l_d, _ = diff(ae_d, enhanced_D, mask)
+        (l_d * (-kt) * w).backward()
+        dce, _ = diff(enhanced, cleans, mask)
+        dce.backward()
+        ae_cl = D.forward_paired(cleans, mixture)
+        l_cl, _ = diff(ae_cl, cleans, mask)
+        l_cl = w * l_cl
+        l_cl.backward()
+        l_cl_data = l_cl.item()
+        gn = gnorm(G)
+        gd = gnorm(D)
+        if it == 0:
+            for nm, m, keys in (("G", G, ("rnn2.rnn.weight_hh_l0_reverse", "first_linear.weight")),
+                                ("D", D, ("first_linear.weight", "rnn1.rnn.weight_ih_l0", "final_linear.bias"))):
+                gr = dict(m.named_parameters())
+                for k in keys:
+                    g = gr[k].grad.detach().numpy()
+                    ig = sample_idx(61, g.shape, min(64, g.size))
+                    out["it0.gradsample_idx.%s.%s" % (nm, k)] = ig
+                    out["it0.gradsample.%s.%s" % (nm, k)] = g.reshape(-1)[ig]
+                    out["it0.gradnorm.%s.%s" % (nm, k)] = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        og.step(); od.step()
+        bal = 0.5 * l_cl_data - l_g_data
+        kt = max(min(1, kt + 0.001 * bal), 0)
+        p = "it%d." % it
+        enh = enhanced.detach().numpy()
+        ie = sample_idx(71 + it, enh.shape, 256)
+        out.update({p + "l_adv_ny_G": l_g_data, p + "l_adv_cl": l_cl_data, p + "dce": dce.item(), p + "kt": kt,
+                    p + "g_norm": gn, p + "d_norm": gd, p + "enh_idx": ie, p + "enh_samples": enh.reshape(-1)[ie],
+                    p + "enh_sum": float(enh.astype(np.float64).sum())})
+        print("F6 it", it, {k: out[p + k] for k in ("l_adv_ny_G", "l_adv_cl", "dce", "kt", "g_norm", "d_norm")}, flush=True)
+    np.savez_compressed(os.path.join(OUT, "f6_fsegan_config4.npz"), **out)
+
+
+def f7_am_config5():
+    """F7: BASELINE config 5 per-GPU step - AM_training/train.py:297-349 at size (N=30,T=200,F=80; A = 2xconv1d(128,k11)
+    + 5x1000 BiGRU + fc, plain Adam lr 1e-4), 2 iterations: loss, 256 logit samples, gradient norms + samples."""
+    Fdim, HA, M, N, T, L = 80, 1000, 128, 30, 200, 20
+    A = REF.DeepSpeech(rnn_type=nn.GRU, labels=LABELS, rnn_hidden_size=HA, rnn_layers=5, kernel_sz=11, stride=2,
+                       map=M, cnn_layers=2, nFreq=Fdim)
+    load_weights(A, 9203, conv_std=0.1)
+    lr = 1e-4
+    opt = torch.optim.Adam(A.parameters(), lr=lr)
+    out = dict(weight_seed=9203, lr=lr, N=N, F=Fdim, T=T, HA=HA, M=M, L=L, input_seed0=9210, label_seed0=9220)
+    for it in range(2):
+        x = t(prng.uniform(9210 + it, (N, Fdim, T), 0.0, 6.0))
+        targets = t(prng.randint(9220 + it, (N * L,), 1, 28).astype(np.int32))
+        target_sizes = torch.full((N,), L, dtype=torch.int32)
+        o = A(x).transpose(0, 1)
+        sizes = torch.ones(N).mul_(int(o.size(0))).int()
+        loss = ctc_sum(o, targets, sizes, target_sizes) / N
+        opt.zero_grad()
+        loss.backward()
+        p = "it%d." % it
+        if it == 0:
+            gr = dict(A.named_parameters())
+            tot = 0.0
+            for k, v in gr.items():
+                tot += float((v.grad.double() ** 2).sum())
+            out["it0.gradnorm_total"] = float(np.sqrt(tot))
+            for k in ("conv.0.weight", "conv.3.weight", "rnns.0.rnn.weight_ih_l0", "rnns.2.rnn.weight_hh_l0_reverse",
+                      "rnns.4.batch_norm.module.weight", "fc.0.module.1.weight"):
+                g = gr[k].grad.detach().numpy()
+                ig = sample_idx(81, g.shape, 64)
+                out["it0.gradsample_idx." + k] = ig
+                out["it0.gradsample." + k] = g.reshape(-1)[ig]
+                out["it0.gradnorm." + k] = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        opt.step()
+        lg = o.detach().numpy()
+        il = sample_idx(91 + it, lg.shape, 256)
+        out.update({p + "loss": loss.item(), p + "logit_idx": il, p + "logit_samples": lg.reshape(-1)[il],
+                    p + "logit_abs_sum": float(np.abs(lg.astype(np.float64)).sum())})
+        print("F7 it", it, loss.item(), flush=True)
+    np.savez_compressed(os.path.join(OUT, "f7_am_config5.npz"), **out)
+
+
+def f8_host_side():
+    """F8: host-side contract vectors from the reference's OWN loader_functions._collate_fn / _collate_fn_paired /
+    FeatDataset.parse_transcript (loader_functions.py:37-105) and AM_training/decoder.py GreedyDecoder
+    (convert_to_strings / process_string / wer / cer, :45-74,146-201).  decoder.py imports the third-party
+    `Levenshtein` C extension, absent from this image: a plain dynamic-programming edit distance is injected under that
+    module name for the import (the quantity is the textbook Levenshtein distance; nothing else of the package is used)."""
+    import tempfile
+    import types as _types
+    import loader_functions as LF   # the reference's
+    lev = _types.ModuleType("Levenshtein")
+
+    def distance(a, b):
+        prev = list(range(len(b) + 1))
+        for i, ca in enumerate(a, 1):
+            cur = [i]
+            for j, cb in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+            prev = cur
+        return prev[-1]
+    lev.distance = distance
+    sys.modules["Levenshtein"] = lev
+    sys.path.insert(0, "/root/reference/AM_training")
+    import decoder as RDEC          # the reference's AM_training/decoder.py
+    out = {}
+    # ---- collate: ragged batch given in NON-sorted order, with ties
+    lens, Fdim = [17, 31, 31, 9, 24], 6
+    feats = [prng.uniform(1300 + i, (Fdim, n), 0.0, 6.0) for i, n in enumerate(lens)]
+    paired = [prng.uniform(1400 + i, (Fdim, n), 0.0, 6.0) for i, n in enumerate(lens)]
+    labs = [prng.randint(1500 + i, (k,), 1, 28).tolist() for i, k in enumerate([3, 5, 0, 2, 4])]
+    for i in range(len(lens)):
+        out["collate.feat%d" % i] = feats[i]
+        out["collate.paired%d" % i] = paired[i]
+        out["collate.label%d" % i] = np.asarray(labs[i], np.int32)
+    r = LF._collate_fn([(t(feats[i]), labs[i]) for i in range(len(lens))])
+    for k, v in zip(("inputs", "targets", "pct", "target_sizes", "mask"), r):
+        out["collate.out." + k] = v.numpy()
+    r = LF._collate_fn_paired([(t(feats[i]), labs[i], t(paired[i])) for i in range(len(lens))])
+    for k, v in zip(("inputs", "outputs", "mask", "targets", "pct", "target_sizes"), r):
+        out["collate_paired.out." + k] = v.numpy()
+    # ---- parse_transcript: unknown characters AND index-0 characters are dropped (filter(None, ...))
+    texts = ["hello world", "it's  a_test\nwith newline", "UPPER lower 123", "", "_'_ z"]
+    with tempfile.TemporaryDirectory() as td:
+        man = os.path.join(td, "m.csv")
+        rows = []
+        for i, s in enumerate(texts):
+            tp = os.path.join(td, "t%d.txt" % i)
+            open(tp, "w", encoding="utf8").write(s)
+            rows.append("x.pt7,%s" % tp)
+        open(man, "w").write("\n".join(rows) + "\n")
+        ds = LF.FeatDataset(manifest=man, labels=LABELS)
+        for i in range(len(texts)):
+            out["transcript.text%d" % i] = np.frombuffer(texts[i].encode("utf8"), np.uint8).copy()
+            out["transcript.ids%d" % i] = np.asarray(ds.parse_transcript(rows[i].split(",")[1]), np.int32)
+    out["transcript.n"] = len(texts)
+    # ---- greedy decoding: argmax paths -> strings (collapse repeats, drop blanks), WER / CER edit distances
+    dec = RDEC.GreedyDecoder(LABELS)
+    Tn, Nn = 40, 6
+    paths = prng.randint(1600, (Nn, Tn), 0, 28).astype(np.int64)
+    paths[:, ::3] = 0                      # blanks
+    paths[1, 5:12] = 9                     # a long repeat
+    paths[2, :] = 0                        # all blank -> empty string
+    paths[3, 10:20] = 28                   # repeated spaces
+    sizes = np.asarray([40, 33, 40, 25, 1, 0], np.int32)
+    strings = dec.convert_to_strings([p.tolist() for p in paths], sizes.tolist(), remove_repetitions=True)
+    out["decode.paths"], out["decode.sizes"] = paths, sizes
+    for i, s in enumerate(strings):
+        out["decode.str%d" % i] = np.frombuffer(s[0].encode("utf8"), np.uint8).copy()
+    tgt = [prng.randint(1700 + i, (k,), 1, 28).tolist() for i, k in enumerate([9, 7, 0, 12, 3, 5])]
+    tstr = dec.convert_to_strings(tgt)
+    pairs = [(strings[i][0], tstr[i][0]) for i in range(Nn)] + [("the cat sat", "the cat sat on the mat"), ("a b c", "c b a"), ("", "x y")]
+    out["decode.npairs"] = len(pairs)
+    for i, (a, b) in enumerate(pairs):
+        out["decode.pair%d.a" % i] = np.frombuffer(a.encode("utf8"), np.uint8).copy()
+        out["decode.pair%d.b" % i] = np.frombuffer(b.encode("utf8"), np.uint8).copy()
+        out["decode.pair%d.wer" % i] = dec.wer(a, b)
+        out["decode.pair%d.cer" % i] = dec.cer(a, b)
+    for i, g in enumerate(tgt):
+        out["decode.target%d" % i] = np.asarray(g, np.int32)
+        out["decode.target_str%d" % i] = np.frombuffer(tstr[i][0].encode("utf8"), np.uint8).copy()
+    np.savez_compressed(os.path.join(OUT, "f8_host_side.npz"), **out)
+    print("F8 keys", len(out), [s[0] for s in strings])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip F3 (config 2, minutes of CPU)")
+    ap.add_argument("--only", default="", help="comma list of fixtures to (re)generate: f1,f2,f3,f4,f5,f6,f7,f8")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
+    if a.only:
+        table = dict(f1=f1_tiny, f2=f2_dce, f3=f3_config2, f4=f4_ops, f5=f5_fsegan_am, f6=f6_fsegan_config4,
+                     f7=f7_am_config5, f8=f8_host_side)
+        for k in a.only.split(","):
+            table[k]()
+        sys.exit(0)
     f1_tiny()
     f4_ops()
     f5_fsegan_am()
     f2_dce()
+    f8_host_side()
     if not a.skip_big:
         f3_config2()
+        f6_fsegan_config4()
+        f7_am_config5()
