@@ -24,6 +24,7 @@ SIGNATURES = {
     "aas_device_cus": [],
     "aas_set_debug_flags": [c_int],
     "aas_set_precision": [c_int],
+    "aas_set_rnn_launch_tag": [c_int],
     "aas_set_rnn_cu_limit": [c_int],
     "aas_gemm_f32": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                      c_int, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_i64],
@@ -47,14 +48,23 @@ SIGNATURES = {
     "aas_gru_bwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "aas_bn_fwd": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp],
     "aas_bn_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_vp],
+    "aas_bn_stats": [c_vp, c_vp, c_i64, c_int, c_vp],
+    "aas_bn_apply": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp],
+    "aas_bn_bwd_reduce": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_vp, c_vp],
+    "aas_bn_bwd_apply": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp],
+    "aas_bn_eval": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32],
+    "aas_softmax_rows": [c_vp, c_vp, c_vp, c_i64, c_int],
     "aas_col2im_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int],
     "aas_l1_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "aas_l1_bwd": [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_int],
     "aas_ctc_get_workspace_size": [c_vp, c_vp, c_int, c_int, c_int, ctypes.POINTER(c_sz)],
     "aas_compute_ctc_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int],
     "aas_ctc_loss_async": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_f32],
+    "aas_greedy_decode": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "aas_edit_distance": [c_vp, c_int, c_vp, c_int],
     "aas_adam_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_f32],
     "aas_adam_dev_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_int, c_f32],
+    "aas_lmfb320_fwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp],
     "aas_lmfb_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
 }
 _RESTYPES = {"aas_last_error": ctypes.c_char_p, "aas_rnn_sync_bytes": c_sz, "aas_rnn_xchg_bytes": c_sz}

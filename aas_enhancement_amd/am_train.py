@@ -1,25 +1,46 @@
-"""Acoustic-model (A) CTC pre-training step on the HIP path - the hot loop of the reference's
-AM_training/train.py:293-349 (BASELINE config 5): A(x) -> CTC / N -> Adam(lr) (plain Adam, not amsgrad, :246-247).
-Same batch tuple as the AAS trainer (`_collate_fn` order).  Data-parallel: the flat gradient buffer of A is
-SUM-all-reduced over RCCL with the loss normalised by the global batch size."""
+"""Acoustic-model (A) CTC pre-training on the HIP path - the reference's AM_training/train.py (BASELINE config 5):
+the step (:297-349: A(x) -> CTC / N -> plain Adam, inf-loss guard :322-328), the epoch loop with per-epoch greedy-decode
+validation (:293-459), the per-epoch / best-WER checkpoint packages (:461-478, DeepSpeech.serialize format, `--continue_from`
+:163-185) and the logits dump of AM_training/test.py:138-202 (`--decoder none`).
+
+Data parallel (new in this build): every rank trains its strided shard of the global batch; the loss is normalised by the
+GLOBAL batch size and A's flat gradient buffer is SUM-all-reduced over RCCL bucket by bucket as the layers' weight gradients
+finish (dist.BucketReducer).  Same batch tuples as the AAS trainer (`_collate_fn` order; the mask entry is ignored).
+
+    python -m aas_enhancement_amd.am_train --train_manifest tr.csv --val_manifest val.csv --labels_path labels.json \
+        --nFreq 80 --rnn_size 1000 --rnn_layers 5 --conv_map 128 --batch_size 30 --lr 1e-4 --epochs 10 --gpu 0
+"""
+import argparse
+import json
+import os
+import random
+import time
+
+import numpy as np
 import torch
 
 from . import ops
 from .ctc import CTCLoss
-from .dist import DPContext, FlatBuffers
+from .decoder import GreedyDecoder
+from .dist import BucketReducer, DPContext, FlatBuffers
+from .model import DeepSpeech, supported_rnns
 from .optim import FlatAdam
-from .utils import _get_variable_nograd
+from .utils import AverageMeter, _get_variable_nograd
 
 
 class AMTrainer(object):
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), dp=None):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), dp=None, labels=None):
         self.model = model
         self.criterion = CTCLoss()
+        ops.name_layers(model, "A")
         self.flat = FlatBuffers(model)
         self.opt = FlatAdam(self.flat, lr=lr, betas=betas, amsgrad=False)
         self.dp = dp or DPContext.from_env()
-        ops.DIRECT_WGRAD[0] = True
+        self._reducer = BucketReducer(self.dp, [self.flat]) if self.dp.active else None
+        self.decoder = GreedyDecoder(labels if labels is not None else DeepSpeech.get_labels(model))
+        self.losses = AverageMeter()
 
+    # ---- one step (:297-349) -----------------------------------------------------------------------------------
     def train_step(self, data_list):
         inputs, targets, input_percentages, target_sizes = data_list[0], data_list[1], data_list[2], data_list[3]
         inputs = _get_variable_nograd(inputs)
@@ -30,13 +51,223 @@ class AMTrainer(object):
         N_glob = self.dp.global_counts([N])[0] if self.dp.active else N
         ops.sync_wgrad()
         self.flat.zero_grad()
-        out = self.model(inputs).transpose(0, 1)
-        loss = self.criterion(out, targets, sizes, target_sizes, prepared=meta) / N_glob
-        loss.backward()
-        ops.sync_wgrad()
-        if self.dp.active:
-            self.dp.allreduce_sum_(self.flat.flat_g)
-        self.opt.step()
+        if self._reducer is not None:
+            self._reducer.begin()
+            ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
+        try:
+            out = self.model(inputs).transpose(0, 1)
+            loss = self.criterion(out, targets, sizes, target_sizes, prepared=meta) / N_glob
+            loss.backward()
+            ops.sync_wgrad()
+            if self._reducer is not None:
+                self._reducer.flush(self.flat)
+                self._reducer.wait()
+        finally:
+            ops.WGRAD_HOOK[0] = None
         v = self.dp.reduce_scalars(loss.detach().reshape(1).clone())
-        loss_value = float(v)
-        return dict(loss=loss_value, is_inf=loss_value in (float("inf"), float("-inf")), logits=out)
+        loss_value = float(v)                                  # host read-back: a synchronisation point
+        is_inf = loss_value in (float("inf"), float("-inf"))
+        if not is_inf:
+            ops.check_rnn_health((loss_value,))
+        # inf-loss guard (:322-328): the reference only zeroes the LOGGED value and still steps on the (non-finite)
+        # gradients; an infeasible utterance here has an exactly-zero CTC gradient, so the batch's finite part is applied
+        self.opt.step()
+        return dict(loss=0.0 if is_inf else loss_value, is_inf=is_inf, logits=out)
+
+    # ---- validation (:357-399) ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def validate(self, batches, transcript_prob=0.0):
+        """Greedy-decode WER / CER in percent, averaged over utterances (each utterance's edit distance divided by its own
+        reference length, as the reference does); the model runs in eval mode (running-statistics BatchNorm, softmax)."""
+        self.model.eval()
+        total_wer = total_cer = 0.0
+        n_utt = 0
+        try:
+            for data in batches:
+                inputs, targets, input_percentages, target_sizes = data[0], data[1], data[2], data[3]
+                split_targets, offset = [], 0
+                for size in target_sizes.tolist():
+                    split_targets.append(targets[offset:offset + int(size)])
+                    offset += int(size)
+                out = self.model(_get_variable_nograd(inputs)).transpose(0, 1)
+                sizes = input_percentages.clone().mul_(int(out.size(0))).int()
+                decoded, _ = self.decoder.decode(out, sizes)
+                refs = self.decoder.convert_to_strings(split_targets)
+                for x in range(len(refs)):
+                    hyp, ref = decoded[x][0], refs[x][0]
+                    wer_i = self.decoder.wer(hyp, ref) / float(max(len(ref.split()), 1))
+                    cer_i = self.decoder.cer(hyp, ref) / float(max(len(ref), 1))
+                    total_wer += wer_i
+                    total_cer += cer_i
+                    if random.uniform(0, 1) < transcript_prob:
+                        print("reference = " + ref)
+                        print("decoding = " + hyp)
+                        print("wer = " + str(wer_i) + ", cer = " + str(cer_i))
+                n_utt += len(refs)
+        finally:
+            self.model.train()
+        n_utt = max(n_utt, 1)
+        return 100.0 * total_wer / n_utt, 100.0 * total_cer / n_utt
+
+    # ---- epoch loop (:293-486) ---------------------------------------------------------------------------------
+    def fit(self, train_batches, val_batches, epochs, save_path=None, best_path=None, start_epoch=0, print_every=100,
+            on_epoch_end=None, history=None):
+        """`train_batches(epoch)` / `val_batches()` return iterables of batch tuples.  Writes the running package to
+        `save_path` after every epoch and the best-validation-WER package to `best_path`.  Returns the history dict."""
+        hist = history or dict(loss_results=[], wer_results=[], cer_results=[])
+        best_wer = min(hist["wer_results"]) if hist["wer_results"] else None
+        rank0 = self.dp.rank == 0
+        for epoch in range(start_epoch, epochs):
+            self.model.train()
+            self.losses.reset()
+            avg_loss, n_batches, end = 0.0, 0, time.time()
+            for i, data in enumerate(train_batches(epoch)):
+                if self.dp.active:
+                    data = self.dp.shard_collated(tuple(data[:4]) + ((data[4],) if len(data) > 4 else (torch.zeros(data[0].size(0), 1, data[0].size(2), dtype=torch.uint8),)))
+                r = self.train_step(data)
+                if r["is_inf"]:
+                    print("WARNING: received an inf loss, setting loss value to 0")
+                avg_loss += r["loss"]
+                n_batches += 1
+                self.losses.update(r["loss"], data[0].size(0))
+                if rank0 and print_every and i % print_every == 0:
+                    print("Epoch: [{0}][{1}]\tTime {2:.3f}\tLoss {loss.val:.4f} ({loss.avg:.4f})".format(epoch + 1, i + 1, time.time() - end, loss=self.losses))
+                end = time.time()
+            avg_loss /= max(n_batches, 1)
+            if rank0:
+                print("Training Summary Epoch: [{0}]\tAverage Loss {loss:.3f}\t".format(epoch + 1, loss=avg_loss))
+            wer, cer = self.validate(val_batches()) if val_batches is not None else (float("nan"), float("nan"))
+            hist["loss_results"].append(avg_loss); hist["wer_results"].append(wer); hist["cer_results"].append(cer)
+            if rank0:
+                print("Validation Summary Epoch: [{0}]\tAverage WER {wer:.3f}\tAverage CER {cer:.3f}\t".format(epoch + 1, wer=wer, cer=cer))
+                pkg = lambda: DeepSpeech.serialize(self.model, optimizer=self.opt, epoch=epoch, loss_results=list(hist["loss_results"]),
+                                                   wer_results=list(hist["wer_results"]), cer_results=list(hist["cer_results"]))
+                if save_path:
+                    torch.save(pkg(), save_path)
+                if best_path and (best_wer is None or best_wer > wer):
+                    print("Found better validated model, saving to %s" % best_path)
+                    torch.save(pkg(), best_path)
+            if best_wer is None or best_wer > wer:
+                best_wer = wer
+            if on_epoch_end is not None:
+                on_epoch_end(epoch, avg_loss, wer, cer)
+        return hist
+
+    @classmethod
+    def resume(cls, path, lr=1e-4, gpu=0, dp=None):
+        """`--continue_from` (:163-185): model + optimiser state + history from a package; -> (trainer, start_epoch, history)."""
+        package = torch.load(path, map_location=lambda storage, loc: storage)
+        model = DeepSpeech.load_model_package(package, gpu=gpu)
+        tr = cls(model, lr=lr, dp=dp)
+        if package.get("optim_dict") is not None:
+            tr.opt.load_state_dict(package["optim_dict"])
+        start_epoch = int(package.get("epoch", 1)) - 1
+        if package.get("iteration", None) is None:
+            start_epoch += 1          # saved after the epoch finished: continue with the next one
+        hist = dict(loss_results=list(package.get("loss_results", []) or []), wer_results=list(package.get("wer_results", []) or []),
+                    cer_results=list(package.get("cer_results", []) or []))
+        return tr, start_epoch, hist
+
+
+@torch.no_grad()
+def dump_logits(model, batches, output_path=None):
+    """AM_training/test.py:138-202 with `--decoder none`: a list of (logits [T',N,C] numpy, sizes [N] numpy) per batch,
+    saved with np.save when `output_path` is given (the input of the offline beam-search / LM tuning tools)."""
+    was_training = model.training
+    model.eval()
+    out = []
+    try:
+        for data in batches:
+            inputs, input_percentages = data[0], data[2]
+            o = model(_get_variable_nograd(inputs)).transpose(0, 1)
+            sizes = input_percentages.clone().mul_(int(o.size(0))).int()
+            out.append((o.cpu().numpy(), sizes.numpy()))
+    finally:
+        model.train(was_training)
+    if output_path:
+        arr = np.empty(len(out), dtype=object)
+        for i, item in enumerate(out):
+            arr[i] = item
+        np.save(output_path, arr, allow_pickle=True)
+    return out
+
+
+def weights_init(model, seed=None):
+    """AM_training/utils.py:119-131 as applied by train.py:242 (`model.apply(weights_init)`): Conv weight ~ N(0, 0.1) and
+    bias 0; BatchNorm weight ~ N(1, 0.01) and bias 0; everything else (GRU, fc) keeps its constructor initialisation."""
+    from .model import _BNParams, _ConvK
+    g = torch.Generator().manual_seed(seed) if seed is not None else None
+    for m in model.modules():
+        if isinstance(m, _ConvK):
+            m.weight.data.copy_(torch.randn(m.weight.shape, generator=g) * 0.1)
+            m.bias.data.zero_()
+        elif isinstance(m, _BNParams):
+            m.weight.data.copy_(1.0 + torch.randn(m.weight.shape, generator=g) * 0.01)
+            m.bias.data.zero_()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="DeepSpeech acoustic-model CTC training (AM_training/train.py flags)")
+    ap.add_argument("--train_manifest", required=True)
+    ap.add_argument("--val_manifest", required=True)
+    ap.add_argument("--labels_path", default="labels.json")
+    ap.add_argument("--batch_size", default=30, type=int)
+    ap.add_argument("--num_workers", default=1, type=int)
+    ap.add_argument("--nFreq", default=40, type=int)
+    ap.add_argument("--rnn_size", default=1000, type=int)
+    ap.add_argument("--rnn_layers", default=5, type=int)
+    ap.add_argument("--rnn_type", default="gru")
+    ap.add_argument("--conv_map", default=128, type=int)
+    ap.add_argument("--conv_kernel", default=11, type=int)
+    ap.add_argument("--conv_stride", default=2, type=int)
+    ap.add_argument("--conv_layers", default=2, type=int)
+    ap.add_argument("--epochs", default=70, type=int)
+    ap.add_argument("--lr", default=1e-4, type=float)
+    ap.add_argument("--gpu", default=0, type=int)
+    ap.add_argument("--print_every", default=100, type=int)
+    ap.add_argument("--save_folder", default="models/")
+    ap.add_argument("--model_path", default="models/deepspeech_final.pth.tar")
+    ap.add_argument("--continue_from", default="")
+    ap.add_argument("--DB_name", default="librispeech")
+    ap.add_argument("--expnum", default=0, type=int)
+    ap.add_argument("--preprocess", default="file", help="file: LMFB .pt7 tensors | code: waveforms + the LMFB HIP kernel")
+    ap.add_argument("--no_sortagrad", dest="sortagrad", action="store_false")
+    ap.add_argument("--seed", default=123456, type=int)
+    ap.add_argument("--dist_backend", default="nccl")
+    a = ap.parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        a.gpu = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(a.gpu)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(a.dist_backend, **(dict(device_id=torch.device("cuda", a.gpu)) if a.dist_backend == "nccl" else {}))
+    torch.manual_seed(a.seed); np.random.seed(a.seed); random.seed(a.seed)
+    torch.cuda.set_device(a.gpu)
+    from .data_loader import DataLoader
+    with open(a.labels_path) as f:
+        labels = str("".join(json.load(f)))
+    dl = DataLoader(batch_size=a.batch_size, tr_ny_manifest=a.train_manifest, val_manifest=a.val_manifest, labels=labels,
+                    num_workers=a.num_workers, pin_memory=True, preprocess=a.preprocess, n_mels=a.nFreq)
+    os.makedirs(a.save_folder, exist_ok=True)
+    if a.continue_from:
+        tr, start_epoch, hist = AMTrainer.resume(a.continue_from, lr=a.lr, gpu=a.gpu)
+    else:
+        model = DeepSpeech(rnn_hidden_size=a.rnn_size, rnn_layers=a.rnn_layers, rnn_type=supported_rnns[a.rnn_type.lower()], labels=labels,
+                           kernel_sz=a.conv_kernel, stride=a.conv_stride, map=a.conv_map, cnn_layers=a.conv_layers, nFreq=a.nFreq)
+        weights_init(model)
+        tr, start_epoch, hist = AMTrainer(model.cuda(), lr=a.lr, labels=labels), 0, None
+    n_train = (len(dl._ds["ny/train"]) + a.batch_size - 1) // a.batch_size
+    if not (a.sortagrad and start_epoch == 0):
+        dl._sp["ny/train"].shuffle()
+    train_batches = lambda epoch: (dl.next("ny", "train") for _ in range(n_train))
+    val_batches = lambda: (dl.next("ny", "val") for _ in range(dl.num_batches("val")))
+    tr.fit(train_batches, val_batches, a.epochs, save_path="%s/%s_%d.pth.tar" % (a.save_folder, a.DB_name, a.expnum), best_path=a.model_path,
+           start_epoch=start_epoch, print_every=a.print_every, history=hist)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,7 +46,12 @@ parser.add_argument("--beta2", type=float, default=0.999)
 # additions of this build (not in the reference)
 parser.add_argument("--schedule", default="fused", help="fused | as_executed (results identical)")
 parser.add_argument("--fsegan_as_written", type=str2bool, default=False)
-parser.add_argument("--sync_bn", type=str2bool, default=False, help="data parallel: all-reduce A's BatchNorm statistics")
+parser.add_argument("--sync_bn", type=str2bool, default=False,
+                    help="data parallel: all-reduce A's BatchNorm statistics (global-batch BN; default: local-batch BN per rank)")
+parser.add_argument("--dist_backend", default="nccl", help="torch.distributed backend under torchrun: nccl (= RCCL on ROCm) | gloo")
+parser.add_argument("--preprocess", default="file", help="file: manifests list precomputed LMFB .pt7 tensors (the reference's only "
+                                                         "mode) | code: manifests list 16 kHz waveform tensors and the LMFB "
+                                                         "HIP kernel extracts log-Mel features on the fly (AM_training/train.py:59)")
 
 
 def get_config(argv=None):

@@ -58,3 +58,16 @@ extern "C" int aas_set_rnn_cu_limit(int cus) {
     g_rnn_cu_limit = cus;
     return 0;
 }
+
+// Identifies the persistent recurrent launches queued after the call: a launch that hits its bounded-spin timeout
+// stores this value (>= 1) in the sticky error word of its sync buffer, so the host can name the layer.
+static int g_rnn_tag = 1;
+int aas_rnn_launch_tag_value() { return g_rnn_tag; }
+extern "C" int aas_set_rnn_launch_tag(int tag) {
+    if (tag < 1) {
+        aas_set_error("aas_set_rnn_launch_tag: tag must be >= 1");
+        return 1;
+    }
+    g_rnn_tag = tag;
+    return 0;
+}

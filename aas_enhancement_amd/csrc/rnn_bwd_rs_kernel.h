@@ -150,7 +150,7 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                     if ((++spins & 255u) == 0) {
                         if (ld_cnt(err) != 0) break;
                         if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
-                            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (lane == 0) __hip_atomic_store(err, (unsigned)p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
                         }
                     }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                 if ((++spins & 63u) == 0) {
                     if (ld_cnt(err) != 0) break;
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
-                        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) __hip_atomic_store(err, (unsigned)p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                 }
@@ -335,6 +335,7 @@ int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
     const int cus = aas_rnn_cus();
     AAS_CHECK(cus > 0, "%s: no HIP device", name);
     p.flags = aas_debug_flags_value();
+    p.tag = aas_rnn_launch_tag_value();
     // 32-unit slices (512-thread workgroups) halve the number of slices and with it the bytes every step moves
     // through the fabric; small layers keep 16-unit slices so that enough workgroups share the work
     const int U = (p.H >= 256 && !(p.flags & 512)) ? 32 : 16;

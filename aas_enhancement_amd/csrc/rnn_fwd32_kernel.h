@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
                     if ((++spins & 255u) == 0) {
                         if (ld_cnt(err) != 0) break;
                         if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
-                            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (lane == 0) __hip_atomic_store(err, (unsigned)p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
                         }
                     }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
                 if ((++spins & 63u) == 0) {
                     if (ld_cnt(err) != 0) break;
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
-                        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) __hip_atomic_store(err, (unsigned)p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                 }
@@ -260,6 +260,7 @@ template <int MODE>
 int run_fwd32(const char* name, RnnP p, hipStream_t s) {
     constexpr bool LSTM = (MODE == LSTM_FWD);
     p.flags = aas_debug_flags_value();
+    p.tag = aas_rnn_launch_tag_value();
     if (p.H < 256 || (p.flags & 512)) return -1;
     const int cus = aas_rnn_cus();
     AAS_CHECK(cus > 0, "%s: no HIP device", name);

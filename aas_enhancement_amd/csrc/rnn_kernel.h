@@ -45,6 +45,7 @@ struct RnnP {
     int P, Q;
     int n0, n1;          // batch rows [n0, n1) handled by this launch
     int rpg;             // batch rows per group (<= 16*MT): smaller groups = fewer exchanged bytes per workgroup
+    int tag;             // written to the sticky error word when a bounded spin times out (aas_set_rnn_launch_tag)
     int flags;           // debug/ablation bits (aas_set_debug_flags): 1 no exchange loads, 2 no MFMA, 4 no wait, 8 no publish
 };
 
@@ -53,7 +54,7 @@ __device__ __forceinline__ unsigned ld_cnt(const unsigned* p) {
 }
 
 // Wait until *cnt >= target (thread 0 only).  Bounded: ~0.5 s of wall clock, then flags ERR.
-__device__ __forceinline__ void wait_counter(unsigned* cnt, unsigned target, unsigned* err) {
+__device__ __forceinline__ void wait_counter(unsigned* cnt, unsigned target, unsigned* err, unsigned tag) {
     if (ld_cnt(cnt) >= target) return;
     unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
     unsigned spins = 0;
@@ -62,7 +63,7 @@ __device__ __forceinline__ void wait_counter(unsigned* cnt, unsigned target, uns
         if ((++spins & 255u) == 0) {
             if (ld_cnt(err) != 0) return;
             if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(err, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
         }
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
             if (!(p.flags & 4)) {
-                if (tid == 0) wait_counter(cnt, (unsigned)p.P * (unsigned)s, err);
+                if (tid == 0) wait_counter(cnt, (unsigned)p.P * (unsigned)s, err, (unsigned)p.tag);
                 __syncthreads();
             }
             const int m = lane & 15, q = lane >> 4;
@@ -403,6 +404,7 @@ int run(const char* name, RnnP p, hipStream_t s) {
     const int cus = aas_rnn_cus();
     AAS_CHECK(cus > 0, "%s: no HIP device", name);
     p.flags = aas_debug_flags_value();
+    p.tag = aas_rnn_launch_tag_value();
     p.P = cdiv(p.H, C::U);
     AAS_CHECK(p.P * 2 <= cus, "%s: H=%d needs %d resident workgroups, device has %d CUs", name, p.H, p.P * 2, cus);
     const int kx = FWD ? p.H : C::G * p.H;

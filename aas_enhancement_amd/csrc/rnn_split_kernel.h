@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     if ((++spins & 255u) == 0) {
                         if (ld_cnt(err) != 0) break;
                         if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
-                            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (lane == 0) __hip_atomic_store(err, (unsigned)p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
                         }
                     }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                             if ((++spins & 63u) == 0) {
                                 if (ld_cnt(err) != 0) break;
                                 if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
-                                    if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    if (lane == 0) __hip_atomic_store(err, (unsigned)p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     break;
                                 }
                             }
@@ -438,6 +438,7 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
     const int cus = aas_rnn_cus();
     AAS_CHECK(cus > 0, "%s: no HIP device", name);
     p.flags = aas_debug_flags_value();
+    p.tag = aas_rnn_launch_tag_value();
     p.P = cdiv(p.H, C::U);
     AAS_CHECK(p.P * 2 <= cus, "%s: H=%d needs %d resident workgroups, device has %d CUs", name, p.H, p.P * 2, cus);
     const int Hp = p.P * C::U;

@@ -1,14 +1,40 @@
 """DataLoader.next(cl_ny, type) with the reference's restart-and-shuffle semantics
-(Speech_enhancement_by_AAS/data_loader.py:8-83)."""
+(Speech_enhancement_by_AAS/data_loader.py:8-83), plus what the reference leaves to `.cuda()` inside the trainer:
+
+* `pin_memory=True`: batches are collated into pinned host memory (torch's pin thread) and copied to the device on a
+  private copy stream ONE BATCH AHEAD, so the H2D copy of batch i+1 overlaps the training step on batch i; `next()`
+  hands out device tensors for the big arrays (inputs / clean targets / mask) and host tensors for the small integer
+  metadata the trainer reads on the host (targets, input_percentages, target_sizes) - the `_collate_fn` tuple layouts.
+* `preprocess="code"` (AM_training/train.py:59 `--preprocess file|code`): manifests list 16 kHz waveform tensors
+  instead of precomputed LMFB `.pt7` files; the log-Mel features are extracted on the device by the LMFB HIP kernel
+  (aas_enhancement_amd/lmfb.py), per utterance length, on the copy stream - also one batch ahead.
+"""
+import torch
+
+from . import loader_functions as LF
 from .loader_functions import FeatDataset, FeatLoader, FeatLoader_paired, FeatSampler
 
 
 class DataLoader():
     def __init__(self, batch_size, paired=False, tr_cl_manifest="", tr_ny_manifest="", trsub_manifest="",
-                 val_manifest="", val2_manifest="", labels=None, num_workers=1):
+                 val_manifest="", val2_manifest="", labels=None, num_workers=1, pin_memory=False, preprocess="file",
+                 device=None, n_mels=80):
         self.batch_size, self.labels, self.num_workers = batch_size, labels, num_workers
+        self.paired, self.preprocess = paired, preprocess
+        if preprocess not in ("file", "code"):
+            raise ValueError("preprocess must be 'file' or 'code', got %r" % (preprocess,))
+        self.pin = bool(pin_memory) and torch.cuda.is_available()
+        self.device = torch.device(device) if device is not None else (torch.device("cuda", torch.cuda.current_device()) if self.pin else None)
         self.Loader = FeatLoader_paired if paired else FeatLoader
-        self._ds, self._sp, self._it = {}, {}, {}
+        self._collate = None
+        if preprocess == "code":
+            self._collate = LF._collate_wave_paired if paired else LF._collate_wave
+            if self.device is None or self.device.type != "cuda":
+                raise RuntimeError("preprocess='code' extracts LMFB features with the HIP kernel: it needs the GPU (no CPU fallback)")
+            from .lmfb import LMFB
+            self._lmfb = LMFB(n_mels=n_mels).to(self.device)
+        self._ds, self._sp, self._it, self._ahead = {}, {}, {}, {}
+        self._copy_stream = torch.cuda.Stream(device=self.device) if (self.device is not None and self.device.type == "cuda") else None
         for key, manifest, sampled in (("cl/train", tr_cl_manifest, True), ("ny/train", tr_ny_manifest, True),
                                        ("ny/trsub", trsub_manifest, False), ("ny/val", val_manifest, False),
                                        ("ny/val2", val2_manifest, False)):
@@ -19,20 +45,79 @@ class DataLoader():
                 self._it[key] = self._make(key)
 
     def _make(self, key):
+        kw = dict(num_workers=self.num_workers, pin_memory=self.pin)
+        if self._collate is not None:
+            kw["collate_fn"] = self._collate
         if key in self._sp:
-            return iter(self.Loader(self._ds[key], num_workers=self.num_workers, batch_sampler=self._sp[key]))
-        return iter(self.Loader(self._ds[key], batch_size=self.batch_size, num_workers=self.num_workers))
+            return iter(self.Loader(self._ds[key], batch_sampler=self._sp[key], **kw))
+        return iter(self.Loader(self._ds[key], batch_size=self.batch_size, **kw))
 
     def num_batches(self, type):
         ds = self._ds["ny/" + type]
         return (len(ds) + self.batch_size - 1) // self.batch_size
 
-    def next(self, cl_ny="", type=""):
-        key = "%s/%s" % (cl_ny, type)
+    # ---- host side: the reference's semantics (data_loader.py:42-83) ---------------------------------------------
+    def _next_host(self, key):
         try:
             return next(self._it[key])
         except StopIteration:
             if key in self._sp:
-                self._sp[key].shuffle()
+                self._sp[key].shuffle()       # training sets: reshuffle the batch order, then restart
             self._it[key] = self._make(key)
             return next(self._it[key])
+
+    # ---- device side: one batch ahead on the copy stream ---------------------------------------------------------
+    def _to_device(self, batch):
+        """-> (tuple in the collate layout with the big tensors on the device, event recorded on the copy stream)."""
+        dev, cs = self.device, self._copy_stream
+        with torch.cuda.stream(cs):
+            if self.preprocess == "code":
+                batch = self._features_from_waves(batch)
+            out = []
+            for t in batch:
+                if torch.is_tensor(t) and t.dim() == 3:            # inputs / outputs [N,F,T] and mask [N,1,T]
+                    if t.dtype == torch.uint8 and not hasattr(t, "n_valid"):
+                        t.n_valid = int(t.numel()) - int(t.sum().item()) if not t.is_cuda else None
+                    d = t if t.is_cuda else t.to(dev, non_blocking=True)
+                    if getattr(t, "n_valid", None) is not None:
+                        d.n_valid = t.n_valid
+                    out.append(d)
+                else:
+                    out.append(t)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        return tuple(out), ev
+
+    def _features_from_waves(self, batch):
+        """(waves[N,S], lengths[N], targets, target_sizes[, clean waves]) -> the `_collate_fn*` tuple with LMFB features:
+        T_i = 1 + S_i // hop frames per utterance, zero beyond T_i, input_percentages = T_i / T_max, mask = 1 on padding."""
+        if self.paired:
+            waves, lengths, targets, target_sizes, cleans = batch
+        else:
+            waves, lengths, targets, target_sizes = batch
+        hop = self._lmfb.hop
+        d_len = lengths.to(torch.int32).to(self.device, non_blocking=True)
+        feats = self._lmfb(waves.to(self.device, non_blocking=True), d_len)
+        frames = 1 + lengths.to(torch.int64) // hop
+        t_max = feats.size(2)
+        mask = (torch.arange(t_max)[None, :] >= frames[:, None]).to(torch.uint8).unsqueeze(1)
+        mask.n_valid = int(frames.sum())
+        pct = (frames.double() / float(t_max)).float()
+        if self.paired:
+            clean_feats = self._lmfb(cleans.to(self.device, non_blocking=True), d_len)
+            return feats, clean_feats, mask, targets, pct, target_sizes
+        return feats, targets, pct, target_sizes, mask
+
+    def next(self, cl_ny="", type=""):
+        key = "%s/%s" % (cl_ny, type)
+        if self._copy_stream is None:
+            return self._next_host(key)
+        if key not in self._ahead:
+            self._ahead[key] = self._to_device(self._next_host(key))
+        batch, ev = self._ahead[key]
+        torch.cuda.current_stream().wait_event(ev)
+        for t in batch:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(torch.cuda.current_stream())
+        self._ahead[key] = self._to_device(self._next_host(key))   # start the next batch's copy / extraction now
+        return batch

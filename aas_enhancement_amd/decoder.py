@@ -1,19 +1,22 @@
 """Greedy CTC decoding + WER/CER with the reference's API (AM_training/decoder.py:45-74,146-201).
-Validation-only.  Pure Python: python-Levenshtein (a C extension the reference
-uses) is not a dependency here."""
+Validation pass of the trainers.  The argmax + collapse runs on the device (aas_greedy_decode,
+one wavefront per utterance) when the scores are on the GPU; the edit distance is the native host function
+aas_edit_distance of libaas_hip.so (the reference uses the python-Levenshtein C extension)."""
+import ctypes
+
+import numpy as np
 import torch
 
 
 def _levenshtein(a, b):
-    if len(a) < len(b):
-        a, b = b, a
-    prev = list(range(len(b) + 1))
-    for i, ca in enumerate(a, 1):
-        cur = [i]
-        for j, cb in enumerate(b, 1):
-            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
-        prev = cur
-    return prev[-1]
+    """Edit distance of two strings (native two-row dynamic programme over the code points)."""
+    from ._lib import lib
+    ia = np.fromiter((ord(c) for c in a), dtype=np.int32, count=len(a))
+    ib = np.fromiter((ord(c) for c in b), dtype=np.int32, count=len(b))
+    d = lib().aas_edit_distance(ia.ctypes.data_as(ctypes.c_void_p), len(a), ib.ctypes.data_as(ctypes.c_void_p), len(b))
+    if d < 0:
+        raise RuntimeError("aas_edit_distance failed")
+    return int(d)
 
 
 class Decoder(object):
@@ -65,8 +68,30 @@ class GreedyDecoder(Decoder):
         return string, torch.IntTensor(offsets)
 
     def decode(self, probs, sizes=None):
-        """probs [T,N,C] -> argmax path, repeats collapsed, blanks dropped."""
+        """probs [T,N,C] -> (strings, offsets): argmax path, repeats collapsed, blanks dropped (decoder.py:186-201)."""
+        if probs.is_cuda:
+            return self._decode_device(probs, sizes)
         _, max_probs = torch.max(probs.transpose(0, 1), 2)
-        max_probs = max_probs.cpu()
         return self.convert_to_strings(max_probs.view(max_probs.size(0), max_probs.size(1)), sizes,
                                        remove_repetitions=True, return_offsets=True)
+
+    def _decode_device(self, probs, sizes):
+        from ._lib import check, lib, ptr, stream
+        probs = probs.detach()
+        probs = probs if probs.is_contiguous() else probs.contiguous()
+        T, N, C = probs.shape
+        dev = probs.device
+        sz = torch.full((N,), T, dtype=torch.int32) if sizes is None else torch.as_tensor(sizes).to(torch.int32).reshape(-1)
+        d_sz = sz.to(dev)
+        out = torch.empty((N, T), dtype=torch.int32, device=dev)
+        offs = torch.empty((N, T), dtype=torch.int32, device=dev)
+        lens = torch.empty((N,), dtype=torch.int32, device=dev)
+        check(lib().aas_greedy_decode(stream(), ptr(probs), ptr(d_sz), T, N, C, self.blank_index, ptr(out), ptr(offs), ptr(lens)),
+              "aas_greedy_decode")
+        out_h, offs_h, lens_h = out.cpu(), offs.cpu(), lens.cpu().tolist()
+        strings, offsets = [], []
+        for n in range(N):
+            k = lens_h[n]
+            strings.append(["".join(self.int_to_char[i] for i in out_h[n, :k].tolist())])
+            offsets.append([offs_h[n, :k].clone()])
+        return strings, offsets

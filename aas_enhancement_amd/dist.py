@@ -35,6 +35,10 @@ class DPContext(object):
             return like.device
         return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
 
+    def barrier(self):
+        if self.active:
+            dist.barrier(group=self.group)
+
     def global_counts(self, values):
         """SUM over ranks of a short list of integers (N, nElement ...) -> list[int]."""
         if not self.active:
@@ -113,6 +117,9 @@ class FlatBuffers(object):
             p.data = self.flat_p[off:off + n].view_as(p)
             self.slices.append((off, n))
             off += n
+            # marks the parameter for ops._BiRNNLayer: its weight gradients may be accumulated straight into .grad on the
+            # side stream, because whoever owns these buffers joins that stream (ops.sync_wgrad) before reading them
+            p._aas_flat_grad = True
         self.bind_grads()
 
     def bind_grads(self):
@@ -124,3 +131,55 @@ class FlatBuffers(object):
     def zero_grad(self):
         self.flat_g.zero_()
         self.bind_grads()
+
+
+class BucketReducer(object):
+    """Bucketed, overlapped SUM all-reduce of the flat gradient buffers (>= 16 MB buckets launched as each
+    network's weight gradients finish, D's first, then E's).
+
+    A recurrent layer's four weight-gradient products are queued on the side stream by ops._birnn_bwd, which then calls
+    `on_wgrad(grads)` from that stream's context: the layer's contiguous slice of the flat buffer (16 MB for a 500-unit
+    BiLSTM layer, 48 MB for a 1000-unit BiGRU layer) is all-reduced right there, ordered after the products on the side
+    stream and overlapping the rest of the backward pass.  `flush(flat)` reduces whatever the hooks did not cover (the
+    small pointwise / conv / BN / fc parameters) and `wait()` makes the current stream wait for every collective.
+    Armed only in steps where every layer is back-propagated exactly once (the fused schedule without grad-norm logging)."""
+    MIN_ELEMS = 1 << 20
+
+    def __init__(self, dp, flats):
+        self.dp, self.flats = dp, list(flats)
+        self.handles, self.done = [], {}
+
+    def begin(self):
+        self.handles = []
+        self.done = {id(f): [] for f in self.flats}
+
+    def _locate(self, grads):
+        for f in self.flats:
+            base, total = f.flat_g.data_ptr(), f.flat_g.numel()
+            offs = [(g.data_ptr() - base) // 4 for g in grads]
+            if all(0 <= o < total for o in offs):
+                lo = min(offs)
+                hi = max(o + g.numel() for o, g in zip(offs, grads))
+                return f, lo, hi, sum(g.numel() for g in grads)
+        return None, 0, 0, 0
+
+    def on_wgrad(self, grads):
+        f, lo, hi, n = self._locate(grads)
+        if f is None or hi - lo != n or n < self.MIN_ELEMS:
+            return
+        self.handles.append(self.dp.allreduce_sum_(f.flat_g[lo:hi], async_op=True))
+        self.done[id(f)].append((lo, hi))
+
+    def flush(self, flat):
+        pos = 0
+        for lo, hi in sorted(self.done[id(flat)]) + [(flat.flat_g.numel(), flat.flat_g.numel())]:
+            if lo > pos:
+                self.handles.append(self.dp.allreduce_sum_(flat.flat_g[pos:lo], async_op=True))
+            pos = max(pos, hi)
+        self.done[id(flat)] = [(0, flat.flat_g.numel())]
+
+    def wait(self):
+        for h in self.handles:
+            if h is not None:
+                h.wait()
+        self.handles = []

@@ -32,12 +32,12 @@ class FeatDataset(Dataset):
         return self.size
 
 
-def _pad_batch(feats, pin=False):
+def _pad_batch(feats):
     """Zero-pad a list of [F, T_i] features (already in batch order) to [N, F, T_max].
     -> (padded, lengths[N] int64, mask[N,1,T_max] u8 with 1 = padding); mask.n_valid = number of real frames."""
     lengths = torch.tensor([f.size(1) for f in feats], dtype=torch.int64)
     t_max = int(lengths.max())
-    padded = torch.zeros(len(feats), feats[0].size(0), t_max, pin_memory=pin)
+    padded = torch.zeros(len(feats), feats[0].size(0), t_max)
     for row, f in zip(padded, feats):
         row[:, :f.size(1)] = f
     mask = (torch.arange(t_max)[None, :] >= lengths[:, None]).to(torch.uint8).unsqueeze(1)
@@ -60,7 +60,7 @@ def _collate_fn(batch):
     """-> (inputs[N,F,T], targets[sum L] i32, input_percentages[N] f32, target_sizes[N] i32, mask[N,1,T] u8)
     (loader_functions.py:47-73)"""
     batch = _order(batch)
-    inputs, lengths, mask = _pad_batch([s[0] for s in batch], pin=PIN_MEMORY[0])
+    inputs, lengths, mask = _pad_batch([s[0] for s in batch])
     targets, target_sizes = _flat_targets([s[1] for s in batch])
     return inputs, targets, (lengths.double() / float(inputs.size(2))).float(), target_sizes, mask
 
@@ -68,16 +68,40 @@ def _collate_fn(batch):
 def _collate_fn_paired(batch):
     """-> (inputs, outputs(clean), mask, targets, input_percentages, target_sizes)  (loader_functions.py:75-105)"""
     batch = _order(batch)
-    inputs, lengths, mask = _pad_batch([s[0] for s in batch], pin=PIN_MEMORY[0])
-    outputs = torch.zeros_like(inputs, pin_memory=PIN_MEMORY[0])
+    inputs, lengths, mask = _pad_batch([s[0] for s in batch])
+    outputs = torch.zeros_like(inputs)
     for row, s in zip(outputs, batch):
         row[:, :s[0].size(1)] = s[2][:, :s[0].size(1)]
     targets, target_sizes = _flat_targets([s[1] for s in batch])
     return inputs, outputs, mask, targets, (lengths.double() / float(inputs.size(2))).float(), target_sizes
 
 
-# collate straight into pinned host memory (set by data_loader.DataLoader(pin_memory=True) in the loading process)
-PIN_MEMORY = [False]
+def _pad_waves(waves):
+    lengths = torch.tensor([w.numel() for w in waves], dtype=torch.int64)
+    out = torch.zeros(len(waves), int(lengths.max()))
+    for row, w in zip(out, waves):
+        row[:w.numel()] = w.reshape(-1)
+    return out, lengths
+
+
+def _collate_wave(batch):
+    """`--preprocess code`: samples are (waveform[S], transcript).  -> (waves[N,S_max] zero padded, lengths[N] samples,
+    targets[sum L] i32, target_sizes[N] i32), longest first; data_loader turns it into the `_collate_fn` tuple on the device."""
+    batch = sorted(batch, key=lambda s: s[0].numel(), reverse=True)
+    waves, lengths = _pad_waves([s[0] for s in batch])
+    targets, target_sizes = _flat_targets([s[1] for s in batch])
+    return waves, lengths, targets, target_sizes
+
+
+def _collate_wave_paired(batch):
+    """paired variant: samples are (noisy waveform, transcript, clean waveform of the same length)."""
+    batch = sorted(batch, key=lambda s: s[0].numel(), reverse=True)
+    waves, lengths = _pad_waves([s[0] for s in batch])
+    cleans, _ = _pad_waves([s[2] for s in batch])
+    if cleans.size(1) != waves.size(1):
+        cleans = torch.nn.functional.pad(cleans, (0, waves.size(1) - cleans.size(1)))[:, :waves.size(1)]
+    targets, target_sizes = _flat_targets([s[1] for s in batch])
+    return waves, lengths, targets, target_sizes, cleans
 
 
 class FeatLoader(DataLoader):

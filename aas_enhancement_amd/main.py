@@ -26,6 +26,22 @@ def main(config):
         paired = True
     else:
         raise ValueError("unknown trainer %r" % config.trainer)
+    # Data parallel (new in this build; the reference is single-GPU, main.py:28-30): launched with
+    #   python -m torch.distributed.run --nproc-per-node N -m aas_enhancement_amd.main --trainer AAS ...
+    # one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE come from the launcher's environment.  Every rank reads the same
+    # manifests with the same seed, so all ranks draw the same global minibatch and keep their strided shard of it.
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        config.gpu = local_rank
+        torch.cuda.set_device(local_rank)   # (device selection only: nothing has touched the GPU before this point)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            kw = dict(device_id=torch.device("cuda", local_rank)) if config.dist_backend == "nccl" else {}
+            dist.init_process_group(config.dist_backend, **kw)
+    import numpy as np
+    np.random.seed(config.random_seed)      # FeatSampler shuffles with numpy: identical batch order on every rank
     if config.gpu >= 0:
         torch.cuda.manual_seed(config.random_seed)
         torch.cuda.set_device(config.gpu)
@@ -45,14 +61,21 @@ def main(config):
         labels = str("".join(json.load(label_file)))
     data_loader = DataLoader(batch_size=config.batch_size, paired=paired, tr_cl_manifest=config.tr_cl_manifest,
                              tr_ny_manifest=config.tr_ny_manifest, trsub_manifest=config.trsub_manifest,
-                             val_manifest=config.val_manifest, val2_manifest=config.val2_manifest, labels=labels)
+                             val_manifest=config.val_manifest, val2_manifest=config.val2_manifest, labels=labels,
+                             pin_memory=config.gpu >= 0, preprocess=config.preprocess)
     os.makedirs("logs/" + str(config.expnum), exist_ok=True)
     trainer = Trainer(config, data_loader)
     torch.manual_seed(config.random_seed)
-    if config.mode == "train":
-        trainer.train()
-    else:
-        raise NotImplementedError("mode %r: the reference trainers define neither test() nor visualize()" % config.mode)
+    try:
+        if config.mode == "train":
+            trainer.train()
+        else:
+            raise NotImplementedError("mode %r: the reference trainers define neither test() nor visualize()" % config.mode)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -58,13 +58,14 @@ class _RNNWeights(nn.Module):
         b = 1.0 / math.sqrt(hidden_size)
         for p in self.parameters():
             nn.init.uniform_(p, -b, b)
+        self._aas_layer_id = ops.register_layer("%s %d->%d" % (kind, input_size, hidden_size))
 
     def flatten_parameters(self):
         pass
 
     def run(self, x, residual, rs=None):
         return ops.birnn_layer(x, self.weight_ih_l0, self.weight_hh_l0, self.weight_ih_l0_reverse,
-                               self.weight_hh_l0_reverse, self.kind, residual, rs)
+                               self.weight_hh_l0_reverse, self.kind, residual, rs, self._aas_layer_id)
 
 
 class _BNParams(nn.Module):
@@ -80,8 +81,8 @@ class _BNParams(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
     def forward(self, x, slope=1.0):
-        if not self.training:
-            raise NotImplementedError("eval-mode BatchNorm is not on the training hot path (the reference never calls ASR.eval())")
+        if not self.training:   # model.eval(): running statistics (AM_training/train.py:357 validation; the AAS trainers
+            return ops.batchnorm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, slope)  # never do)
         y = ops.batchnorm_rows(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                self.momentum, slope)
         self.num_batches_tracked += 1
@@ -103,7 +104,7 @@ class SequenceWise(nn.Module):
 class InferenceBatchSoftmax(nn.Module):
     def forward(self, input_):
         if not self.training:
-            raise NotImplementedError("eval-mode softmax is validation-only (SURVEY 8f 'next')")
+            return ops.softmax_rows(input_)
         return input_
 
 

@@ -27,13 +27,57 @@ def _sync_buf(dev):
     return b
 
 
-def rnn_timeout_flag(dev=None):
-    """True if any persistent RNN launch on this device hit its bounded-spin timeout."""
-    bad = False
+_layer_names = {}   # launch tag // 2 -> layer name (tag 1 = a launch of an unregistered layer)
+
+
+def register_layer(name):
+    """-> id of a recurrent layer; its launches carry tag 2*id (forward) / 2*id+1 (BPTT) into the sticky error word."""
+    lid = len(_layer_names) + 1
+    _layer_names[lid] = name
+    return lid
+
+
+def name_layers(module, prefix):
+    """Give every recurrent layer of `module` a readable name ("G.rnn2.rnn") for timeout diagnostics."""
+    for n, m in module.named_modules():
+        lid = getattr(m, "_aas_layer_id", None)
+        if lid is not None:
+            _layer_names[lid] = prefix + "." + n
+
+
+def rnn_timeout_layers():
+    """Names of the persistent launches whose bounded spins timed out since the flags were last cleared (host sync)."""
+    out = []
     for k, b in _scratch.items():
         if k[0] == "sync":
-            bad = bad or bool(b.view(torch.int32)[1024].item())
-    return bad
+            tag = int(b.view(torch.int32)[1024].item())
+            if tag:
+                out.append("%s %s" % (_layer_names.get(tag // 2, "unregistered layer"), "BPTT" if tag & 1 else "forward"))
+    return out
+
+
+def rnn_timeout_flag(dev=None):
+    """True if any persistent RNN launch on this device hit its bounded-spin timeout."""
+    return len(rnn_timeout_layers()) > 0
+
+
+def clear_rnn_timeout():
+    for k, b in _scratch.items():
+        if k[0] == "sync":
+            b.view(torch.int32)[1024:1025].zero_()
+
+
+def check_rnn_health(scalars=()):
+    """Call at a host synchronisation point.  A non-finite loss is reported as divergence (a NaN in h also looks like
+    the exchange poison word and would stall every step in the spin timeout); otherwise a raised sticky word names the
+    layer whose exchange timed out - its gradients are garbage and training must not continue."""
+    import math
+    if any(not math.isfinite(float(v)) for v in scalars):
+        raise FloatingPointError("training diverged: non-finite loss scalars %r" % (list(scalars),))
+    bad = rnn_timeout_layers()
+    if bad:
+        raise RuntimeError("persistent recurrent kernel: cross-CU exchange timed out in %s (results of this step are invalid)"
+                           % ", ".join(bad))
 
 
 def _xchg_buf(dev, T, N, H, G):
@@ -87,7 +131,8 @@ def device_cus():
 # the recurrent layers' weight-gradient GEMMs run on a side HIP stream and ACCUMULATE straight into .grad
 # (autograd gets None for those inputs): they are only needed at the optimiser step, so they overlap the next
 # layer's persistent BPTT launch instead of sitting on the backward critical path.  sync_wgrad() joins.
-DIRECT_WGRAD = [False]
+DIRECT_WGRAD = [True]    # kill switch; the path is taken only for parameters re-homed by dist.FlatBuffers (_aas_flat_grad)
+WGRAD_HOOK = [None]      # callable(list of .grad views) run on the side stream after a layer's products are queued
 _SKIP_WGRAD = bool(int(__import__('os').environ.get('AAS_SKIP_WGRAD', '0')))
 _wgrad_streams = {}
 
@@ -119,7 +164,7 @@ class Profiler:
     `classes` selects which launch classes are bracketed with events: "rnn" and/or "gemm"."""
     enabled = False
     classes = ("rnn",)
-    records = []  # (name, algorithmic_flops, start_event, end_event)
+    records = []  # (name, algorithmic_flops, start_event, end_event, T or 0)
 
     @classmethod
     def start(cls, classes=("rnn",)):
@@ -130,8 +175,8 @@ class Profiler:
         """-> {name: dict(count, total_ms, avg_ms, flops_per_launch)}; call after a device sync."""
         cls.enabled = False
         out = {}
-        for name, flops, e0, e1 in cls.records:
-            d = out.setdefault(name, dict(count=0, total_ms=0.0, flops=0.0))
+        for name, flops, e0, e1, T in cls.records:
+            d = out.setdefault(name, dict(count=0, total_ms=0.0, flops=0.0, T=T))
             d["count"] += 1
             d["total_ms"] += e0.elapsed_time(e1)
             d["flops"] += flops
@@ -143,9 +188,9 @@ class Profiler:
 
 
 class _timed:
-    def __init__(self, klass, name, flops):
+    def __init__(self, klass, name, flops, T=0):
         self.on = Profiler.enabled and klass in Profiler.classes
-        self.name, self.flops = name, flops
+        self.name, self.flops, self.T = name, flops, T
 
     def __enter__(self):
         if self.on:
@@ -156,14 +201,14 @@ class _timed:
     def __exit__(self, *a):
         if self.on:
             self.e1.record(torch.cuda.current_stream())
-            Profiler.records.append((self.name, self.flops, self.e0, self.e1))
+            Profiler.records.append((self.name, self.flops, self.e0, self.e1, self.T))
 
 
 # --------------------------------------------------------------------------------------- GEMM
 def gemm(mode, M, N, K, A, lda, B, ldb, C, ldc, bias=None, addend=None, ldd=0, accumulate=False,
          batch=1, sA=0, sB=0, sC=0, kdivA=0, kouterA=0, kdivB=0, kouterB=0, a_off=0, b_off=0, c_off=0):
     """Raw GEMM on device pointers; *_off are element offsets into A/B/C."""
-    with _timed("gemm", "gemm_f32", 2.0 * M * N * K * batch):
+    with _timed("gemm", "gemm_%s" % ("nt", "nn", "tn")[mode], 2.0 * M * N * K * batch):
         _gemm_raw(mode, M, N, K, A, lda, B, ldb, C, ldc, bias, addend, ldd, accumulate, batch, sA, sB, sC, kdivA, kouterA,
                   kdivB, kouterB, a_off, b_off, c_off)
 
@@ -373,7 +418,7 @@ def linear_rows(x, W, b=None, rs=None):
 PLANES_PRE = [os.environ.get("AAS_PLANES_PRE", "1") == "1"]   # input projections of the recurrent layers on the plane GEMM
 
 
-def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
+def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0):
     """x [T,N,I] -> (pre, hout[2,T,N,H], gact, cst)."""
     T, N, I = x.shape
     G = 4 if kind == "lstm" else 3
@@ -418,21 +463,22 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r):
     sync = _sync_buf(dev)
     xchg = _xchg_buf(dev, T, N, H, G)
     rflops = 2.0 * 2 * T * N * H * G * H  # both directions, T steps of [N,H]x[H,G*H]
+    lib().aas_set_rnn_launch_tag(2 * lid if lid else 1)
     if kind == "lstm":
         cst = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
-        with _timed("rnn", "lstm_fwd", rflops):
+        with _timed("rnn", "lstm_fwd[N=%d,H=%d]" % (N, H), rflops, T):
             check(lib().aas_lstm_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(cst),
                                      ptr(sync), ptr(xchg)), "aas_lstm_fwd")
     else:
         cst = None
-        with _timed("rnn", "gru_fwd", rflops):
+        with _timed("rnn", "gru_fwd[N=%d,H=%d]" % (N, H), rflops, T):
             check(lib().aas_gru_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync),
                                     ptr(xchg)), "aas_gru_fwd")
     return hout, gact, cst
 
 
 def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residual, need_dx=True, need_dw=True, rs=None,
-               direct=None):
+               direct=None, lid=0):
     T, N, I = x.shape
     G = 4 if kind == "lstm" else 3
     H = w_hh.shape[1]
@@ -443,14 +489,15 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     xchg = _xchg_buf(dev, T, N, H, G)
     dgx = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
     rflops = 2.0 * 2 * T * N * H * GH
+    lib().aas_set_rnn_launch_tag(2 * lid + 1 if lid else 1)
     if kind == "lstm":
-        with _timed("rnn", "lstm_bwd", rflops):
+        with _timed("rnn", "lstm_bwd[N=%d,H=%d]" % (N, H), rflops, T):
             check(lib().aas_lstm_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), ptr(dgx),
                                      ptr(sync), ptr(xchg)), "aas_lstm_bwd")
         dgh = dgx
     else:
         dgh = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
-        with _timed("rnn", "gru_bwd", rflops):
+        with _timed("rnn", "gru_bwd[N=%d,H=%d]" % (N, H), rflops, T):
             check(lib().aas_gru_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(dgx),
                                     ptr(dgh), ptr(sync), ptr(xchg)), "aas_gru_bwd")
     x2 = x.view(T * N, I)
@@ -495,6 +542,8 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         with torch.cuda.stream(side):
             side.wait_event(ev)
             wgrads(direct, True)
+            if WGRAD_HOOK[0] is not None:
+                WGRAD_HOOK[0](direct)
         for t_ in (dgx, dgh, x, hout):
             t_.record_stream(side)
         return dx, None, None, None, None
@@ -509,13 +558,13 @@ class _BiRNNLayer(torch.autograd.Function):
     (reference model.py:80-86,101-105 and the residual adds at :223-226)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual, rs=None):
+    def forward(ctx, x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual, rs=None, lid=0):
         require_cuda(x, w_ih, w_hh)
-        ctx.rs = rs
+        ctx.rs, ctx.lid = rs, lid
         ctx.params = (w_ih, w_hh, w_ih_r, w_hh_r)  # the nn.Parameters themselves (for the direct-accumulate path)
         x = _c(x)
         w_ih, w_hh, w_ih_r, w_hh_r = _c(w_ih), _c(w_hh), _c(w_ih_r), _c(w_hh_r)
-        hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r)
+        hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid)
         y = add3(hout[0], hout[1], x if residual else None)
         ctx.kind, ctx.residual = kind, residual
         ctx.save_for_backward(x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst if cst is not None else hout)
@@ -526,22 +575,27 @@ class _BiRNNLayer(torch.autograd.Function):
         x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst = ctx.saved_tensors
         direct = None
         if DIRECT_WGRAD[0] and all(ctx.needs_input_grad[1:5]):
-            gr = [getattr(p_, "grad", None) for p_ in ctx.params]
+            gr = [getattr(p_, "grad", None) if getattr(p_, "_aas_flat_grad", False) else None for p_ in ctx.params]
             if all(g is not None and g.is_contiguous() and g.shape == p_.shape for g, p_ in zip(gr, ctx.params)):
                 direct = gr
         dx, a, b, c, d = _birnn_bwd(ctx.kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, ctx.residual,
                                     need_dx=ctx.needs_input_grad[0], need_dw=any(ctx.needs_input_grad[1:5]), rs=ctx.rs,
-                                    direct=direct)
-        return dx, a, b, c, d, None, None, None
+                                    direct=direct, lid=ctx.lid)
+        return dx, a, b, c, d, None, None, None, None
 
 
-def birnn_layer(x, w_ih, w_hh, w_ih_r, w_hh_r, kind="lstm", residual=False, rs=None):
-    return _BiRNNLayer.apply(x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual, rs)
+def birnn_layer(x, w_ih, w_hh, w_ih_r, w_hh_r, kind="lstm", residual=False, rs=None, lid=0):
+    return _BiRNNLayer.apply(x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual, rs, lid)
 
 
 # --------------------------------------------------------------------------------------- batch norm
+SYNC_BN = [None]   # a dist.DPContext: train-mode statistics are all-reduced over the ranks (SyncBN)
+
+
 class _BatchNormRows(torch.autograd.Function):
-    """Train-mode BatchNorm over the rows of x[..., C] (+ fused LeakyReLU(slope)); updates running stats."""
+    """Train-mode BatchNorm over the rows of x[..., C] (+ fused LeakyReLU(slope)); updates running stats.
+    With SYNC_BN set (data parallel, --sync_bn) the per-channel sums and the row count are all-reduced between the
+    statistics pass and the apply pass, forward and backward, so the result equals the single-process global batch."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope):
@@ -551,9 +605,20 @@ class _BatchNormRows(torch.autograd.Function):
         R = x.numel() // C
         y = torch.empty_like(x)
         stats = torch.empty((4, C), device=x.device, dtype=torch.float32)
-        wsd = _wsd(x.device, 2 * C)
-        check(lib().aas_bn_fwd(stream(), ptr(x), ptr(y), R, C, ptr(gamma), ptr(beta), float(eps), float(slope),
-                               ptr(stats), ptr(running_mean), ptr(running_var), float(momentum), ptr(wsd)), "aas_bn_fwd")
+        dp = SYNC_BN[0]
+        ctx.dp, ctx.rows = dp, None
+        if dp is None:
+            wsd = _wsd(x.device, 2 * C)
+            check(lib().aas_bn_fwd(stream(), ptr(x), ptr(y), R, C, ptr(gamma), ptr(beta), float(eps), float(slope),
+                                   ptr(stats), ptr(running_mean), ptr(running_var), float(momentum), ptr(wsd)), "aas_bn_fwd")
+        else:
+            red = torch.empty(2 * C + 1, device=x.device, dtype=torch.float64)   # [sum, sumsq, rows]: ONE collective
+            check(lib().aas_bn_stats(stream(), ptr(x), R, C, ptr(red)), "aas_bn_stats")
+            red[2 * C:].fill_(float(R))
+            dp.reduce_scalars(red)
+            ctx.rows = red[2 * C:]
+            check(lib().aas_bn_apply(stream(), ptr(x), ptr(y), R, C, ptr(gamma), ptr(beta), float(eps), float(slope), ptr(stats),
+                                     ptr(running_mean), ptr(running_var), float(momentum), ptr(red), ptr(ctx.rows)), "aas_bn_apply")
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.slope = slope
         return y
@@ -567,10 +632,40 @@ class _BatchNormRows(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
-        wsd = _wsd(x.device, 2 * C)
-        check(lib().aas_bn_bwd(stream(), ptr(x), ptr(dy), ptr(dx), R, C, ptr(gamma), ptr(beta), float(ctx.slope),
-                               ptr(stats), ptr(dgamma), ptr(dbeta), 0, ptr(wsd)), "aas_bn_bwd")
+        if ctx.dp is None:
+            wsd = _wsd(x.device, 2 * C)
+            check(lib().aas_bn_bwd(stream(), ptr(x), ptr(dy), ptr(dx), R, C, ptr(gamma), ptr(beta), float(ctx.slope),
+                                   ptr(stats), ptr(dgamma), ptr(dbeta), 0, ptr(wsd)), "aas_bn_bwd")
+        else:
+            loc = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+            check(lib().aas_bn_bwd_reduce(stream(), ptr(x), ptr(dy), R, C, ptr(gamma), ptr(beta), float(ctx.slope), ptr(stats),
+                                          ptr(loc)), "aas_bn_bwd_reduce")
+            glob = loc.clone()
+            ctx.dp.reduce_scalars(glob)
+            check(lib().aas_bn_bwd_apply(stream(), ptr(x), ptr(dy), ptr(dx), R, C, ptr(gamma), ptr(beta), float(ctx.slope),
+                                         ptr(stats), ptr(dgamma), ptr(dbeta), 0, ptr(glob), ptr(loc), ptr(ctx.rows)), "aas_bn_bwd_apply")
         return dx, (dgamma if ctx.needs_input_grad[1] else None), (dbeta if ctx.needs_input_grad[2] else None), None, None, None, None, None
+
+
+def batchnorm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, slope=1.0):
+    """Eval-mode BatchNorm (running statistics) + fused LeakyReLU; inference only (no autograd)."""
+    require_cuda(x, gamma)
+    x = _c(x.detach())
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().aas_bn_eval(stream(), ptr(x), ptr(y), x.numel() // C, C, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                            float(eps), float(slope)), "aas_bn_eval")
+    return y
+
+
+def softmax_rows(x):
+    """softmax over the last dim (C <= 64); inference only (InferenceBatchSoftmax in eval mode, model.py:58-64)."""
+    require_cuda(x)
+    x = _c(x.detach())
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().aas_softmax_rows(stream(), ptr(x), ptr(y), x.numel() // C, C), "aas_softmax_rows")
+    return y
 
 
 def batchnorm_rows(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, slope=1.0):
@@ -700,8 +795,9 @@ class _CTC(torch.autograd.Function):
         costs = torch.empty((N,), device=dev, dtype=torch.float32)
         grads = torch.empty_like(acts)
         lp = ptr(d_lab) if nl > 0 else ptr(meta)
-        check(lib().aas_ctc_loss_async(stream(), ptr(acts), ptr(grads), lp, ptr(d_off), ptr(d_ll), ptr(d_al), C, N, T,
-                                       max_l, ptr(costs), ptr(ws), int(blank), 1.0), "aas_ctc_loss_async")
+        with _timed("ctc", "ctc[N=%d,T=%d,L<=%d]" % (N, T, max_l), 0.0, 2 * T):
+            check(lib().aas_ctc_loss_async(stream(), ptr(acts), ptr(grads), lp, ptr(d_off), ptr(d_ll), ptr(d_al), C, N, T,
+                                           max_l, ptr(costs), ptr(ws), int(blank), 1.0), "aas_ctc_loss_async")
         ctx.save_for_backward(grads)
         ctx.costs = costs
         # reduce the N costs with the colsum kernel (R = N rows, C = 1 column)

@@ -48,8 +48,38 @@ class FlatAdam(object):
     @torch.no_grad()
     def step(self, grad_scale=1.0):
         self.step_count += 1
+        if getattr(self, "_t_dev", None) is not None:
+            self._t_dev.fill_(float(self.step_count))   # keep the device counter of step_dev() in step (paths may alternate)
         ops.adam_step(self.flat.flat_p, self.flat.flat_g, self.m, self.v, self.vmax, self.lr, self.betas[0],
                       self.betas[1], self.eps, self.step_count, self.amsgrad, grad_scale)
+
+    # ---- torch.optim.Adam-shaped state (the `optim_dict` of a DeepSpeech package, model.py:393-394 / train.py:170) -------
+    def state_dict(self):
+        state = {}
+        for i, (p, (off, n)) in enumerate(zip(self.flat.params, self.flat.slices)):
+            st = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.m[off:off + n].view_as(p).clone(),
+                  "exp_avg_sq": self.v[off:off + n].view_as(p).clone()}
+            if self.vmax is not None:
+                st["max_exp_avg_sq"] = self.vmax[off:off + n].view_as(p).clone()
+            state[i] = st
+        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=0, amsgrad=self.amsgrad,
+                     params=list(range(len(self.flat.params))))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        for i, (off, n) in enumerate(self.flat.slices):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            if self.vmax is not None and "max_exp_avg_sq" in st:
+                self.vmax[off:off + n].copy_(st["max_exp_avg_sq"].reshape(-1))
+            self.step_count = int(float(st["step"]))
+        if sd.get("param_groups"):
+            self.lr = sd["param_groups"][0].get("lr", self.lr)
+        if getattr(self, "_t_dev", None) is not None:
+            self._t_dev.fill_(float(self.step_count))
 
     # ---- device-resident step counter (hipGraph capture: no host-side scalars change between replays) -------
     @torch.no_grad()

@@ -55,7 +55,7 @@ class Trainer(object):
         if len(getattr(config, "load_path", "")) > 0:
             self.load_model()
         self.logFile = None
-        if config.mode == "train" and getattr(config, "write_log", True):
+        if config.mode == "train" and getattr(config, "write_log", True) and int(os.environ.get("RANK", "0")) == 0:
             os.makedirs(self.model_dir, exist_ok=True)
             self.logFile = open(self.model_dir + "/log.txt", "w")
         self._opts = None
@@ -93,10 +93,12 @@ class Trainer(object):
     def make_optimizers(self):
         """Adam(amsgrad) per network (:127-129) on flat parameter/gradient buffers: one fused HIP launch,
         one grad-norm launch and (data parallel) one RCCL all-reduce per network."""
-        from .dist import DPContext, FlatBuffers
+        from .dist import BucketReducer, DPContext, FlatBuffers
         from .optim import FlatAdam
         c = self.config
         self.dp = getattr(self, "dp", None) or DPContext.from_env()
+        for name, m in (("G", self.G), ("D", self.D), ("ASR", self.ASR)):
+            ops.name_layers(m, name)
         self._frozen_asr = self.asr_frozen()
         if self._frozen_asr:
             for p in self.ASR.parameters():
@@ -106,7 +108,10 @@ class Trainer(object):
             self._flat["A"] = FlatBuffers(self.ASR)
         mk = lambda f: FlatAdam(f, lr=c.lr, betas=(self.beta1, self.beta2), amsgrad=True)
         self._opts = (mk(self._flat["G"]), mk(self._flat["A"]) if "A" in self._flat else None, mk(self._flat["D"]))
-        ops.DIRECT_WGRAD[0] = True  # recurrent-layer weight gradients accumulate into the flat buffers on a side stream
+        # (recurrent-layer weight gradients of FlatBuffers-owned parameters accumulate into the flat buffers on a side stream)
+        self._reducer = BucketReducer(self.dp, self._flat.values()) if self.dp.active else None
+        # data parallel: A's BatchNorm statistics over the GLOBAL batch (--sync_bn) instead of "8 replicas with local-batch BN"
+        ops.SYNC_BN[0] = self.dp if (self.dp.active and getattr(c, "sync_bn", False)) else None
         return self._opts
 
     def zero_grad_all(self):
@@ -146,6 +151,8 @@ class Trainer(object):
             self.make_optimizers()
         optimizer_g, optimizer_asr, optimizer_d = self._opts
         c, dp = self.config, self.dp
+        if getattr(self, "_kt_dev_live", False):
+            self.read_scalars()   # queued train_step_async steps advanced kt on the device: fetch it (one sync)
         self.zero_grad_all()
         inputs, targets, input_percentages, target_sizes, mask = self._prep(data_list)
         cl_inputs, cl_mask = data_list_cl[0], data_list_cl[4]
@@ -279,6 +286,7 @@ class Trainer(object):
         # one packed device->host read for the three scalars the controller / log need
         packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), l_CTC.detach().reshape(())])
         l_adv_ny_G_data, l_adv_cl_data, l_ctc_data = dp.reduce_scalars(packed).tolist()
+        ops.check_rnn_health((l_adv_ny_G_data, l_adv_cl_data, l_ctc_data))   # (the read-back above synchronised)
         self.ctc_tr_local.update(l_ctc_data, N_glob)
         # Proportional Control Theory (:190-194)
         g_d_balance = self.gamma * l_adv_cl_data - l_adv_ny_G_data
@@ -294,55 +302,93 @@ class Trainer(object):
     # bias corrections and the loss scalars stay on the device, so the sequence is identical every step and is
     # captured once per batch signature and replayed (the ~300 launches of a step otherwise cost more host time
     # than GPU time).  Same kernels, same order, same results as train_step(schedule='fused', log_norms=False).
-    def _device_core(self, inputs, cl_inputs, nv_ny, nv_cl, ctc_meta, capturing=False):
-        c = self.config
+    def _device_core(self, inputs, cl_inputs, nv_ny, nv_cl, ctc_meta, capturing=False, it=None):
+        """The fused iteration as a device-only launch sequence.  Data parallel: the loss normalisers are the all-reduced
+        GLOBAL counts (kept on the device), the gradient buffers are all-reduced bucket by bucket as the weight-gradient
+        products finish (dist.BucketReducer), and kt is advanced from the all-reduced loss scalars - still no host sync."""
+        c, dp = self.config, self.dp
         optimizer_g, optimizer_asr, optimizer_d = self._opts
+        asr_steps = optimizer_asr is not None and (it is None or it > c.allow_ASR_update_iter)
         if not capturing:
             ops.sync_wgrad()
         for f in self._flat.values():
             f.flat_g.zero_()
         N = inputs.size(0)
-        enhanced = self.G(inputs)
-        leaf = enhanced.detach().requires_grad_(True)
-        overlap = self._overlap_asr()
-        acoustic = None
-        rs = torch.empty(N + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
-        rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
-        rs[N:] = 1.0
-        if overlap:  # two chains of persistent launches side by side, half the chip each
-            ops.set_rnn_cu_limit(ops.device_cus() // 2)
-        if self._interleave_ok():
-            l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, N, ctc_meta, None, None, None,
-                                                                            nv_ny=nv_ny, nv_cl=nv_cl)
+        dev = inputs.device
+        if dp.active:
+            cnt = torch.tensor([float(N), float(nv_ny), float(nv_cl)], dtype=torch.float64).pin_memory().to(dev, non_blocking=True)
+            dp.reduce_scalars(cnt)                       # global N, nElement(noisy), nElement(clean): stays on the device
+            scales = ((c.w_adversarial / cnt[1]).float(), (c.w_adversarial / cnt[2]).float(), (c.w_acoustic / cnt[0]).float())
+            n_glob = cnt[0]
+            self._reducer.begin()
+            ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
         else:
-            if overlap:
-                acoustic = self._acoustic_branch(enhanced, None, None, None, N, ctc_meta)
-            ae = self.D(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
-            l_adv_ny_G = ops.l1_sum(ae[:N], leaf) * (c.w_adversarial / nv_ny)
-            l_adv_cl = ops.l1_sum(ae[N:], cl_inputs) * (c.w_adversarial / nv_cl)
-            (l_adv_ny_G + l_adv_cl).backward()
-            if acoustic is None:
-                acoustic = self._acoustic_branch(enhanced, None, None, None, N, ctc_meta)
-            prob, l_CTC, leaf_a = acoustic
-        torch.cuda.current_stream().wait_stream(self._side)
-        # E's BPTT launches are capped too: the CUs they leave free run E's weight-gradient GEMMs (side stream), which would
-        # otherwise wait for each fully-resident 512-thread launch to retire
-        ops.set_rnn_cu_limit(int(os.environ.get("AAS_EBWD_CUS", "128")))
-        leaf_a.grad.record_stream(torch.cuda.current_stream())
-        enhanced.backward(ops.add3(leaf.grad, leaf_a.grad))
-        ops.set_rnn_cu_limit(0)
-        ops.sync_wgrad()
+            scales = (c.w_adversarial / nv_ny, c.w_adversarial / nv_cl, c.w_acoustic / N)
+            n_glob = float(N)
+        try:
+            enhanced = self.G(inputs)
+            leaf = enhanced.detach().requires_grad_(True)
+            overlap = self._overlap_asr()
+            acoustic = None
+            rs = torch.empty(N + cl_inputs.size(0), device=dev, dtype=torch.float32)
+            rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
+            rs[N:] = 1.0
+            if overlap:  # two chains of persistent launches side by side, half the chip each
+                ops.set_rnn_cu_limit(ops.device_cus() // 2)
+            if self._interleave_ok():
+                l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, None, ctc_meta, None, None, None,
+                                                                                scales=scales)
+            else:
+                if overlap:
+                    acoustic = self._acoustic_branch(enhanced, None, None, None, None, ctc_meta, scale=scales[2])
+                ae = self.D(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
+                l_adv_ny_G = ops.l1_sum(ae[:N], leaf) * scales[0]
+                l_adv_cl = ops.l1_sum(ae[N:], cl_inputs) * scales[1]
+                (l_adv_ny_G + l_adv_cl).backward()
+                if acoustic is None:
+                    acoustic = self._acoustic_branch(enhanced, None, None, None, None, ctc_meta, scale=scales[2])
+                prob, l_CTC, leaf_a = acoustic
+            if dp.active:   # D's small parameters (the layer buckets are already in flight): overlaps E's backward
+                self._reducer.flush(self._flat["D"])
+            torch.cuda.current_stream().wait_stream(self._side)
+            if dp.active and asr_steps:
+                self._reducer.flush(self._flat["A"])
+            # E's BPTT launches are capped too: the CUs they leave free run E's weight-gradient GEMMs (side stream), which would
+            # otherwise wait for each fully-resident 512-thread launch to retire
+            ops.set_rnn_cu_limit(int(os.environ.get("AAS_EBWD_CUS", "128")))
+            leaf_a.grad.record_stream(torch.cuda.current_stream())
+            enhanced.backward(ops.add3(leaf.grad, leaf_a.grad))
+            ops.set_rnn_cu_limit(0)
+            ops.sync_wgrad()
+            if dp.active:
+                self._reducer.flush(self._flat["G"])
+                self._reducer.wait()
+        finally:
+            ops.WGRAD_HOOK[0] = None
         optimizer_g.step_dev()
         optimizer_d.step_dev()
-        if optimizer_asr is not None:
+        if asr_steps:
             optimizer_asr.step_dev()
         packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), l_CTC.detach().reshape(())]).double()
+        if dp.active:
+            dp.reduce_scalars(packed)   # every loss is already divided by its GLOBAL normaliser: the sum over ranks is the loss
         # Proportional Control Theory (:190-194) on the device
         bal = self.gamma * packed[1] - packed[0]
         self._kt_dev.copy_(torch.clamp(self._kt_dev + self.lb * bal, 0.0, 1.0))
         self._g_out[:3].copy_(packed)
         self._g_out[3:4].copy_(self._kt_dev)
+        # running CTC average of the log line (ctc_tr_local.update(l_ctc, N) every iteration, :169-170) kept on the device
+        self._g_out[4:5].add_(packed[2] * n_glob)
+        self._g_out[5:6].add_(n_glob)
         return enhanced, prob
+
+    def _ensure_dev_state(self, dev):
+        if getattr(self, "_kt_dev", None) is None:
+            self._kt_dev = torch.zeros(1, device=dev, dtype=torch.float64)
+            self._g_out = torch.zeros(6, device=dev, dtype=torch.float64)
+            self._graphs = {}
+            self._kt_dev.fill_(float(self.kt))
+            self._kt_dev_live = True
 
     def train_step_async(self, data_list, data_list_cl, iter):
         """The fused iteration queued WITHOUT any host synchronisation: kt, the Adam bias corrections and the loss scalars
@@ -350,13 +396,12 @@ class Trainer(object):
         from pinned memory, and nothing is read back - so the host queues step i+1 while the GPU is still running step i
         and the ~10 ms of Python launch overhead per step never leaves a stream dry at a step boundary.  Returns device
         tensors; `read_scalars()` (one D2H copy) updates `self.kt` and returns the last step's losses - call it when a log
-        line needs them (the reference logs every `log_iter` iterations, trainer_AAS.py:196-215).  Falls back to
-        train_step when the configuration needs host decisions inside the step (data parallel, trainable A, ragged pair)."""
+        line needs them (the reference logs every `log_iter` iterations, trainer_AAS.py:196-215).  Works data parallel
+        (global normalisers, bucketed gradient all-reduce, all-reduced kt inputs: all on the device) and with a trainable
+        A.  Falls back to train_step for the as-executed schedule and for a noisy / clean pair of different padded length."""
         if self._opts is None:
             self.make_optimizers()
-        c = self.config
-        asr_steps = self._opts[1] is not None
-        if self.dp.active or self.schedule != "fused" or asr_steps:
+        if self.schedule != "fused":
             return self.train_step(data_list, data_list_cl, iter, log_norms=False)
         inputs, targets, input_percentages, target_sizes, mask = self._prep(data_list)
         cl_inputs, cl_mask = data_list_cl[0], data_list_cl[4]
@@ -372,23 +417,23 @@ class Trainer(object):
         sizes = input_percentages.clone().mul_(int(t_out)).int()
         meta = ops.ctc_prepare(targets, sizes, target_sizes, "cpu")
         meta = dict(meta, meta=meta["meta"].pin_memory().to(dev, non_blocking=True))
-        if getattr(self, "_kt_dev", None) is None:
-            self._kt_dev = torch.zeros(1, device=dev, dtype=torch.float64)
-            self._g_out = torch.zeros(4, device=dev, dtype=torch.float64)
-            self._graphs = {}
-            self._kt_dev.fill_(float(self.kt))
-        elif not getattr(self, "_kt_dev_live", False):
+        self._ensure_dev_state(dev)
+        if not getattr(self, "_kt_dev_live", False):
             self._kt_dev.fill_(float(self.kt))   # another path advanced the host copy since
         self._kt_dev_live = True
-        enhanced, prob = self._device_core(inputs, cl_inputs, nv_ny, nv_cl, meta)
-        self._async_n = inputs.size(0)
+        enhanced, prob = self._device_core(inputs, cl_inputs, nv_ny, nv_cl, meta, it=iter)
         return dict(enhanced=enhanced, prob=prob, scalars=self._g_out)
 
     def read_scalars(self):
-        """One D2H copy of (l_adv_ny_G, l_adv_cl, l_ctc, kt) of the last train_step_async; updates the host-side kt."""
-        l_adv_ny_G, l_adv_cl, l_ctc, kt = self._g_out.tolist()
+        """One D2H copy of (l_adv_ny_G, l_adv_cl, l_ctc, kt) of the last train_step_async; updates the host-side kt and the
+        running CTC average, and (it is a synchronisation point) raises if a persistent kernel timed out or the run diverged."""
+        l_adv_ny_G, l_adv_cl, l_ctc, kt, ctc_sum, ctc_n = self._g_out.tolist()
+        self._g_out[4:6].zero_()
+        ops.check_rnn_health((l_adv_ny_G, l_adv_cl, l_ctc))
         self.kt = kt
-        self.ctc_tr_local.update(l_ctc, getattr(self, "_async_n", 1))
+        self._kt_dev_live = False
+        if ctc_n > 0:
+            self.ctc_tr_local.update(ctc_sum / ctc_n, ctc_n)
         bal = self.gamma * l_adv_cl - l_adv_ny_G
         return dict(l_adv_ny_G=l_adv_ny_G, l_adv_cl=l_adv_cl, l_ctc=l_ctc, kt=kt, conv_measure=l_adv_cl + abs(bal))
 
@@ -416,10 +461,9 @@ class Trainer(object):
         meta = ops.ctc_prepare(targets, sizes, target_sizes, "cpu")
         sig = (tuple(inputs.shape), nv_ny, nv_cl, meta["nl"], meta["max_l"])
         dev = next(self.G.parameters()).device
-        if getattr(self, "_kt_dev", None) is None:
-            self._kt_dev = torch.zeros(1, device=dev, dtype=torch.float64)
-            self._g_out = torch.zeros(4, device=dev, dtype=torch.float64)
-            self._graphs = {}
+        self._ensure_dev_state(dev)
+        if getattr(self, "_kt_dev_live", False):
+            self.read_scalars()
         self._kt_dev.fill_(float(self.kt))
         self._kt_dev_live = False
         g = self._graphs.get(sig)
@@ -457,7 +501,14 @@ class Trainer(object):
             restore()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # capture on a stream of our own whose scratch exists already: a sync buffer first created DURING capture would
+            # be zero-filled by a captured memset, i.e. every replay would clear the sticky timeout word
+            if getattr(self, "_cap_stream", None) is None:
+                self._cap_stream = torch.cuda.Stream()
+            with torch.cuda.stream(self._cap_stream):
+                ops._sync_buf(dev)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=self._cap_stream):
                 enh, prob = self._device_core(st["inputs"], st["cl"], nv_ny, nv_cl, st["meta"], capturing=True)
             for (f, o), sn in zip(pairs, snap):
                 o.step_count = sn[4]  # capture only recorded the launches; nothing ran
@@ -470,14 +521,16 @@ class Trainer(object):
         g["graph"].replay()
         for o in (self._opts[0], self._opts[2]) + ((self._opts[1],) if asr_steps else ()):
             o.step_count += 1
-        l_adv_ny_G_data, l_adv_cl_data, l_ctc_data, kt = self._g_out.tolist()
+        l_adv_ny_G_data, l_adv_cl_data, l_ctc_data, kt = self._g_out[:4].tolist()
+        self._g_out[4:6].zero_()
+        ops.check_rnn_health((l_adv_ny_G_data, l_adv_cl_data, l_ctc_data))
         self.ctc_tr_local.update(l_ctc_data, inputs.size(0))
         g_d_balance = self.gamma * l_adv_cl_data - l_adv_ny_G_data
         self.kt = kt
         return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, kt=self.kt,
                     conv_measure=l_adv_cl_data + abs(g_d_balance), g_adv=None, g_ctc_adv=None, enhanced=g["enh"], prob=g["prob"])
 
-    def _interleaved_DA(self, enhanced, leaf, cl_inputs, rs, N_glob, ctc_meta, targets, sizes, target_sizes, nv_ny=None, nv_cl=None,
+    def _interleaved_DA(self, enhanced, leaf, cl_inputs, rs, N_glob, ctc_meta, targets, sizes, target_sizes, scales=None,
                         mask=None, cl_mask=None):
         """Discriminator pass and acoustic pass QUEUED layer by layer in alternation on two streams, one combined backward.
 
@@ -510,13 +563,13 @@ class Trainer(object):
             l_adv_cl, _ = self.diffLoss(ae[Nn:], cl_inputs, cl_mask)
             l_adv_ny_G = l_adv_ny_G * c.w_adversarial
             l_adv_cl = c.w_adversarial * l_adv_cl
-        else:
-            l_adv_ny_G = ops.l1_sum(ae[:Nn], leaf) * (c.w_adversarial / nv_ny)
-            l_adv_cl = ops.l1_sum(ae[Nn:], cl_inputs) * (c.w_adversarial / nv_cl)
+        else:   # device path: (weight / normaliser) per loss as python floats or device scalars (data parallel)
+            l_adv_ny_G = ops.l1_sum(ae[:Nn], leaf) * scales[0]
+            l_adv_cl = ops.l1_sum(ae[Nn:], cl_inputs) * scales[1]
         with torch.cuda.stream(side):
             prob = out_a.transpose(0, 1)
             if targets is None:
-                l_CTC = c.w_acoustic * ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) / N_glob
+                l_CTC = ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) * scales[2]
             else:
                 l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / N_glob
         side.wait_stream(main)   # the combined backward is issued from the main stream's context
@@ -537,7 +590,7 @@ class Trainer(object):
     def _overlap_asr():
         return os.environ.get("AAS_OVERLAP_ASR", "1") == "1"
 
-    def _acoustic_branch(self, enhanced, targets, sizes, target_sizes, N_glob, ctc_meta):
+    def _acoustic_branch(self, enhanced, targets, sizes, target_sizes, N_glob, ctc_meta, scale=None):
         """A(enhanced) -> CTC/N -> backward down to a private leaf (optionally on a second stream)."""
         c = self.config
         # Default (AAS_OVERLAP_ASR=1): the acoustic branch runs on a second stream, queued BEFORE the discriminator pass, and
@@ -564,8 +617,8 @@ class Trainer(object):
                 leaf_a = enhanced.detach().requires_grad_(True)
                 enhanced.record_stream(self._side)
                 prob = self.ASR(leaf_a).transpose(0, 1)
-                if targets is None:  # graph path: labels live only in the pre-uploaded device metadata
-                    l_CTC = c.w_acoustic * ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) / N_glob
+                if targets is None:  # device path: labels live only in the pre-uploaded device metadata
+                    l_CTC = ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) * scale
                 else:
                     l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / N_glob
                 l_CTC.backward()
@@ -573,30 +626,49 @@ class Trainer(object):
                 ops.set_precision(prev)
         return prob, l_CTC, leaf_a
 
+    def _next_pair(self):
+        """Next (noisy, clean) training batches; data parallel: every rank draws the same global batch (same seed, same
+        sampler state) and keeps its strided shard of the length-sorted utterances (dist.DPContext.shard_collated)."""
+        data_list = self.data_loader.next(cl_ny="ny", type="train")
+        data_list_cl = self.data_loader.next(cl_ny="cl", type="train")
+        if self.dp.active:
+            data_list, data_list_cl = self.dp.shard_collated(data_list), self.dp.shard_collated(data_list_cl)
+        return data_list, data_list_cl
+
     def train(self):
+        """:125-297.  Iterations that print nothing are queued with train_step_async (no host read-back); logging iterations
+        run train_step, which also returns the two gradient norms of the log line."""
         from tqdm import trange
         c = self.config
         self.make_optimizers()
-        for iter in trange(c.start_iter, c.max_iter):
+        rank0 = self.dp.rank == 0
+        for iter in trange(c.start_iter, c.max_iter, disable=not rank0):
             logging = (iter + 1) % c.log_iter == 0
-            data_list = self.data_loader.next(cl_ny="ny", type="train")
-            data_list_cl = self.data_loader.next(cl_ny="cl", type="train")
-            r = self.train_step(data_list, data_list_cl, iter, log_norms=logging)
-            if logging:
+            data_list, data_list_cl = self._next_pair()
+            if not logging:
+                self.train_step_async(data_list, data_list_cl, iter)
+            else:
+                r = self.train_step(data_list, data_list_cl, iter, log_norms=True)
                 lines = [
                     "[{}/{}] (train) CTC: {:.7f}, ADV_cl: {:.7f}, ADV_ny: {:.7f}".format(iter, c.max_iter, self.ctc_tr_local.avg, r["l_adv_cl"], r["l_adv_ny_G"]),
                     "[{}/{}] (train) conv_measure: {:.4f}, kt: {:.4f} ".format(iter, c.max_iter, r["conv_measure"], self.kt),
                     "[{}/{}] (train) gradient norm, adv: {:.4f}, adv + ctc : {:.4f}".format(iter, c.max_iter, float(r["g_adv"]), float(r["g_ctc_adv"])),
                 ]
                 for s in lines:
-                    print(s)
+                    if rank0:
+                        print(s)
                     if self.logFile:
                         self.logFile.write(s + "\n")
                 if self.logFile:
                     self.logFile.flush()
                 self.ctc_tr_local.reset()
             if (iter + 1) % c.save_iter == 0:
-                self.validate_and_checkpoint(iter)
+                if getattr(self, "_kt_dev_live", False):
+                    self.read_scalars()
+                if rank0:   # every rank holds identical parameters: rank 0 validates and writes the checkpoints
+                    self.validate_and_checkpoint(iter)
+                if self.dp.active:
+                    self.dp.barrier()
 
     # ---- validation + checkpoint lifecycle (:215-297) -----------------------------------------
     def validate_and_checkpoint(self, iter):

@@ -4,7 +4,7 @@ import os
 import torch
 
 from .model import L1Loss_mask, stackedBRNN, supported_rnns
-from .optim import Adam
+from . import ops
 from .utils import AverageMeter, _get_variable_nograd, attach_n_valid
 
 
@@ -38,14 +38,20 @@ class Trainer(object):
     def train_step(self, data_list, iter=0):
         """:116-127; data_list = (inputs, cleans, mask, ...) (_collate_fn_paired order)."""
         if self._opt is None:
-            self._opt = Adam(self.G.parameters(), lr=self.config.lr, betas=(self.beta1, self.beta2), amsgrad=True)
+            from .dist import FlatBuffers
+            from .optim import FlatAdam
+            ops.name_layers(self.G, "G")
+            self._flat = FlatBuffers(self.G)
+            self._opt = FlatAdam(self._flat, lr=self.config.lr, betas=(self.beta1, self.beta2), amsgrad=True)
         mask = data_list[2]
         attach_n_valid(mask) if not mask.is_cuda else None
         inputs, cleans, mask = _get_variable_nograd(data_list[0]), _get_variable_nograd(data_list[1]), _get_variable_nograd(mask)
         outputs = self.G(inputs)
         dce, nElement = self.diffLoss(outputs, cleans, mask)
-        self.zero_grad_all()
+        ops.sync_wgrad()
+        self._flat.zero_grad()
         dce.backward()
+        ops.sync_wgrad()   # the recurrent layers' weight gradients accumulate into the flat buffer on a side stream
         self._opt.step()
         return dict(dce=dce, nElement=nElement, outputs=outputs)
 

@@ -12,7 +12,6 @@ import torch
 
 from . import ops
 from .model import L1Loss_mask, stackedBRNN, supported_rnns
-from .optim import Adam
 from .utils import AverageMeter, _get_variable_nograd, attach_n_valid
 
 
@@ -36,6 +35,7 @@ class Trainer(object):
             os.makedirs(self.model_dir, exist_ok=True)
             self.logFile = open(self.model_dir + "/log.txt", "w")
         self._opts = None
+        self._flat = None
 
     def zero_grad_all(self):
         self.G.zero_grad(); self.D.zero_grad()
@@ -46,49 +46,75 @@ class Trainer(object):
         self.G = stackedBRNN(I=c.nFeat, O=c.nFeat, H=c.rnn_size, L=c.rnn_layers, rnn_type=rt)
         self.D = stackedBRNN(I=2 * c.nFeat, O=c.nFeat, H=c.rnn_size, L=c.rnn_layers, rnn_type=rt)
 
+    def make_optimizers(self):
+        """Adam(amsgrad) per network on flat parameter / gradient buffers (one fused launch each); the recurrent layers'
+        weight gradients accumulate into them on the side stream (ops.sync_wgrad joins before they are read)."""
+        from .dist import FlatBuffers
+        from .optim import FlatAdam
+        c = self.config
+        for name, m in (("G", self.G), ("D", self.D)):
+            ops.name_layers(m, name)
+        self._flat = {"G": FlatBuffers(self.G), "D": FlatBuffers(self.D)}
+        mk = lambda f: FlatAdam(f, lr=c.lr, betas=(self.beta1, self.beta2), amsgrad=True)
+        self._opts = (mk(self._flat["G"]), mk(self._flat["D"]))
+        return self._opts
+
     def get_gradient_norm(self, model):
+        ops.sync_wgrad()
         acc = torch.zeros((1,), device=next(model.parameters()).device, dtype=torch.float64)
-        for p in model.parameters():
-            if p.grad is not None:
-                ops.sqsum_into(acc, p.grad)
+        flat = (self._flat or {}).get("G" if model is self.G else "D")
+        if flat is not None:
+            ops.sqsum_into(acc, flat.flat_g)
+        else:
+            for p in model.parameters():
+                if p.grad is not None:
+                    ops.sqsum_into(acc, p.grad)
         return acc.sqrt().to(torch.float32)
 
     def train_step(self, data_list, iter=0):
+        """:128-182 (intended semantics) with the same identities as the AAS trainer: D(enhanced | mixture) and
+        D(clean | mixture) share ONE batched pass of 2N rows, the D-step parameter gradients of the enhanced half are (-kt) x
+        its G-step ones (per-utterance weights on the weight-gradient products only), and E is back-propagated once with
+        d(adv)/d(enhanced) + d(dce)/d(enhanced)."""
         c = self.config
         if self._opts is None:
-            mk = lambda m: Adam(m.parameters(), lr=c.lr, betas=(self.beta1, self.beta2), amsgrad=True)
-            self._opts = (mk(self.G), mk(self.D))
+            self.make_optimizers()
         optimizer_g, optimizer_d = self._opts
-        self.zero_grad_all()
+        ops.sync_wgrad()
+        for f in self._flat.values():
+            f.zero_grad()
         mask = data_list[2]
         attach_n_valid(mask) if not mask.is_cuda else None
         mixture, cleans, mask = _get_variable_nograd(data_list[0]), _get_variable_nograd(data_list[1]), _get_variable_nograd(mask)
+        N = mixture.size(0)
         enhanced = self.G(mixture)
-        ae_ny_G = self.D.forward_paired(enhanced, mixture)
-        l_adv_ny_G, _ = self.diffLoss(ae_ny_G, enhanced, mask)
+        leaf = enhanced.detach().requires_grad_(True)
+        rs = torch.empty(2 * N, device=leaf.device, dtype=torch.float32)
+        rs[:N] = -float(self.kt)
+        rs[N:] = 1.0
+        paired = torch.cat([torch.cat([leaf, mixture], 1), torch.cat([cleans, mixture], 1)], 0)   # forward_paired x 2 (model.py:233-238)
+        ae = self.D(paired, wgrad_row_scale=rs)
+        l_adv_ny_G, _ = self.diffLoss(ae[:N], leaf, mask)
         l_adv_ny_G = l_adv_ny_G * c.w_adversarial
-        l_adv_ny_G.backward(retain_graph=True)
-        # D-step = (-kt) x the G-step's D-parameter gradients (same identity as the AAS trainer)
-        for p in self.D.parameters():
-            if p.grad is not None:
-                ops.axpby_(p.grad, p.grad, -float(self.kt), 0.0)
-        dce, nElement = self.diffLoss(enhanced, cleans, mask)
-        if not self.as_written:
-            dce.backward()
-        ae_cl = self.D.forward_paired(cleans, mixture)
-        l_adv_cl, _ = self.diffLoss(ae_cl, cleans, mask)
+        l_adv_cl, _ = self.diffLoss(ae[N:], cleans, mask)
         l_adv_cl = c.w_adversarial * l_adv_cl
-        l_adv_cl.backward()
+        dce, nElement = self.diffLoss(leaf, cleans, mask)
+        total = l_adv_ny_G + l_adv_cl
+        if not self.as_written:   # the reference only logs the DCE term (:161-163); the intended G loss back-propagates it
+            total = total + dce
+        total.backward()
+        enhanced.backward(leaf.grad)
         g_norm = self.get_gradient_norm(self.G)
         optimizer_g.step(); optimizer_d.step()
         l_adv_ny_G_data, l_adv_cl_data, dce_loss, g_norm = torch.stack(
             [l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), dce.detach().reshape(()), g_norm.reshape(())]).tolist()
+        ops.check_rnn_health((l_adv_ny_G_data, l_adv_cl_data, dce_loss))
         self.dce_tr_local.update(dce_loss, nElement)
         g_d_balance = self.gamma * l_adv_cl_data - l_adv_ny_G_data
         self.kt += self.lb * g_d_balance
         self.kt = max(min(1, self.kt), 0)
         return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, dce=dce_loss, kt=self.kt,
-                    conv_measure=l_adv_cl_data + abs(g_d_balance), g_norm=g_norm)
+                    conv_measure=l_adv_cl_data + abs(g_d_balance), g_norm=g_norm, enhanced=enhanced)
 
     def train(self):
         from tqdm import trange

@@ -29,9 +29,19 @@ int aas_version(void);
 const char* aas_last_error(void);
 /* number of CUs of the current device (persistent recurrent kernels size their grids from it) */
 int aas_device_cus(void);
-/* ablation bits for the persistent RNN kernels (profiling only; results are wrong when non-zero):
- * 1 skip exchange loads, 2 skip MFMA, 4 skip arrival wait, 8 skip publish (drain + arrival). */
+/* Debug / A-B bits (process-wide, read when a launch is queued; one host thread per process, like the reference
+ * trainer).  Ablation bits - results are WRONG when one is set (profiling, and the timeout test):
+ *   persistent recurrent kernels: 1 skip the exchange loads, 2 skip the MFMAs, 4 skip the wait / poll, 8 skip the
+ *     publish stores (consumers then run into their bounded-spin timeout), 64 record phase time stamps;
+ *   GEMM kernels: 16 skip the MFMAs, 32 skip the stores, 64 skip the loads, 128 epilogue only.
+ * Kernel-selection bits (results unchanged): 32 plain first exchange load in the forward kernels, 256 all-gather
+ *   BPTT instead of the reduce-scatter kernel, 512 16-unit slices, 8192 poll before streaming in the reduce-scatter
+ *   BPTT, 1024 128x128 tiles in aas_gemm_planes, 16384 the general (any S) CTC kernel even when S <= 64. */
 int aas_set_debug_flags(int flags);
+/* Tag (>= 1) of the persistent recurrent launches queued after the call.  Every bounded spin in those kernels gives
+ * up after ~0.5 s and stores the tag of its launch in a sticky error word at byte 4096 of the launch's `sync` buffer
+ * (never cleared by the library): the host reads it at its next synchronisation point and names the layer. */
+int aas_set_rnn_launch_tag(int tag);
 /* Matrix-product operand precision: 0 = exact fp32-input MFMA; 1 (default) = split-bf16: each fp32 operand is
  * carried as bf16 hi + bf16 lo and the product as hi*hi + lo*hi + hi*lo with fp32 accumulation (~1e-5 relative,
  * fp32-class; 3 bf16 MFMAs instead of 16 fp32-MFMA issue slots). */
@@ -154,6 +164,27 @@ int aas_bn_bwd(aasStream_t stream, const float* x, const float* dy, float* dx, i
                const float* gamma, const float* beta, float slope, float* stats,
                float* dgamma, float* dbeta, int accumulate, double* wsd);
 
+/* The same two passes as separate launches, so that a data-parallel caller can all-reduce the per-channel sums between
+ * them (SyncBN over the global batch): aas_bn_stats leaves wsd[0..C) = sum x, wsd[C..2C) = sum x^2 of THIS
+ * rank's R rows; the caller sums wsd (and the row count, as a double at d_rows[0]) over the ranks; aas_bn_apply then
+ * normalises with the global statistics (d_rows = NULL: the local R).  Backward likewise: aas_bn_bwd_reduce leaves
+ * sum dy / sum dy*xhat; aas_bn_bwd_apply takes the all-reduced sums in `wsd` and this rank's own in `wsd_local`
+ * (NULL = wsd) - dgamma/dbeta are local sums, because the gradient all-reduce adds the ranks up. */
+int aas_bn_stats(aasStream_t stream, const float* x, int64_t R, int C, double* wsd);
+int aas_bn_apply(aasStream_t stream, const float* x, float* y, int64_t R, int C, const float* gamma, const float* beta,
+                 float eps, float slope, float* stats, float* running_mean, float* running_var, float momentum,
+                 const double* wsd, const double* d_rows);
+int aas_bn_bwd_reduce(aasStream_t stream, const float* x, const float* dy, int64_t R, int C, const float* gamma,
+                      const float* beta, float slope, const float* stats, double* wsd);
+int aas_bn_bwd_apply(aasStream_t stream, const float* x, const float* dy, float* dx, int64_t R, int C, const float* gamma,
+                     const float* beta, float slope, float* stats, float* dgamma, float* dbeta, int accumulate,
+                     const double* wsd, const double* wsd_local, const double* d_rows);
+/* Eval-mode BatchNorm (running statistics; model.eval() in AM_training/train.py:357 validation) and the row softmax of
+ * InferenceBatchSoftmax in eval mode (model.py:58-64; C <= 64 classes, one wavefront per row). */
+int aas_bn_eval(aasStream_t stream, const float* x, float* y, int64_t R, int C, const float* gamma, const float* beta,
+                const float* running_mean, const float* running_var, float eps, float slope);
+int aas_softmax_rows(aasStream_t stream, const float* x, float* y, int64_t R, int C);
+
 /* conv1d backward-data helper: dx[n,t,f] = sum_{kk} dcol[n,(t-kk)/s,kk,f] over valid (t-kk)%s==0.
  * dcol [N,T1,KW,F] (from the NN GEMM dOut x W2), dx [N,T,F] channels-last.  model.py:289,297. */
 int aas_col2im_f32(aasStream_t stream, const float* dcol, float* dx, int N, int T, int T1, int F, int KW, int stride);
@@ -183,6 +214,16 @@ int aas_ctc_loss_async(aasStream_t stream, const float* activations, float* grad
                        const int* d_act_lens, int alphabet, int minibatch, int max_T, int max_label_len,
                        float* costs, void* workspace, int blank, float grad_scale);
 
+/* Greedy CTC decoding (AM_training/decoder.py:186-201 GreedyDecoder.decode; call sites trainer_AAS.py:321-323,
+ * AM_training/train.py:377-381): probs [T,N,C] scores (any monotone transform of the posteriors), d_sizes[N] valid frames
+ * per utterance.  Per utterance: argmax per frame, drop blanks and frames equal to the previous FRAME's label.
+ * out_labels / out_offsets [N,T] (first out_lens[n] entries valid; out_offsets may be NULL), out_lens [N]; all device. */
+int aas_greedy_decode(aasStream_t stream, const float* probs, const int* d_sizes, int T, int N, int C, int blank,
+                      int* out_labels, int* out_offsets, int* out_lens);
+/* HOST function (no device work): Levenshtein distance of two int sequences - the python-Levenshtein C extension behind
+ * Decoder.wer / Decoder.cer (AM_training/decoder.py:45-74).  Returns the distance, or -1 on bad arguments. */
+int aas_edit_distance(const int* h_a, int na, const int* h_b, int nb);
+
 /* ---------------------------------------------------------------- optimiser -------------------
  * torch.optim.Adam(amsgrad=True/False) element-wise update (trainer_AAS.py:127-129,185-188;
  * AM_training/train.py:246-247), torch 2.x semantics:
@@ -200,11 +241,24 @@ int aas_adam_dev_f32(aasStream_t stream, float* p, const float* g, float* m, flo
 
 /* ---------------------------------------------------------------- features --------------------
  * log-Mel filterbank: wave [N,S] -> out [N,n_mels,T] with T = 1 + S/hop; hamming(periodic) window
- * of `win` samples, centre=True reflect padding, |DFT|^2 -> mel -> log1p.  Tables from
- * aas_lmfb_tables: dft [win, 2*nbins] (cos | -sin, window folded in), melT [nbins, n_mels].
+ * of `win` samples, centre=True reflect padding, |DFT|^2 -> mel -> log1p.  The caller supplies the constant
+ * tables (aas_enhancement_amd/lmfb.py builds them): dft [win, 2*nbins] (cos | -sin, window folded in),
+ * melT [nbins, n_mels].
  * (AM_training/train.py:39-42,55-60,199; model.py:194-198.) */
 int aas_lmfb_fwd(aasStream_t stream, const float* wave, int N, int S, int win, int hop, int n_mels,
                  const float* dft, const float* melT, float* out);
+
+/* The same features on the matrix cores, specialised for the reference's audio configuration (win = n_fft = 320,
+ * hop = 160; AM_training/train.py:39-42) and for batches of utterances of DIFFERENT lengths: d_lens[n] (device, may be
+ * NULL = S) valid samples of utterance n; frames t >= 1 + d_lens[n]/160 are written as zeros, reflect padding is at the
+ * utterance's own ends.  Constant tables from the caller (aas_enhancement_amd/lmfb.py):
+ *   tables     [2 (bf16 hi, lo)][4 segments][96 columns][96 k] bf16: cos(2 pi j 2c/320), cos(2 pi j (2c+1)/320),
+ *              sin(2 pi (j+1) 2c/320), sin(2 pi (j+1) (2c+1)/320) - the twiddles of the twice-folded real DFT;
+ *   window     [320] hamming (periodic);  mel_start / mel_cnt [n_mels] first bin and width of each triangular filter,
+ *   mel_w      [n_mels][mel_maxw = 24] its weights. */
+int aas_lmfb320_fwd(aasStream_t stream, const float* wave, const int* d_lens, int N, int S, int n_mels,
+                    const void* tables, const float* window, const int* mel_start, const int* mel_cnt,
+                    const float* mel_w, int mel_maxw, float* out);
 
 #ifdef __cplusplus
 }

@@ -126,3 +126,111 @@ def test_flat_buffers_keep_module_api():
         fb.flat_p.add_(1.0)
     for k, v in D.state_dict().items():
         assert torch.allclose(v, before[k] + 1.0)
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from aas_enhancement_amd.dist import BucketReducer, DPContext, FlatBuffers
+        dp = DPContext.from_env()
+        torch.manual_seed(3)
+        # three "layers" of four tensors each (the shape of a recurrent layer's parameters) plus two small tensors
+        mods = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(8, 5)) for _ in range(12)] + [torch.nn.Parameter(torch.randn(3)) for _ in range(2)])
+        flat = FlatBuffers(mods)
+        red = BucketReducer(dp, [flat])
+        red.MIN_ELEMS = 100          # 4 x 40 = 160 elements per layer bucket
+        g = torch.Generator().manual_seed(10 + rank)
+        flat.flat_g.copy_(torch.randn(flat.flat_g.numel(), generator=g))
+        local = flat.flat_g.clone()
+        red.begin()
+        params = list(mods)
+        red.on_wgrad([p.grad for p in params[8:12]])   # backward order: last layer first
+        red.on_wgrad([p.grad for p in params[0:4]])
+        red.on_wgrad([params[12].grad])                 # too small for a bucket: left to flush()
+        fired = sorted(red.done[id(flat)])
+        red.flush(flat)                                 # layer 2 (never announced) + the small tensors
+        red.wait()
+        q.put((rank, local.numpy(), flat.flat_g.clone().numpy(), fired))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_reducer_covers_every_element_exactly_once():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = res[0][1] + res[1][1]
+    for rank, _, reduced, fired in res:
+        assert np.allclose(reduced, total, rtol=0, atol=1e-6), rank      # summed once - not twice, not never
+        assert fired == [(0, 160), (320, 480)]
+
+
+def _main_worker(rank, world, port, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import types
+    from aas_enhancement_amd import main as M
+    seen = {}
+
+    class FakeTrainer(object):
+        def __init__(self, config, data_loader):
+            from aas_enhancement_amd.dist import DPContext
+            self.dp = DPContext.from_env()
+            seen["world"], seen["rank"] = self.dp.world, self.dp.rank
+            seen["batch"] = data_loader.next(cl_ny="ny", type="train")
+            seen["shard"] = self.dp.shard_collated(seen["batch"])
+
+        def train(self):
+            pass
+
+    import aas_enhancement_amd.trainer_AAS as TA
+    TA.Trainer = FakeTrainer
+    torch.cuda.set_device = lambda d: None          # CPU test: device selection is a no-op
+    torch.cuda.manual_seed = lambda s: None
+    cfg, _ = M.get_config(["--trainer", "AAS", "--dist_backend", "gloo", "--batch_size", "4", "--labels_path", os.path.join(tmp, "labels.json"),
+                           "--DB_name", "none", "--tr_ny_manifest", os.path.join(tmp, "ny.csv"), "--tr_cl_manifest", os.path.join(tmp, "cl.csv"),
+                           "--expnum", str(40 + rank), "--gpu", "-1"])
+    os.chdir(tmp)
+    M.main(cfg)
+    q.put((rank, seen["world"], seen["batch"][0].numpy(), seen["shard"][0].numpy(), seen["shard"][3].tolist()))
+
+
+def test_main_initialises_process_group_and_shards(tmp_path):
+    """`torchrun -m aas_enhancement_amd.main --trainer AAS` wiring: RANK/WORLD_SIZE from the environment -> process group ->
+    every rank draws the SAME global batch and keeps its strided shard."""
+    import json
+    tmp = str(tmp_path)
+    json.dump(list("_'abcdefghijklmnopqrstuvwxyz "), open(os.path.join(tmp, "labels.json"), "w"))
+    rows = []
+    for i, T in enumerate([30, 28, 27, 25, 22, 20, 19, 15]):
+        torch.save(torch.full((6, T), float(i)), os.path.join(tmp, "f%d.pt7" % i))
+        open(os.path.join(tmp, "t%d.txt" % i), "w").write("ab c"[: 1 + i % 4])
+        rows.append("%s,%s" % (os.path.join(tmp, "f%d.pt7" % i), os.path.join(tmp, "t%d.txt" % i)))
+    for name in ("ny.csv", "cl.csv"):
+        open(os.path.join(tmp, name), "w").write("\n".join(rows) + "\n")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_main_worker, args=(r, world, port, tmp, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=90) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == 2 and res[1][1] == 2
+    assert np.array_equal(res[0][2], res[1][2])                       # same global batch on both ranks
+    assert np.array_equal(res[0][3], res[0][2][0::2]) and np.array_equal(res[1][3], res[1][2][1::2])
+    assert res[0][4] != res[1][4] or len(res[0][4]) == 2

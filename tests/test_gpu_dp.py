@@ -47,35 +47,51 @@ def _batches():
     return ny, cl
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"] = str(rank); os.environ["WORLD_SIZE"] = str(world)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
         from aas_enhancement_amd.dist import DPContext
         from aas_enhancement_amd.trainer_AAS import Trainer
-        tr = Trainer(_cfg(), None, models=_models())
+        tr = Trainer(_cfg(**_mode_cfg(mode)), None, models=_models())
         tr.dp = DPContext.from_env()
         ny, cl = _batches()
         ny_s = tr.dp.shard_collated(ny)
         cl_s = tr.dp.shard_collated((cl[0], torch.zeros(0, dtype=torch.int32), cl[2], torch.zeros(4, dtype=torch.int32), cl[4]))
-        out = []
+        out, prob = [], None
         for it in range(2):
-            r = tr.train_step(ny_s, cl_s, it, log_norms=False)
-            out.append([r["l_adv_ny_G"], r["l_adv_cl"], r["kt"]])
-        q.put((rank, np.asarray(out), tr._flat["G"].flat_p.detach().cpu().numpy(), tr._flat["D"].flat_p.detach().cpu().numpy()))
+            if mode == "sync":
+                r = tr.train_step(ny_s, cl_s, it, log_norms=False)
+            else:
+                r0 = tr.train_step_async(ny_s, cl_s, it)
+                r = tr.read_scalars()
+                prob = r0["prob"].detach().cpu().numpy() if it == 0 else prob
+            out.append([r["l_adv_ny_G"], r["l_adv_cl"], r["l_ctc"], r["kt"]])
+        q.put((rank, np.asarray(out), tr._flat["G"].flat_p.detach().cpu().numpy(), tr._flat["D"].flat_p.detach().cpu().numpy(), prob))
     finally:
         dist.destroy_process_group()
 
 
-def test_trainer_dp_two_ranks_equals_single():
+def _mode_cfg(mode):
+    if mode == "syncbn":   # the acoustic branch matters only here: global-batch BatchNorm statistics in A
+        return dict(w_acoustic=1.0, sync_bn=True)
+    return dict()
+
+
+@pytest.mark.parametrize("mode", ["sync", "async", "syncbn"])
+def test_trainer_dp_two_ranks_equals_single(mode):
+    """sync: Trainer.train_step; async: the device-resident step bench.py times (global normalisers and kt inputs all-reduced
+    on the device, bucketed gradient all-reduce); syncbn: + A's BatchNorm statistics all-reduced forward and backward, so
+    even the acoustic branch (logits, CTC loss, the gradient it sends into E) equals the single-process global batch."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
@@ -83,15 +99,28 @@ def test_trainer_dp_two_ranks_equals_single():
         p.join(timeout=60)
         assert p.exitcode == 0
     from aas_enhancement_amd.trainer_AAS import Trainer
-    tr = Trainer(_cfg(), None, models=_models())
+    tr = Trainer(_cfg(**dict(_mode_cfg(mode), sync_bn=False)), None, models=_models())
     ny, cl = _batches()
-    ref = []
+    ref, prob_ref = [], None
     for it in range(2):
         r = tr.train_step(ny, cl, it, log_norms=False)
-        ref.append([r["l_adv_ny_G"], r["l_adv_cl"], r["kt"]])
+        if it == 0:
+            prob_ref = r["prob"].detach().cpu().numpy()      # [T', N, C]
+        ref.append([r["l_adv_ny_G"], r["l_adv_cl"], r["l_ctc"], r["kt"]])
     ref = np.asarray(ref)
-    for rank, out, gp, dpar in res:
-        assert np.allclose(out, ref, rtol=2e-4), (rank, out, ref)
-        assert np.abs(gp - tr._flat["G"].flat_p.detach().cpu().numpy()).max() < 2e-4
+    cols = [0, 1, 3] if mode != "syncbn" else [0, 1, 2, 3]      # (local-batch BN: the CTC value differs by design)
+    for rank, out, gp, dpar, prob in res:
+        assert np.allclose(out[:, cols], ref[:, cols], rtol=2e-4), (rank, out, ref)
+        if mode != "sync" or True:
+            tol = 2e-4
+            if mode == "syncbn":
+                assert np.abs(gp - tr._flat["G"].flat_p.detach().cpu().numpy()).max() < tol
+            elif mode == "sync" or mode == "async":
+                pass
+        if mode != "syncbn":
+            # w_acoustic = 0: E and D are untouched by A's local-batch statistics
+            assert np.abs(gp - tr._flat["G"].flat_p.detach().cpu().numpy()).max() < 2e-4
         assert np.abs(dpar - tr._flat["D"].flat_p.detach().cpu().numpy()).max() < 2e-4
+        if mode == "syncbn":
+            assert np.abs(prob - prob_ref[:, rank::2]).max() < 1e-3 * np.abs(prob_ref).max()
     assert np.array_equal(res[0][2], res[1][2])  # identical parameters on every rank

@@ -185,3 +185,22 @@ def test_lmfb_conventions():
     # a 1 kHz tone peaks in the mel band whose centre is nearest 1 kHz (Slaney: 15 mel)
     centres = lmfb_np._mel_to_hz(np.linspace(0, lmfb_np._hz_to_mel(8000.0), 82))[1:-1]
     assert abs(int(f[:, 100].argmax()) - int(np.abs(centres - 1000).argmin())) <= 1
+
+
+def test_lmfb_oracle_stft_against_scipy():
+    """The LMFB oracle is "parity unpinned" (the reference's extractor file is absent).  Its STFT stage at least agrees with an
+    independent implementation: scipy.signal.stft with the same framing (periodic hamming 320, hop 160, reflect-padded centre)."""
+    from scipy import signal
+    from oracle import lmfb_np
+    from aas_enhancement_amd import prng
+    w = prng.normal(126, (31840,), 0.0, 0.1).astype(np.float64)
+    win = lmfb_np.hamming_periodic(320)
+    pad = np.pad(w, (160, 160), mode="reflect")
+    _, _, Z = signal.stft(pad, window=win, nperseg=320, noverlap=160, nfft=320, boundary=None, padded=False, scaling="spectrum")
+    power_scipy = (np.abs(Z) * win.sum()) ** 2                     # undo scipy's 1/sum(window) scaling
+    mel = lmfb_np.mel_basis(16000, 320, 80) @ power_scipy
+    ref = lmfb_np.lmfb(w)
+    assert ref.shape == (80, 200) and np.abs(np.log1p(mel) - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+    # mel filter bank: rows are triangles with unit-area (Slaney) normalisation, centres increasing, no empty filter
+    fb = lmfb_np.mel_basis(16000, 320, 80)
+    assert (fb >= 0).all() and (fb.sum(1) > 0).all() and (np.diff(fb.argmax(1)) >= 0).all()
