@@ -30,8 +30,10 @@ SIGNATURES = {
                      c_int, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_i64],
     "aas_gemm_planes": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                         c_int, c_i64, c_i64, c_i64],
+    "aas_gemm_planes_multi": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64],
     "aas_split_planes": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_int],
     "aas_split_planes_t": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
+    "aas_split_planes_t2": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
     "aas_transpose_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64],
     "aas_swap01_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "aas_add3_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64],

@@ -31,6 +31,9 @@ struct PG {
     int accumulate, splitk, batch;
     int64_t sA, sB, sC;     // batch strides (elements)
     int flags;
+    int multi;              // > 0: `multi` independent problems with their own operand / result pointers (Am/Bm/Cm)
+    const char *Am[4], *Bm[4];
+    float* Cm[4];
 };
 
 constexpr int TK = 32;
@@ -67,9 +70,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_planes_kernel(PG p) {
         kend = min(p.K, (kz + 1) * per * TK);
         if (kbeg >= kend) return;
     }
-    const char* Ap = p.A + bz * p.sA * 4;
-    const char* Bp = p.B + bz * p.sB * 4;
-    float* C = p.C + bz * p.sC;
+    const char* Ap = p.multi ? p.Am[bz] : p.A + bz * p.sA * 4;
+    const char* Bp = p.multi ? p.Bm[bz] : p.B + bz * p.sB * 4;
+    float* C = p.multi ? p.Cm[bz] : p.C + bz * p.sC;
     const float* addend = p.addend ? p.addend + bz * p.sC : nullptr;
     if (p.flags & 128) kend = kbeg;  // ablation: epilogue only
 
@@ -271,7 +274,8 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 // workgroup transposes a 64 (k positions) x 64 (source columns) tile through LDS, so both the fp32 reads and the bf16
 // writes are full 128-byte lines; rs[n] scales source row (t, n).
 __global__ __launch_bounds__(256) void split_rows_t_kernel(const float* __restrict__ src, int64_t ld, int T, int nb, int nbp, int Cc,
-                                                           int64_t Kp, char* __restrict__ planes, const float* __restrict__ rs) {
+                                                           int64_t Kp, char* __restrict__ planes, const float* __restrict__ rs,
+                                                           int64_t tstride) {
     __shared__ float tile[64][65];
     const int c0 = blockIdx.x * 64;
     const int64_t k0 = (int64_t)blockIdx.y * 64;
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256) void split_rows_t_kernel(const float* __restri
         const int t = (int)(kpos / nbp), n = (int)(kpos - (int64_t)t * nbp);
         const int c = c0 + tx;
         float v = 0.f;
-        if (t < T && n < nb && c < Cc) v = src[((int64_t)t * nb + n) * ld + c] * (rs ? rs[n] : 1.f);
+        if (t < T && n < nb && c < Cc) v = src[(int64_t)t * tstride + (int64_t)n * ld + c] * (rs ? rs[n] : 1.f);
         tile[rr][tx] = v;
     }
     __syncthreads();
@@ -316,6 +320,7 @@ extern "C" int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const vo
     p.C = C; p.bias = bias; p.addend = addend; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldd = ldd;
     p.accumulate = accumulate; p.batch = batch; p.sA = strideA; p.sB = strideB; p.sC = strideC; p.splitk = 1;
     p.flags = aas_debug_flags_value();
+    p.multi = 0;
     // 256 x 256 tiles (8 waves) halve the operand bytes per flop that the 128 x 128 kernel pulls through L2 (its bound);
     // they are used when they still give every CU about a tile, else 128 x 128 with split-K when K is deep
     const int64_t big_tiles = (int64_t)cdiv(M, 256) * cdiv(N, 256) * batch;
@@ -349,6 +354,47 @@ extern "C" int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const vo
     return 0;
 }
 
+// `count` (<= 4) independent products of one shape in ONE launch, each with its own operand / result pointers: the four
+// weight-gradient products of a bidirectional recurrent layer (dW_ih, dW_hh per direction) fill the chip together
+// instead of four quarter-size launches.  Always accumulates into C (weight gradients add into the flat buffers).
+extern "C" int aas_gemm_planes_multi(aasStream_t stream, int M, int N, int K, int count, const void* const* h_A,
+                                     const void* const* h_B, float* const* h_C, int64_t lda, int64_t ldb, int64_t ldc) {
+    AAS_CHECK(M >= 0 && N >= 0 && K >= 0 && count >= 1 && count <= 4, "aas_gemm_planes_multi: bad sizes M=%d N=%d K=%d count=%d", M, N, K, count);
+    AAS_CHECK(h_A && h_B && h_C, "aas_gemm_planes_multi: null pointer table");
+    AAS_CHECK(K % 32 == 0 && lda % 32 == 0 && ldb % 32 == 0, "aas_gemm_planes_multi: K, lda, ldb must be multiples of 32");
+    if (M == 0 || N == 0 || K == 0) return 0;
+    PG p = {};
+    for (int i = 0; i < count; ++i) {
+        AAS_CHECK(h_A[i] && h_B[i] && h_C[i], "aas_gemm_planes_multi: null operand %d", i);
+        AAS_CHECK(((reinterpret_cast<uintptr_t>(h_A[i]) | reinterpret_cast<uintptr_t>(h_B[i])) & 127) == 0, "aas_gemm_planes_multi: planes must be 128-byte aligned");
+        p.Am[i] = (const char*)h_A[i]; p.Bm[i] = (const char*)h_B[i]; p.Cm[i] = h_C[i];
+    }
+    p.multi = count;
+    p.A = p.Am[0]; p.B = p.Bm[0]; p.C = p.Cm[0];
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldd = 0; p.accumulate = 1; p.batch = count; p.splitk = 1;
+    p.flags = aas_debug_flags_value();
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t big_tiles = (int64_t)cdiv(M, 256) * cdiv(N, 256) * count;
+    const bool big = big_tiles >= 192 && !(p.flags & 1024);
+    const int bm = big ? 256 : 128, bn = big ? 256 : 128;
+    dim3 grid(cdiv(N, bn), cdiv(M, bm), count);
+    const int blocks = grid.x * grid.y * count;
+    if (!big && blocks < 192 && K >= 1024) {     // too few tiles to fill the chip: split K (atomic accumulation)
+        int want = (384 + blocks - 1) / blocks;
+        const int maxs = K / 512;
+        int sk = want < maxs ? want : maxs;
+        if (sk > 16) sk = 16;
+        if (sk > 1) { p.splitk = sk; grid.z = count * sk; }
+    }
+    int rc;
+    if (big) rc = launch_planes<256, 256, 4, 2, true>(p, grid, s);
+    else if (p.splitk > 1) rc = launch_planes<128, 128, 2, 2, false>(p, grid, s);
+    else rc = launch_planes<128, 128, 2, 2, true>(p, grid, s);
+    AAS_CHECK(rc == 0, "aas_gemm_planes_multi: could not raise the dynamic LDS limit");
+    AAS_LAUNCH_CHECK("aas_gemm_planes_multi");
+    return 0;
+}
+
 extern "C" int aas_split_planes(aasStream_t stream, const float* src, int64_t ld, int64_t rows, int K, int Kp, void* planes,
                                 const float* row_scale, int nb) {
     AAS_CHECK(src && planes && rows >= 0 && K >= 0 && Kp >= K && Kp % 32 == 0, "aas_split_planes: bad arguments (K=%d Kp=%d)", K, Kp);
@@ -363,12 +409,25 @@ extern "C" int aas_split_planes(aasStream_t stream, const float* src, int64_t ld
     return 0;
 }
 
-extern "C" int aas_split_planes_t(aasStream_t stream, const float* src, int64_t ld, int T, int nb, int nbp, int C, int64_t Kp, void* planes,
-                                  const float* row_scale) {
+static int split_planes_t_impl(aasStream_t stream, const float* src, int64_t ld, int T, int nb, int nbp, int C, int64_t Kp, void* planes,
+                               const float* row_scale, int64_t tstride) {
     AAS_CHECK(src && planes && T >= 1 && nb >= 1 && nbp >= nb && nbp % 8 == 0 && C >= 1 && Kp >= (int64_t)T * nbp && Kp % 32 == 0,
               "aas_split_planes_t: bad arguments (T=%d nb=%d nbp=%d C=%d Kp=%lld)", T, nb, nbp, C, (long long)Kp);
     hipLaunchKernelGGL(split_rows_t_kernel, dim3(cdiv(C, 64), (unsigned)((Kp + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src, ld, T, nb, nbp,
-                       C, Kp, (char*)planes, row_scale);
+                       C, Kp, (char*)planes, row_scale, tstride > 0 ? tstride : (int64_t)nb * ld);
     AAS_LAUNCH_CHECK("aas_split_planes_t");
     return 0;
+}
+
+extern "C" int aas_split_planes_t(aasStream_t stream, const float* src, int64_t ld, int T, int nb, int nbp, int C, int64_t Kp, void* planes,
+                                  const float* row_scale) {
+    return split_planes_t_impl(stream, src, ld, T, nb, nbp, C, Kp, planes, row_scale, 0);
+}
+
+// same, with the T blocks of nb rows `tstride` elements apart (blocks that are separate tensors of one flat buffer:
+// the two directions' W_ih as the transposed operand of the input-gradient product)
+extern "C" int aas_split_planes_t2(aasStream_t stream, const float* src, int64_t ld, int64_t tstride, int T, int nb, int nbp, int C,
+                                   int64_t Kp, void* planes, const float* row_scale) {
+    AAS_CHECK(tstride > 0, "aas_split_planes_t2: tstride must be positive");
+    return split_planes_t_impl(stream, src, ld, T, nb, nbp, C, Kp, planes, row_scale, tstride);
 }

@@ -68,16 +68,17 @@ def clear_rnn_timeout():
 
 
 def check_rnn_health(scalars=()):
-    """Call at a host synchronisation point.  A non-finite loss is reported as divergence (a NaN in h also looks like
-    the exchange poison word and would stall every step in the spin timeout); otherwise a raised sticky word names the
-    layer whose exchange timed out - its gradients are garbage and training must not continue."""
+    """Call at a host synchronisation point.  A raised sticky word names the layer whose exchange timed out - its
+    gradients are garbage and training must not continue; a non-finite loss without it is reported as divergence."""
     import math
-    if any(not math.isfinite(float(v)) for v in scalars):
-        raise FloatingPointError("training diverged: non-finite loss scalars %r" % (list(scalars),))
+    # (a NaN that training itself produced is published as a quiet-NaN bit pattern, never as the exchange's poison word
+    #  0xFFFFFFFF / tag 3, so it cannot raise the sticky word: the word means a launch really waited ~0.5 s in vain)
     bad = rnn_timeout_layers()
     if bad:
         raise RuntimeError("persistent recurrent kernel: cross-CU exchange timed out in %s (results of this step are invalid)"
                            % ", ".join(bad))
+    if any(not math.isfinite(float(v)) for v in scalars):
+        raise FloatingPointError("training diverged: non-finite loss scalars %r" % (list(scalars),))
 
 
 def _xchg_buf(dev, T, N, H, G):
@@ -259,6 +260,25 @@ def split_planes_t(x3d, T, nb, C, ld=None, row_scale=None, off=0, extra=0):
     return Planes(buf, C, T * nbp, Kp), nbp
 
 
+def split_planes_t_into(buf_rows, x3d, T, nb, nbp, C, Kp, ld=None, row_scale=None, off=0, tstride=0):
+    """aas_split_planes_t[2] into rows [0, C) of an existing plane buffer view `buf_rows` (bf16 [C, 2*Kp])."""
+    if tstride:
+        check(lib().aas_split_planes_t2(stream(), x3d.data_ptr() + 4 * off, ld if ld is not None else C, tstride, T, nb, nbp, C, Kp,
+                                        ptr(buf_rows), ptr(row_scale)), "aas_split_planes_t2")
+    else:
+        check(lib().aas_split_planes_t(stream(), x3d.data_ptr() + 4 * off, ld if ld is not None else C, T, nb, nbp, C, Kp,
+                                       ptr(buf_rows), ptr(row_scale)), "aas_split_planes_t")
+
+
+def gemm_planes_multi(M, N, K, items, lda, ldb, ldc):
+    """items: list (<= 4) of (A_ptr, B_ptr, C_ptr) device byte addresses; C_i[M,N] += A_i[M,K] B_i[N,K]^T in ONE launch."""
+    import ctypes
+    n = len(items)
+    arr = lambda k: (ctypes.c_void_p * n)(*[int(it[k]) for it in items])
+    with _timed("gemm", "gemm_planes_wgrad", 2.0 * M * N * K * n):
+        check(lib().aas_gemm_planes_multi(stream(), M, N, K, n, arr(0), arr(1), arr(2), lda, ldb, ldc), "aas_gemm_planes_multi")
+
+
 def gemm_planes(M, N, K, A, B, C, ldc, bias=None, addend=None, ldd=0, accumulate=False, batch=1, sA=0, sB=0, sC=0,
                 a_off=0, b_off=0, c_off=0, lda=None, ldb=None):
     """C[M,N] (+)= A[M,K] B[N,K]^T on Planes operands; K is the k extent actually multiplied (multiple of 32);
@@ -416,6 +436,27 @@ def linear_rows(x, W, b=None, rs=None):
 
 # --------------------------------------------------------------------------------------- RNN layers
 PLANES_PRE = [os.environ.get("AAS_PLANES_PRE", "1") == "1"]   # input projections of the recurrent layers on the plane GEMM
+PLANES_BWD = [os.environ.get("AAS_PLANES_BWD", "1") == "1"]   # their input-gradient and weight-gradient products too
+
+
+def _wih_t_planes(w_ih, w_ih_r, GH, I):
+    """[W_ih ; W_ih_rev]^T as planes [I rows][k = d*GH + g] (the B operand of dx = d(gates) W_ih); frozen weights once."""
+    frozen = not (w_ih.requires_grad or w_ih_r.requires_grad)
+    sig = (w_ih.data_ptr(), w_ih._version, w_ih_r.data_ptr(), w_ih_r._version, GH, I, "T")
+    ent = getattr(w_ih, "_aas_planes_t", None) if frozen else None
+    if ent is not None and ent[0] == sig:
+        return ent[1]
+    Kp = _kp(2 * GH)
+    buf = torch.empty((I, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
+    dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4
+    split_planes_t_into(buf, w_ih, 2, GH, GH, I, Kp, ld=I, tstride=dw)
+    wt = Planes(buf, I, 2 * GH, Kp)
+    if frozen and not torch.cuda.is_current_stream_capturing():
+        try:
+            w_ih._aas_planes_t = (sig, wt)
+        except Exception:  # noqa: BLE001
+            pass
+    return wt
 
 
 def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0):
@@ -503,10 +544,18 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     x2 = x.view(T * N, I)
     R = T * N
     dx = None
+    use_planes = (_precision[0] == 1 and PLANES_BWD[0] and R >= 1024 and H >= 64 and I >= 64 and GH % 8 == 0
+                  and (w_ih_r.data_ptr() - w_ih.data_ptr()) > 0)
     if need_dx:
         dx = torch.empty((T, N, I), device=dev, dtype=torch.float32)
         dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4
-        if dw > 0 and dw % 4 == 0:
+        if use_planes:
+            # dx[R, I] = d(gates)[R, 2GH] [W_ih ; W_ih_rev]: the NT plane GEMM on a row-major split of d(gates) (one HBM pass)
+            # and the transposed weight planes (2 GH x I elements; cached when the weights are frozen)
+            dga = split_planes(dgx.view(R, 2 * GH), R, 2 * GH)
+            wt = _wih_t_planes(w_ih, w_ih_r, GH, I)
+            gemm_planes(R, I, dga.Kp, dga, wt, dx, I, addend=dy if residual else None, ldd=I)
+        elif dw > 0 and dw % 4 == 0:
             # dx = [dg_fwd | dg_rev] (K = 2GH) x [W_ih ; W_ih_rev]: one launch, B rows addressed two-level
             gemm(NN, R, I, 2 * GH, dgx, 2 * GH, w_ih, I, dx, I, addend=dy if residual else None, ldd=I, kdivB=GH, kouterB=dw)
         else:
@@ -515,9 +564,45 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     if not need_dw:
         return dx, None, None, None, None
 
+    def wgrads_planes(out):
+        """The four weight-gradient products as ONE multi-problem plane GEMM: d(gates)^T (per-utterance weights folded into
+        the transposing split - no scale_rows pass) against x^T and the time-shifted h^T planes, accumulated into `out`."""
+        nbp = (N + 31) // 32 * 32                      # k offsets are whole 32-blocks: one time step = nbp k positions
+        K = T * nbp
+        Kp = _kp(K + nbp)                              # + one zero time step behind the data: room for the shifted windows
+        bf = torch.bfloat16
+        dgT = torch.empty((2 * GH, 2 * Kp), device=dev, dtype=bf)
+        split_planes_t_into(dgT, dgx, T, N, nbp, 2 * GH, Kp, ld=2 * GH, row_scale=rs)
+        if dgh is not dgx:
+            dghT = torch.empty((2 * GH, 2 * Kp), device=dev, dtype=bf)
+            split_planes_t_into(dghT, dgh, T, N, nbp, 2 * GH, Kp, ld=2 * GH, row_scale=rs)
+        else:
+            dghT = dgT
+        xT = torch.empty((I, 2 * Kp), device=dev, dtype=bf)
+        split_planes_t_into(xT, x2, T, N, nbp, I, Kp, ld=I)
+        hT = torch.empty((2 * H, 2 * Kp), device=dev, dtype=bf)
+        split_planes_t_into(hT, hout, T, N, nbp, H, Kp, ld=H)                          # h_fwd
+        split_planes_t_into(hT[H:], hout, T, N, nbp, H, Kp, ld=H, off=T * N * H)       # h_rev
+        row = 4 * Kp                                   # bytes per plane row
+        a_f, a_r = dgT.data_ptr(), dgT.data_ptr() + GH * row
+        ah_f, ah_r = dghT.data_ptr(), dghT.data_ptr() + GH * row
+        shift = nbp * 4                                # one time step inside a row, in bytes (hi | lo interleaved per 32-block)
+        ih = [(a_f, xT.data_ptr(), out[0].data_ptr()), (a_r, xT.data_ptr(), out[2].data_ptr())]
+        # forward direction: sum_{t>=1} dg[t]^T h_f[t-1] -> A window starts one step in; reverse: dg[t]^T h_r[t+1] -> B window does
+        hh = [(ah_f + shift, hT.data_ptr(), out[1].data_ptr()), (ah_r, hT.data_ptr() + H * row + shift, out[3].data_ptr())]
+        if I == H:
+            gemm_planes_multi(GH, H, K, ih + hh, Kp, Kp, H)
+        else:
+            gemm_planes_multi(GH, I, K, ih, Kp, Kp, I)
+            gemm_planes_multi(GH, H, K, hh, Kp, Kp, H)
+        for t_ in (dgT, dghT, xT, hT):
+            t_.record_stream(torch.cuda.current_stream())
+
     def wgrads(out, acc):
         if _SKIP_WGRAD:  # timing experiment only (AAS_SKIP_WGRAD=1): how much of the step the weight-gradient products hold
             return
+        if use_planes and acc and T > 1:
+            return wgrads_planes(out)
         if rs is not None:  # per-utterance weights on the parameter gradients only (dx used the unscaled d(gates))
             scale_rows(dgx, rs, N, out=dgx)
             if dgh is not dgx:

@@ -84,10 +84,19 @@ int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K,
 int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
                     float* C, int64_t ldc, const float* bias, const float* addend, int64_t ldd, int accumulate,
                     int batch, int64_t strideA, int64_t strideB, int64_t strideC);
+/* `count` (<= 4) products of one shape in ONE launch, each with its own plane operands and result (HOST arrays of
+ * device pointers); always accumulates: C_i[M,N] += A_i[M,K] B_i[N,K]^T.  The four weight-gradient products of a
+ * bidirectional recurrent layer (dW_ih, dW_hh per direction; model.py:73-74,94-95 backward) run as one launch. */
+int aas_gemm_planes_multi(aasStream_t stream, int M, int N, int K, int count, const void* const* h_A,
+                          const void* const* h_B, float* const* h_C, int64_t lda, int64_t ldb, int64_t ldc);
 int aas_split_planes(aasStream_t stream, const float* src, int64_t ld, int64_t rows, int K, int Kp, void* planes,
                      const float* row_scale, int nb);
 int aas_split_planes_t(aasStream_t stream, const float* src, int64_t ld, int T, int nb, int nbp, int C, int64_t Kp,
                        void* planes, const float* row_scale);
+/* aas_split_planes_t with the T blocks of nb source rows `tstride` elements apart (row (t, n) at src + t*tstride + n*ld):
+ * [W_ih ; W_ih_reverse] - two tensors of one flat parameter buffer - as the transposed operand of dx = d(gates) W_ih. */
+int aas_split_planes_t2(aasStream_t stream, const float* src, int64_t ld, int64_t tstride, int T, int nb, int nbp, int C,
+                        int64_t Kp, void* planes, const float* row_scale);
 
 /* ---------------------------------------------------------------- layout / elementwise --------
  * out[b, c, r] = in[b, r, c]  with element strides (in: isb, isr, c contiguous; out: osb, osc, r
