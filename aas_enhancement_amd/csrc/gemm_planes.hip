@@ -414,7 +414,7 @@ static int split_planes_t_impl(aasStream_t stream, const float* src, int64_t ld,
     AAS_CHECK(src && planes && T >= 1 && nb >= 1 && nbp >= nb && nbp % 8 == 0 && C >= 1 && Kp >= (int64_t)T * nbp && Kp % 32 == 0,
               "aas_split_planes_t: bad arguments (T=%d nb=%d nbp=%d C=%d Kp=%lld)", T, nb, nbp, C, (long long)Kp);
     hipLaunchKernelGGL(split_rows_t_kernel, dim3(cdiv(C, 64), (unsigned)((Kp + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src, ld, T, nb, nbp,
-                       C, Kp, (char*)planes, row_scale, tstride > 0 ? tstride : (int64_t)nb * ld);
+                       C, Kp, (char*)planes, row_scale, tstride != 0 ? tstride : (int64_t)nb * ld);
     AAS_LAUNCH_CHECK("aas_split_planes_t");
     return 0;
 }
@@ -428,6 +428,6 @@ extern "C" int aas_split_planes_t(aasStream_t stream, const float* src, int64_t 
 // the two directions' W_ih as the transposed operand of the input-gradient product)
 extern "C" int aas_split_planes_t2(aasStream_t stream, const float* src, int64_t ld, int64_t tstride, int T, int nb, int nbp, int C,
                                    int64_t Kp, void* planes, const float* row_scale) {
-    AAS_CHECK(tstride > 0, "aas_split_planes_t2: tstride must be positive");
+    AAS_CHECK(tstride != 0, "aas_split_planes_t2: tstride must be non-zero (it may be negative)");
     return split_planes_t_impl(stream, src, ld, T, nb, nbp, C, Kp, planes, row_scale, tstride);
 }

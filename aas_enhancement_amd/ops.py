@@ -545,7 +545,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     R = T * N
     dx = None
     use_planes = (_precision[0] == 1 and PLANES_BWD[0] and R >= 1024 and H >= 64 and I >= 64 and GH % 8 == 0
-                  and (w_ih_r.data_ptr() - w_ih.data_ptr()) > 0)
+                  and w_ih_r.data_ptr() != w_ih.data_ptr() and (w_ih_r.data_ptr() - w_ih.data_ptr()) % 4 == 0)
     if need_dx:
         dx = torch.empty((T, N, I), device=dev, dtype=torch.float32)
         dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4

@@ -388,7 +388,7 @@ class Trainer(object):
             self._g_out = torch.zeros(6, device=dev, dtype=torch.float64)
             self._graphs = {}
             self._kt_dev.fill_(float(self.kt))
-            self._kt_dev_live = True
+            self._kt_dev_live = False   # the host copy is the current one until a device-resident step has run
 
     def train_step_async(self, data_list, data_list_cl, iter):
         """The fused iteration queued WITHOUT any host synchronisation: kt, the Adam bias corrections and the loss scalars

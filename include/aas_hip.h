@@ -93,7 +93,8 @@ int aas_split_planes(aasStream_t stream, const float* src, int64_t ld, int64_t r
                      const float* row_scale, int nb);
 int aas_split_planes_t(aasStream_t stream, const float* src, int64_t ld, int T, int nb, int nbp, int C, int64_t Kp,
                        void* planes, const float* row_scale);
-/* aas_split_planes_t with the T blocks of nb source rows `tstride` elements apart (row (t, n) at src + t*tstride + n*ld):
+/* aas_split_planes_t with the T blocks of nb source rows `tstride` (non-zero, may be negative) elements apart (row (t, n) at
+ * src + t*tstride + n*ld):
  * [W_ih ; W_ih_reverse] - two tensors of one flat parameter buffer - as the transposed operand of dx = d(gates) W_ih. */
 int aas_split_planes_t2(aasStream_t stream, const float* src, int64_t ld, int64_t tstride, int T, int nb, int nbp, int C,
                         int64_t Kp, void* planes, const float* row_scale);
