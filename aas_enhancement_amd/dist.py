@@ -152,6 +152,11 @@ class BucketReducer(object):
     def begin(self):
         self.handles = []
         self.done = {id(f): [] for f in self.flats}
+        self.expected, self.seen = {}, {}
+
+    def expect(self, flat, times):
+        """Layers of `flat` are back-propagated `times` times this step (two D passes): reduce a bucket after the last one."""
+        self.expected[id(flat)] = int(times)
 
     def _locate(self, grads):
         for f in self.flats:
@@ -166,6 +171,10 @@ class BucketReducer(object):
     def on_wgrad(self, grads):
         f, lo, hi, n = self._locate(grads)
         if f is None or hi - lo != n or n < self.MIN_ELEMS:
+            return
+        k = (id(f), lo)
+        self.seen[k] = self.seen.get(k, 0) + 1
+        if self.seen[k] < self.expected.get(id(f), 1):
             return
         self.handles.append(self.dp.allreduce_sum_(f.flat_g[lo:hi], async_op=True))
         self.done[id(f)].append((lo, hi))

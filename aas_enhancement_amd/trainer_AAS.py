@@ -326,38 +326,10 @@ class Trainer(object):
             scales = (c.w_adversarial / nv_ny, c.w_adversarial / nv_cl, c.w_acoustic / N)
             n_glob = float(N)
         try:
-            enhanced = self.G(inputs)
-            leaf = enhanced.detach().requires_grad_(True)
-            overlap = self._overlap_asr()
-            acoustic = None
-            rs = torch.empty(N + cl_inputs.size(0), device=dev, dtype=torch.float32)
-            rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
-            rs[N:] = 1.0
-            if overlap:  # two chains of persistent launches side by side, half the chip each
-                ops.set_rnn_cu_limit(ops.device_cus() // 2)
-            if self._interleave_ok():
-                l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, None, ctc_meta, None, None, None,
-                                                                                scales=scales)
+            if self._lanes_ok():
+                enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC = self._two_lane_core(inputs, cl_inputs, scales, ctc_meta, asr_steps)
             else:
-                if overlap:
-                    acoustic = self._acoustic_branch(enhanced, None, None, None, None, ctc_meta, scale=scales[2])
-                ae = self.D(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
-                l_adv_ny_G = ops.l1_sum(ae[:N], leaf) * scales[0]
-                l_adv_cl = ops.l1_sum(ae[N:], cl_inputs) * scales[1]
-                (l_adv_ny_G + l_adv_cl).backward()
-                if acoustic is None:
-                    acoustic = self._acoustic_branch(enhanced, None, None, None, None, ctc_meta, scale=scales[2])
-                prob, l_CTC, leaf_a = acoustic
-            if dp.active:   # D's small parameters (the layer buckets are already in flight): overlaps E's backward
-                self._reducer.flush(self._flat["D"])
-            torch.cuda.current_stream().wait_stream(self._side)
-            if dp.active and asr_steps:
-                self._reducer.flush(self._flat["A"])
-            # E's BPTT launches are capped too: the CUs they leave free run E's weight-gradient GEMMs (side stream), which would
-            # otherwise wait for each fully-resident 512-thread launch to retire
-            ops.set_rnn_cu_limit(int(os.environ.get("AAS_EBWD_CUS", "128")))
-            leaf_a.grad.record_stream(torch.cuda.current_stream())
-            enhanced.backward(ops.add3(leaf.grad, leaf_a.grad))
+                enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC = self._batched_D_core(inputs, cl_inputs, scales, ctc_meta, asr_steps)
             ops.set_rnn_cu_limit(0)
             ops.sync_wgrad()
             if dp.active:
@@ -381,6 +353,112 @@ class Trainer(object):
         self._g_out[4:5].add_(packed[2] * n_glob)
         self._g_out[5:6].add_(n_glob)
         return enhanced, prob
+
+    def _batched_D_core(self, inputs, cl_inputs, scales, ctc_meta, asr_steps):
+        """D(enhanced) and D(clean) as ONE batched pass of 2N rows beside the acoustic chain (the round-1 schedule; needs
+        equal padded lengths).  Kept for hipGraph capture and as the A/B reference of the two-lane schedule."""
+        dp = self.dp
+        N, dev = inputs.size(0), inputs.device
+        enhanced = self.G(inputs)
+        leaf = enhanced.detach().requires_grad_(True)
+        overlap = self._overlap_asr()
+        acoustic = None
+        rs = torch.empty(N + cl_inputs.size(0), device=dev, dtype=torch.float32)
+        rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
+        rs[N:] = 1.0
+        if overlap:  # two chains of persistent launches side by side, half the chip each
+            ops.set_rnn_cu_limit(ops.device_cus() // 2)
+        if self._interleave_ok():
+            l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, None, ctc_meta, None, None, None,
+                                                                            scales=scales)
+        else:
+            if overlap:
+                acoustic = self._acoustic_branch(enhanced, None, None, None, None, ctc_meta, scale=scales[2])
+            ae = self.D(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
+            l_adv_ny_G = ops.l1_sum(ae[:N], leaf) * scales[0]
+            l_adv_cl = ops.l1_sum(ae[N:], cl_inputs) * scales[1]
+            (l_adv_ny_G + l_adv_cl).backward()
+            if acoustic is None:
+                acoustic = self._acoustic_branch(enhanced, None, None, None, None, ctc_meta, scale=scales[2])
+            prob, l_CTC, leaf_a = acoustic
+        if dp.active:   # D's small parameters (the layer buckets are already in flight): overlaps E's backward
+            self._reducer.flush(self._flat["D"])
+        torch.cuda.current_stream().wait_stream(self._side)
+        if dp.active and asr_steps:
+            self._reducer.flush(self._flat["A"])
+        # E's BPTT launches are capped too: the CUs they leave free run E's weight-gradient GEMMs (side stream), which would
+        # otherwise wait for each fully-resident 512-thread launch to retire
+        ops.set_rnn_cu_limit(int(os.environ.get("AAS_EBWD_CUS", "128")))
+        leaf_a.grad.record_stream(torch.cuda.current_stream())
+        enhanced.backward(ops.add3(leaf.grad, leaf_a.grad))
+        return enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC
+
+    def _lanes_ok(self):
+        return self._interleave_ok() and os.environ.get("AAS_TWO_LANES", "1") == "1"
+
+    def _two_lane_core(self, inputs, cl_inputs, scales, ctc_meta, asr_steps):
+        """The step as two lanes of half-chip persistent launches that are busy from the first kernel to the last:
+
+            main stream:  E forward      -> D(enhanced) forward -> D(enhanced) backward -> E backward
+            side stream:  D(clean) fwd   -> A forward + CTC     -> A backward           -> D(clean) backward
+
+        D(clean) needs nothing from E, so its forward fills the half of the chip that idles during E's forward and its
+        backward the half that idles during E's backward; D then runs N rows per launch instead of 2N (a persistent launch
+        on a fixed CU budget slows down with the rows per workgroup: BPTT 3.7 -> 6.2 us / step from N=30 to N=60), and
+        the noisy / clean batches may have different padded lengths.  The D-step parameter gradients of the enhanced pass
+        are (-kt) x its G-step ones (per-utterance weights on the weight-gradient products, as before); both passes
+        accumulate into D's flat gradient buffer on the weight-gradient stream.  Every pair of neighbouring chains is
+        QUEUED layer by layer in alternation (forward: generators; backward: one autograd call per pair, whose nodes pop
+        in reverse creation order), because the device only overlaps what the host has already queued."""
+        c, dp = self.config, self.dp
+        N, dev = inputs.size(0), inputs.device
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side = self._side_stream
+        side.wait_stream(main)
+        ops.set_rnn_cu_limit(ops.device_cus() // 2)
+        if dp.active:
+            self._reducer.expect(self._flat["D"], 2)      # every D layer is back-propagated twice: reduce after the second
+        rs = (-self._kt_dev).to(torch.float32).expand(N).contiguous()
+
+        def alternate(gen_main, gen_side):
+            a = b = None
+            while a is None or b is None:
+                if a is None:
+                    a = next(gen_main)
+                if b is None:
+                    with torch.cuda.stream(side):
+                        b = next(gen_side)
+            return a, b
+        # ---- E forward beside D(clean) forward
+        enhanced, ae_cl = alternate(self.G.forward_stages(inputs), self.D.forward_stages(cl_inputs))
+        with torch.cuda.stream(side):
+            l_adv_cl = ops.l1_sum(ae_cl, cl_inputs) * scales[1]
+        # ---- D(enhanced) forward beside A forward (+ CTC)
+        leaf = enhanced.detach().requires_grad_(True)
+        leaf_a = enhanced.detach().requires_grad_(True)
+        side.wait_stream(main)
+        enhanced.record_stream(side)
+        ae_ny, out_a = alternate(self.D.forward_stages(leaf, wgrad_row_scale=rs), self.ASR.forward_stages(leaf_a))
+        l_adv_ny_G = ops.l1_sum(ae_ny, leaf) * scales[0]
+        with torch.cuda.stream(side):
+            prob = out_a.transpose(0, 1)
+            l_CTC = ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) * scales[2]
+        # ---- their backward passes, alternating (nodes pop in reverse creation order, each on its forward's stream)
+        torch.autograd.backward([l_adv_ny_G, l_CTC])
+        if dp.active and asr_steps:
+            with torch.cuda.stream(side):
+                self._reducer.flush(self._flat["A"])
+        # ---- E backward beside D(clean) backward
+        main.wait_stream(side)          # A's gradient wrt enhanced (everything queued on the side stream so far)
+        leaf_a.grad.record_stream(main)
+        gsum = ops.add3(leaf.grad, leaf_a.grad)
+        torch.autograd.backward([enhanced, l_adv_cl], [gsum, None])
+        main.wait_stream(side)
+        if dp.active:
+            self._reducer.flush(self._flat["D"])
+        return enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC
 
     def _ensure_dev_state(self, dev):
         if getattr(self, "_kt_dev", None) is None:
@@ -409,7 +487,7 @@ class Trainer(object):
             attach_n_valid(cl_mask)
         nv = lambda m: getattr(m, "n_valid", None)
         nv_ny, nv_cl = nv(mask), nv(cl_mask)
-        if nv_ny is None or nv_cl is None or tuple(cl_inputs.shape) != tuple(inputs.shape):
+        if nv_ny is None or nv_cl is None or (tuple(cl_inputs.shape) != tuple(inputs.shape) and not self._lanes_ok()):
             return self.train_step(data_list, data_list_cl, iter, log_norms=False)
         dev = next(self.G.parameters()).device
         cl_inputs = _get_variable_nograd(cl_inputs)
