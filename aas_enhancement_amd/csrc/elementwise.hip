@@ -300,6 +300,45 @@ extern "C" int aas_adam_f32(aasStream_t stream, float* p, const float* g, float*
     return 0;
 }
 
+namespace {
+// one thread: advance the device-resident step counter and derive the step-dependent Adam scalars from it
+__global__ void adam_tick_kernel(double* __restrict__ t, double lr, double b1, double b2, float* __restrict__ hyper) {
+    const double tt = t[0] + 1.0;
+    t[0] = tt;
+    hyper[0] = (float)(lr / (1.0 - pow(b1, tt)));
+    hyper[1] = (float)sqrt(1.0 - pow(b2, tt));
+}
+
+// BEGAN proportional controller on the device (trainer_AAS.py:190-194) + the scalars a later log line needs:
+// out = [l_adv_ny_G, l_adv_cl, l_ctc, kt, running sum of l_ctc * n, running sum of n]
+__global__ void began_step_kernel(const float* __restrict__ l_ny, const float* __restrict__ l_cl, const float* __restrict__ l_ctc,
+                                  double* __restrict__ kt, double* __restrict__ out, double gamma, double lambda_k, double n_batch) {
+    const double a = (double)l_ny[0], b = (double)l_cl[0], c = (double)l_ctc[0];
+    double k = kt[0] + lambda_k * (gamma * b - a);
+    k = k < 0.0 ? 0.0 : (k > 1.0 ? 1.0 : k);
+    kt[0] = k;
+    out[0] = a; out[1] = b; out[2] = c; out[3] = k;
+    out[4] += c * n_batch;
+    out[5] += n_batch;
+}
+}  // namespace
+
+extern "C" int aas_adam_tick(aasStream_t stream, double* d_step, float lr, float beta1, float beta2, float* d_hyper) {
+    AAS_CHECK(d_step && d_hyper, "aas_adam_tick: null pointer");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_step, (double)lr, (double)beta1, (double)beta2, d_hyper);
+    AAS_LAUNCH_CHECK("aas_adam_tick");
+    return 0;
+}
+
+extern "C" int aas_began_step(aasStream_t stream, const float* d_l_adv_ny_G, const float* d_l_adv_cl, const float* d_l_ctc,
+                              double* d_kt, double* d_out6, double gamma, double lambda_k, double n_batch) {
+    AAS_CHECK(d_l_adv_ny_G && d_l_adv_cl && d_l_ctc && d_kt && d_out6, "aas_began_step: null pointer");
+    hipLaunchKernelGGL(began_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_l_adv_ny_G, d_l_adv_cl, d_l_ctc, d_kt, d_out6, gamma,
+                       lambda_k, n_batch);
+    AAS_LAUNCH_CHECK("aas_began_step");
+    return 0;
+}
+
 extern "C" int aas_adam_dev_f32(aasStream_t stream, float* p, const float* g, float* m, float* v, float* vmax, int64_t n,
                                 float beta1, float beta2, float eps, const float* d_hyper, int amsgrad, float grad_scale) {
     AAS_CHECK(p && g && m && v && (vmax || !amsgrad) && d_hyper && n >= 0, "aas_adam_dev_f32: bad args");

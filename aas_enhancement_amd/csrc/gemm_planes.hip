@@ -328,7 +328,9 @@ extern "C" int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const vo
     const int bm = big ? 256 : 128, bn = big ? 256 : 128;
     dim3 grid(cdiv(N, bn), cdiv(M, bm), batch);
     const int blocks = grid.x * grid.y * batch;
-    if (!big && blocks < 384 && K >= 1024) {
+    // split K only when the tiles alone cannot occupy even the half of the chip a lane of the step leaves free: the atomic
+    // epilogue (+ the memset in front of it) costs more than a second round of whole tiles
+    if (!big && blocks < 128 && K >= 1024) {
         int want = (512 + blocks - 1) / blocks;
         const int maxs = K / 256;
         int sk = want < maxs ? want : maxs;

@@ -913,6 +913,17 @@ def adam_step_dev(p, g, m, v, vmax, beta1, beta2, eps, d_hyper, amsgrad=True, gr
                                  float(eps), ptr(d_hyper), int(amsgrad), float(grad_scale)), "aas_adam_dev_f32")
 
 
+def adam_tick(d_step, lr, beta1, beta2, d_hyper):
+    check(lib().aas_adam_tick(stream(), ptr(d_step), float(lr), float(beta1), float(beta2), ptr(d_hyper)), "aas_adam_tick")
+
+
+def began_step(l_ny, l_cl, l_ctc, d_kt, d_out6, gamma, lambda_k, n_batch):
+    f = lambda t: _c(t.detach().reshape(1).to(torch.float32))
+    a, b, c = f(l_ny), f(l_cl), f(l_ctc)
+    check(lib().aas_began_step(stream(), ptr(a), ptr(b), ptr(c), ptr(d_kt), ptr(d_out6), float(gamma), float(lambda_k), float(n_batch)),
+          "aas_began_step")
+
+
 def adam_step(p, g, m, v, vmax, lr, beta1, beta2, eps, step, amsgrad=True, grad_scale=1.0):
     check(lib().aas_adam_f32(stream(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), float(lr), float(beta1),
                              float(beta2), float(eps), int(step), int(amsgrad), float(grad_scale)), "aas_adam_f32")

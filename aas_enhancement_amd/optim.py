@@ -90,11 +90,7 @@ class FlatAdam(object):
             dev = self.flat.flat_p.device
             self._t_dev = torch.full((1,), float(self.step_count), device=dev, dtype=torch.float64)
             self._hyper = torch.zeros(2, device=dev, dtype=torch.float32)
-        self._t_dev.add_(1.0)
-        bc1 = 1.0 - torch.pow(torch.full_like(self._t_dev, self.betas[0]), self._t_dev)
-        bc2 = 1.0 - torch.pow(torch.full_like(self._t_dev, self.betas[1]), self._t_dev)
-        self._hyper[0:1].copy_((self.lr / bc1).to(torch.float32))
-        self._hyper[1:2].copy_(torch.sqrt(bc2).to(torch.float32))
+        ops.adam_tick(self._t_dev, self.lr, self.betas[0], self.betas[1], self._hyper)   # t += 1, bias corrections: one tiny launch
         ops.adam_step_dev(self.flat.flat_p, self.flat.flat_g, self.m, self.v, self.vmax, self.betas[0], self.betas[1],
                           self.eps, self._hyper, self.amsgrad, grad_scale)
         self.step_count += 1

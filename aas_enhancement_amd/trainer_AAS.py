@@ -316,7 +316,7 @@ class Trainer(object):
         N = inputs.size(0)
         dev = inputs.device
         if dp.active:
-            cnt = torch.tensor([float(N), float(nv_ny), float(nv_cl)], dtype=torch.float64).pin_memory().to(dev, non_blocking=True)
+            cnt = self._upload_small(torch.tensor([float(N), float(nv_ny), float(nv_cl)], dtype=torch.float64), dev)
             dp.reduce_scalars(cnt)                       # global N, nElement(noisy), nElement(clean): stays on the device
             scales = ((c.w_adversarial / cnt[1]).float(), (c.w_adversarial / cnt[2]).float(), (c.w_acoustic / cnt[0]).float())
             n_glob = cnt[0]
@@ -341,9 +341,11 @@ class Trainer(object):
         optimizer_d.step_dev()
         if asr_steps:
             optimizer_asr.step_dev()
+        if not dp.active:   # controller + log scalars in one tiny launch
+            ops.began_step(l_adv_ny_G, l_adv_cl, l_CTC, self._kt_dev, self._g_out, self.gamma, self.lb, n_glob)
+            return enhanced, prob
         packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), l_CTC.detach().reshape(())]).double()
-        if dp.active:
-            dp.reduce_scalars(packed)   # every loss is already divided by its GLOBAL normaliser: the sum over ranks is the loss
+        dp.reduce_scalars(packed)   # every loss is already divided by its GLOBAL normaliser: the sum over ranks is the loss
         # Proportional Control Theory (:190-194) on the device
         bal = self.gamma * packed[1] - packed[0]
         self._kt_dev.copy_(torch.clamp(self._kt_dev + self.lb * bal, 0.0, 1.0))
@@ -417,7 +419,7 @@ class Trainer(object):
             self._side_stream = torch.cuda.Stream()
         side = self._side = self._side_stream
         side.wait_stream(main)
-        ops.set_rnn_cu_limit(ops.device_cus() // 2)
+        ops.set_rnn_cu_limit(int(os.environ.get("AAS_LANE_CUS", "0")) or ops.device_cus() // 2)
         if dp.active:
             self._reducer.expect(self._flat["D"], 2)      # every D layer is back-propagated twice: reduce after the second
         rs = (-self._kt_dev).to(torch.float32).expand(N).contiguous()
@@ -494,13 +496,35 @@ class Trainer(object):
         t_out = self.ASR.output_length(inputs.size(2))
         sizes = input_percentages.clone().mul_(int(t_out)).int()
         meta = ops.ctc_prepare(targets, sizes, target_sizes, "cpu")
-        meta = dict(meta, meta=meta["meta"].pin_memory().to(dev, non_blocking=True))
+        meta = dict(meta, meta=self._upload_small(meta["meta"], dev))
         self._ensure_dev_state(dev)
         if not getattr(self, "_kt_dev_live", False):
             self._kt_dev.fill_(float(self.kt))   # another path advanced the host copy since
         self._kt_dev_live = True
         enhanced, prob = self._device_core(inputs, cl_inputs, nv_ny, nv_cl, meta, it=iter)
         return dict(enhanced=enhanced, prob=prob, scalars=self._g_out)
+
+    def _upload_small(self, host, dev):
+        """Asynchronous H2D copy of a small host tensor through a ring of REUSED pinned staging buffers (a fresh
+        pin_memory() per step costs a pinned allocation, and the copy from pageable memory would block the host)."""
+        ring = getattr(self, "_pin_ring", None)
+        if ring is None:
+            ring = self._pin_ring = dict(i=0, slots=[None] * 8)
+        k = ring["i"] % len(ring["slots"])
+        ring["i"] += 1
+        slot = ring["slots"][k]
+        n = host.numel()
+        if slot is None or slot[0].numel() < n or slot[0].dtype != host.dtype:
+            slot = [torch.empty(max(256, 2 * n), dtype=host.dtype).pin_memory(), None]
+            ring["slots"][k] = slot
+        elif slot[1] is not None:
+            slot[1].synchronize()        # the copy that last used this staging buffer (8 uploads ago) has long finished
+        slot[0][:n].copy_(host.reshape(-1))
+        out = slot[0][:n].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        slot[1] = ev
+        return out
 
     def read_scalars(self):
         """One D2H copy of (l_adv_ny_G, l_adv_cl, l_ctc, kt) of the last train_step_async; updates the host-side kt and the

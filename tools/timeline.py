@@ -61,6 +61,20 @@ def main():
     print("\nwall time per step by what is in flight (persistent recurrent launches, any GEMM, any other kernel):")
     for key, ms in sorted(hist.items(), key=lambda kv: -kv[1]):
         print("  %-8s %-5s %-6s %8.3f ms" % (key[0], key[1], key[2], ms / nsteps))
+    # Gantt of the persistent launches of one step (offsets from the step's first kernel)
+    one = [r for r in rows if r[0] >= steps[10] and r[0] < steps[11]]
+    if one:
+        t0 = one[0][0]
+        print("\nrecurrent launches of one step (start ms, duration ms, queue, kernel):")
+        for s_, e_, n_, q_ in one:
+            if is_rnn(n_) or "ctc" in n_ or "adam" in n_:
+                print("  %7.3f  %6.3f  q%-3s %s" % ((s_ - t0) / 1e6, (e_ - s_) / 1e6, q_, short(n_)))
+    if "--dump-step" in sys.argv and one:
+        outp = sys.argv[sys.argv.index("--dump-step") + 1]
+        with open(outp, "w") as f:
+            f.write("start_ms,dur_us,queue,kernel\n")
+            for s_, e_, n_, q_ in one:
+                f.write("%.4f,%.1f,%s,%s\n" % ((s_ - t0) / 1e6, (e_ - s_) / 1e3, q_, short(n_)))
     idle = sum(ms for k, ms in hist.items() if k == ("rnn0", "-", "-")) / nsteps
     no_rnn = sum(ms for k, ms in hist.items() if k[0] == "rnn0") / nsteps
     print("GPU idle %.3f ms / step; no recurrent launch in flight %.3f ms / step" % (idle, no_rnn))
