@@ -46,6 +46,9 @@ SIGNATURES = {
     "aas_rnn_xchg_bytes": [c_int, c_int, c_int, c_int],
     "aas_lstm_fwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "aas_lstm_bwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "aas_lstm_bwd_planes": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp],
+    "aas_gru_bwd_planes": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp],
+    "aas_planes_transpose": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
     "aas_gru_fwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "aas_gru_bwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "aas_bn_fwd": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp],

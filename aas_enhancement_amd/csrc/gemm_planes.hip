@@ -302,7 +302,52 @@ __global__ __launch_bounds__(256) void split_rows_t_kernel(const float* __restri
     }
 }
 
+// The same transposition with PLANES as the source (row-major operand planes written by the BPTT kernels): element
+// (row (t, n), column c) = hi + lo (exact in fp32), times rs[n], re-split into planes[c][t*nbp + n].
+__global__ __launch_bounds__(256) void planes_t_kernel(const char* __restrict__ src, int64_t ldp, int T, int nb, int nbp, int Cc,
+                                                       int64_t Kp, char* __restrict__ planes, const float* __restrict__ rs) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64;
+    const int64_t k0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int64_t kpos = k0 + rr;
+        const int t = (int)(kpos / nbp), n = (int)(kpos - (int64_t)t * nbp);
+        const int c = c0 + tx;
+        float v = 0.f;
+        if (t < T && n < nb && c < Cc) {
+            const char* e = src + ((int64_t)t * nb + n) * ldp * 4 + (c >> 5) * 128 + (c & 31) * 2;
+            const unsigned h = *reinterpret_cast<const unsigned short*>(e), l = *reinterpret_cast<const unsigned short*>(e + 64);
+            v = (__uint_as_float(h << 16) + __uint_as_float(l << 16)) * (rs ? rs[n] : 1.f);
+        }
+        tile[rr][tx] = v;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc;
+        const int64_t kpos = k0 + tx;
+        if (c < Cc && kpos < Kp) {
+            unsigned short h, l;
+            split2(tile[tx][cc], h, l);
+            char* o = planes + (int64_t)c * Kp * 4 + (kpos >> 5) * 128 + (kpos & 31) * 2;
+            *reinterpret_cast<unsigned short*>(o) = h;
+            *reinterpret_cast<unsigned short*>(o + 64) = l;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int aas_planes_transpose(aasStream_t stream, const void* src_planes, int64_t src_ld, int T, int nb, int nbp, int C, int64_t Kp,
+                                    void* planes, const float* row_scale) {
+    AAS_CHECK(src_planes && planes && T >= 1 && nb >= 1 && nbp >= nb && nbp % 8 == 0 && C >= 1 && src_ld % 32 == 0 && src_ld >= C &&
+                  Kp >= (int64_t)T * nbp && Kp % 32 == 0,
+              "aas_planes_transpose: bad arguments (T=%d nb=%d nbp=%d C=%d ld=%lld Kp=%lld)", T, nb, nbp, C, (long long)src_ld, (long long)Kp);
+    hipLaunchKernelGGL(planes_t_kernel, dim3(cdiv(C, 64), (unsigned)((Kp + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const char*)src_planes,
+                       src_ld, T, nb, nbp, C, Kp, (char*)planes, row_scale);
+    AAS_LAUNCH_CHECK("aas_planes_transpose");
+    return 0;
+}
 
 extern "C" int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
                                float* C, int64_t ldc, const float* bias, const float* addend, int64_t ldd, int accumulate, int batch,

@@ -237,17 +237,55 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
             }
         }
         const int par = s & 1;
+        unsigned h16[4] = {0, 0, 0, 0}, l16[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int g = 0; g < G; ++g) split_bf16(xv[g], h16[g], l16[g]);
         if (rowok && s + 1 < T) {  // my d(gates) slice as the split-bf16 A tile of the partial product
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                unsigned h16, l16;
-                split_bf16(xv[g], h16, l16);
-                a_hi[par][row][g * U + unit] = (unsigned short)h16;
-                a_lo[par][row][g * U + unit] = (unsigned short)l16;
+                a_hi[par][row][g * U + unit] = (unsigned short)h16[g];
+                a_lo[par][row][g * U + unit] = (unsigned short)l16[g];
             }
         }
-        // fp32 d(gates) for the layer's GEMMs (plain stores)
-        if (ok) {
+        if (p.dgp1) {
+            // d(gates) for the layer's GEMMs straight in their operand form: row (t, n) of interleaved bf16 hi | lo planes
+            // (per 32-wide k block 64 B of hi then 64 B of lo), k = d*G*H + g*H + unit - no fp32 copy, no split pass
+            if (ok) {
+                char* r1 = reinterpret_cast<char*>(p.dgp1) + tn * (int64_t)p.dgKp * 4;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int k = d * GH + g * H + gunit;
+                    char* o = r1 + (k >> 5) * 128 + (k & 31) * 2;
+                    *reinterpret_cast<unsigned short*>(o) = (unsigned short)h16[g];
+                    *reinterpret_cast<unsigned short*>(o + 64) = (unsigned short)l16[g];
+                }
+                if (!LSTM) {
+                    char* r2 = reinterpret_cast<char*>(p.dgp2) + tn * (int64_t)p.dgKp * 4;
+                    unsigned hn, ln;
+                    split_bf16(dn_keep, hn, ln);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int k = d * GH + g * H + gunit;
+                        char* o = r2 + (k >> 5) * 128 + (k & 31) * 2;
+                        *reinterpret_cast<unsigned short*>(o) = (unsigned short)(g == 2 ? hn : h16[g]);
+                        *reinterpret_cast<unsigned short*>(o + 64) = (unsigned short)(g == 2 ? ln : l16[g]);
+                    }
+                }
+            }
+            // zero pad columns [2*G*H, Kp) of my rows (the last slice of the reverse direction owns them)
+            if (rowok && d == 1 && pslice == P - 1) {
+                for (int k = 2 * GH + unit; k < p.dgKp; k += U) {
+                    char* o1 = reinterpret_cast<char*>(p.dgp1) + tn * (int64_t)p.dgKp * 4 + (k >> 5) * 128 + (k & 31) * 2;
+                    *reinterpret_cast<unsigned short*>(o1) = 0;
+                    *reinterpret_cast<unsigned short*>(o1 + 64) = 0;
+                    if (!LSTM) {
+                        char* o2 = reinterpret_cast<char*>(p.dgp2) + tn * (int64_t)p.dgKp * 4 + (k >> 5) * 128 + (k & 31) * 2;
+                        *reinterpret_cast<unsigned short*>(o2) = 0;
+                        *reinterpret_cast<unsigned short*>(o2 + 64) = 0;
+                    }
+                }
+            }
+        } else if (ok) {  // fp32 d(gates) (plain stores)
             float* dg = p.dg1 + (tn * 2 + d) * GH + gunit;
 #pragma unroll
             for (int g = 0; g < G; ++g) dg[g * H] = xv[g];
@@ -370,6 +408,10 @@ int run_bwd_any(const char* name, RnnP p, hipStream_t s) {
     if (p.xchg && aas_precision_value() != 0 && !(aas_debug_flags_value() & 256)) {
         const int rc = run_bwd_rs<MODE>(name, p, s);
         if (rc >= 0) return rc;
+    }
+    if (p.dgp1) {   // only the reduce-scatter kernel writes operand planes: the caller falls back to fp32 d(gates) + a split pass
+        aas_set_error("%s: plane output needs the split-bf16 reduce-scatter BPTT kernel (precision 1, exchange buffer, supported H)", name);
+        return 3;
     }
     return run_any<MODE>(name, p, s);
 }

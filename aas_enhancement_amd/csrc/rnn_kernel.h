@@ -40,6 +40,9 @@ struct RnnP {
     const float* dy;     // bwd: [T,N,H]
     float* dg1;          // bwd: LSTM dgates / GRU dgh  [T,N,2,G*H]  (exchanged)
     float* dg2;          // bwd: GRU dgx               [T,N,2,G*H]
+    unsigned short* dgp1; // bwd, optional: dg1 / dg2 as interleaved bf16 hi|lo PLANES [T*N rows][dgKp] (k = d*G*H + g*H + unit)
+    unsigned short* dgp2; //   instead of fp32 - the operand form of the layer's input-gradient and weight-gradient GEMMs
+    int dgKp;
     unsigned* sync;
     unsigned* xchg;      // split-bf16 exchange arrays (hi | lo), NULL -> exact fp32 kernels
     int P, Q;

@@ -437,6 +437,7 @@ def linear_rows(x, W, b=None, rs=None):
 # --------------------------------------------------------------------------------------- RNN layers
 PLANES_PRE = [os.environ.get("AAS_PLANES_PRE", "1") == "1"]   # input projections of the recurrent layers on the plane GEMM
 PLANES_BWD = [os.environ.get("AAS_PLANES_BWD", "1") == "1"]   # their input-gradient and weight-gradient products too
+PLANES_EMIT = [os.environ.get("AAS_PLANES_EMIT", "1") == "1"]  # the BPTT kernels write d(gates) as operand planes (no fp32, no split)
 
 
 def _wih_t_planes(w_ih, w_ih_r, GH, I):
@@ -528,31 +529,53 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     dy = _c(dy)
     sync = _sync_buf(dev)
     xchg = _xchg_buf(dev, T, N, H, G)
-    dgx = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
-    rflops = 2.0 * 2 * T * N * H * GH
-    lib().aas_set_rnn_launch_tag(2 * lid + 1 if lid else 1)
-    if kind == "lstm":
-        with _timed("rnn", "lstm_bwd[N=%d,H=%d]" % (N, H), rflops, T):
-            check(lib().aas_lstm_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), ptr(dgx),
-                                     ptr(sync), ptr(xchg)), "aas_lstm_bwd")
-        dgh = dgx
-    else:
-        dgh = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
-        with _timed("rnn", "gru_bwd[N=%d,H=%d]" % (N, H), rflops, T):
-            check(lib().aas_gru_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(dgx),
-                                    ptr(dgh), ptr(sync), ptr(xchg)), "aas_gru_bwd")
-    x2 = x.view(T * N, I)
     R = T * N
-    dx = None
     use_planes = (_precision[0] == 1 and PLANES_BWD[0] and R >= 1024 and H >= 64 and I >= 64 and GH % 8 == 0
                   and w_ih_r.data_ptr() != w_ih.data_ptr() and (w_ih_r.data_ptr() - w_ih.data_ptr()) % 4 == 0)
+    rflops = 2.0 * 2 * T * N * H * GH
+    lib().aas_set_rnn_launch_tag(2 * lid + 1 if lid else 1)
+    # d(gates) straight in the operand form of the layer's GEMMs (row-major bf16 hi|lo planes) when the plane path is taken:
+    # no fp32 copy and no split pass between the BPTT launch and the input-gradient GEMM
+    dgx = dgh = dgp = dghp = None
+    Kpg = _kp(2 * GH)
+    # (only when every consumer takes planes: the plane weight-gradient path needs the flat-buffer accumulate form)
+    if use_planes and PLANES_EMIT[0] and T > 1 and (direct is not None or not need_dw):
+        dgp = torch.empty((R, 2 * Kpg), device=dev, dtype=torch.bfloat16)
+        if kind == "lstm":
+            with _timed("rnn", "lstm_bwd[N=%d,H=%d]" % (N, H), rflops, T):
+                rc = lib().aas_lstm_bwd_planes(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), ptr(dgp), Kpg,
+                                               ptr(sync), ptr(xchg))
+            dghp = dgp
+        else:
+            dghp = torch.empty((R, 2 * Kpg), device=dev, dtype=torch.bfloat16)
+            with _timed("rnn", "gru_bwd[N=%d,H=%d]" % (N, H), rflops, T):
+                rc = lib().aas_gru_bwd_planes(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(dgp), ptr(dghp),
+                                              Kpg, ptr(sync), ptr(xchg))
+        if rc == 3:          # this shape / mode has no plane-emitting kernel: fp32 d(gates) + split passes below
+            dgp = dghp = None
+        else:
+            check(rc, "aas_%s_bwd_planes" % kind)
+    if dgp is None:
+        dgx = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
+        if kind == "lstm":
+            with _timed("rnn", "lstm_bwd[N=%d,H=%d]" % (N, H), rflops, T):
+                check(lib().aas_lstm_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), ptr(dgx),
+                                         ptr(sync), ptr(xchg)), "aas_lstm_bwd")
+            dgh = dgx
+        else:
+            dgh = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
+            with _timed("rnn", "gru_bwd[N=%d,H=%d]" % (N, H), rflops, T):
+                check(lib().aas_gru_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(dgx),
+                                        ptr(dgh), ptr(sync), ptr(xchg)), "aas_gru_bwd")
+    x2 = x.view(T * N, I)
+    dx = None
     if need_dx:
         dx = torch.empty((T, N, I), device=dev, dtype=torch.float32)
         dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4
         if use_planes:
             # dx[R, I] = d(gates)[R, 2GH] [W_ih ; W_ih_rev]: the NT plane GEMM on a row-major split of d(gates) (one HBM pass)
             # and the transposed weight planes (2 GH x I elements; cached when the weights are frozen)
-            dga = split_planes(dgx.view(R, 2 * GH), R, 2 * GH)
+            dga = Planes(dgp, R, 2 * GH, Kpg) if dgp is not None else split_planes(dgx.view(R, 2 * GH), R, 2 * GH)
             wt = _wih_t_planes(w_ih, w_ih_r, GH, I)
             gemm_planes(R, I, dga.Kp, dga, wt, dx, I, addend=dy if residual else None, ldd=I)
         elif dw > 0 and dw % 4 == 0:
@@ -571,13 +594,15 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         K = T * nbp
         Kp = _kp(K + nbp)                              # + one zero time step behind the data: room for the shifted windows
         bf = torch.bfloat16
-        dgT = torch.empty((2 * GH, 2 * Kp), device=dev, dtype=bf)
-        split_planes_t_into(dgT, dgx, T, N, nbp, 2 * GH, Kp, ld=2 * GH, row_scale=rs)
-        if dgh is not dgx:
-            dghT = torch.empty((2 * GH, 2 * Kp), device=dev, dtype=bf)
-            split_planes_t_into(dghT, dgh, T, N, nbp, 2 * GH, Kp, ld=2 * GH, row_scale=rs)
-        else:
-            dghT = dgT
+        def transposed(src_f32, src_planes):
+            out_ = torch.empty((2 * GH, 2 * Kp), device=dev, dtype=bf)
+            if src_planes is not None:
+                check(lib().aas_planes_transpose(stream(), ptr(src_planes), Kpg, T, N, nbp, 2 * GH, Kp, ptr(out_), ptr(rs)), "aas_planes_transpose")
+            else:
+                split_planes_t_into(out_, src_f32, T, N, nbp, 2 * GH, Kp, ld=2 * GH, row_scale=rs)
+            return out_
+        dgT = transposed(dgx, dgp)
+        dghT = dgT if (dgh is dgx and dghp is dgp) else transposed(dgh, dghp)
         xT = torch.empty((I, 2 * Kp), device=dev, dtype=bf)
         split_planes_t_into(xT, x2, T, N, nbp, I, Kp, ld=I)
         hT = torch.empty((2 * H, 2 * Kp), device=dev, dtype=bf)
@@ -597,6 +622,9 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
             gemm_planes_multi(GH, H, K, hh, Kp, Kp, H)
         for t_ in (dgT, dghT, xT, hT):
             t_.record_stream(torch.cuda.current_stream())
+        for t_ in (dgp, dghp):
+            if t_ is not None:
+                t_.record_stream(torch.cuda.current_stream())
 
     def wgrads(out, acc):
         if _SKIP_WGRAD:  # timing experiment only (AAS_SKIP_WGRAD=1): how much of the step the weight-gradient products hold

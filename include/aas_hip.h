@@ -84,6 +84,10 @@ int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K,
 int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
                     float* C, int64_t ldc, const float* bias, const float* addend, int64_t ldd, int accumulate,
                     int batch, int64_t strideA, int64_t strideB, int64_t strideC);
+/* aas_split_planes_t with PLANES as the source: planes[c][t*nbp + n] = split((hi + lo)(row (t, n), column c) * row_scale[n])
+ * for the row-major operand planes [T*nb rows][src_ld] that aas_lstm_bwd_planes / aas_gru_bwd_planes write. */
+int aas_planes_transpose(aasStream_t stream, const void* src_planes, int64_t src_ld, int T, int nb, int nbp, int C, int64_t Kp,
+                         void* planes, const float* row_scale);
 /* `count` (<= 4) products of one shape in ONE launch, each with its own plane operands and result (HOST arrays of
  * device pointers); always accumulates: C_i[M,N] += A_i[M,K] B_i[N,K]^T.  The four weight-gradient products of a
  * bidirectional recurrent layer (dW_ih, dW_hh per direction; model.py:73-74,94-95 backward) run as one launch. */
@@ -149,6 +153,16 @@ int aas_lstm_fwd(aasStream_t stream, int T, int N, int H, const float* pre, cons
  * dgates [T,N,2,4H] receives d(loss)/d(pre) (same layout as pre). */
 int aas_lstm_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh,
                  const float* w_hh_rev, const float* gact, const float* cst, float* dgates, void* sync, void* xchg);
+
+/* aas_lstm_bwd with d(gates) written straight in the operand form of the layer's GEMMs instead of fp32: interleaved
+ * bf16 hi|lo planes [T*N rows][Kp] (Kp = 2*4*H rounded up to 32; column k = d*4H + g*H + unit; pad columns zeroed) - what
+ * aas_split_planes would produce from the fp32 tensor, without that tensor or the pass.  Returns 3 (and does nothing)
+ * when the split-bf16 reduce-scatter kernel cannot be used (exact-fp32 mode, no exchange buffer, unsupported H): the
+ * caller then uses aas_lstm_bwd + aas_split_planes.  aas_gru_bwd_planes likewise (Kp = 2*3*H rounded up to 32). */
+int aas_lstm_bwd_planes(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
+                        const float* gact, const float* cst, void* dgates_planes, int Kp, void* sync, void* xchg);
+int aas_gru_bwd_planes(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
+                       const float* hout, const float* gact, void* dgx_planes, void* dgh_planes, int Kp, void* sync, void* xchg);
 
 /* Bidirectional bias-free GRU (cuDNN RNN under model.py:73-74,83), gate order r,z,n:
  *   pre [T,N,2,3H]; w_hh, w_hh_rev [3H,H]; hout [2,T,N,H];
