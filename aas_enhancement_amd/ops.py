@@ -657,8 +657,9 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
             wgrads(direct, True)
             if WGRAD_HOOK[0] is not None:
                 WGRAD_HOOK[0](direct)
-        for t_ in (dgx, dgh, x, hout):
-            t_.record_stream(side)
+        for t_ in (dgx, dgh, dgp, dghp, x, hout):
+            if t_ is not None:
+                t_.record_stream(side)
         return dx, None, None, None, None
     outs = [torch.empty((GH, I), device=dev, dtype=torch.float32), torch.empty((GH, H), device=dev, dtype=torch.float32),
             torch.empty((GH, I), device=dev, dtype=torch.float32), torch.empty((GH, H), device=dev, dtype=torch.float32)]
