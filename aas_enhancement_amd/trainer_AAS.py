@@ -326,7 +326,7 @@ class Trainer(object):
             scales = (c.w_adversarial / nv_ny, c.w_adversarial / nv_cl, c.w_acoustic / N)
             n_glob = float(N)
         try:
-            if self._lanes_ok():
+            if self._lanes_ok(tuple(cl_inputs.shape) == tuple(inputs.shape)):
                 enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC = self._two_lane_core(inputs, cl_inputs, scales, ctc_meta, asr_steps)
             else:
                 enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC = self._batched_D_core(inputs, cl_inputs, scales, ctc_meta, asr_steps)
@@ -395,8 +395,11 @@ class Trainer(object):
         enhanced.backward(ops.add3(leaf.grad, leaf_a.grad))
         return enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC
 
-    def _lanes_ok(self):
-        return self._interleave_ok() and os.environ.get("AAS_TWO_LANES", "1") == "1"
+    def _lanes_ok(self, same_shape=True):
+        """AAS_TWO_LANES = auto (default): the two-lane schedule when the noisy and clean batches have different padded
+        lengths (real loaders), the batched-D schedule when they are equal (0.1-0.3 ms / step faster at config 2); 1 / 0 force."""
+        mode = os.environ.get("AAS_TWO_LANES", "auto")
+        return self._interleave_ok() and (mode == "1" or (mode == "auto" and not same_shape))
 
     def _two_lane_core(self, inputs, cl_inputs, scales, ctc_meta, asr_steps):
         """The step as two lanes of half-chip persistent launches that are busy from the first kernel to the last:
@@ -489,7 +492,7 @@ class Trainer(object):
             attach_n_valid(cl_mask)
         nv = lambda m: getattr(m, "n_valid", None)
         nv_ny, nv_cl = nv(mask), nv(cl_mask)
-        if nv_ny is None or nv_cl is None or (tuple(cl_inputs.shape) != tuple(inputs.shape) and not self._lanes_ok()):
+        if nv_ny is None or nv_cl is None or (tuple(cl_inputs.shape) != tuple(inputs.shape) and not self._lanes_ok(False)):
             return self.train_step(data_list, data_list_cl, iter, log_norms=False)
         dev = next(self.G.parameters()).device
         cl_inputs = _get_variable_nograd(cl_inputs)

@@ -54,13 +54,15 @@ def _config2_batches(it=0):
     return ny, cl
 
 
+@pytest.mark.parametrize("lanes", ["auto", "1"], ids=["batchedD", "twolanes"])
 @pytest.mark.parametrize("frozen", [True, False], ids=["frozenA", "trainableA"])
-def test_timed_async_path_config2_iteration0_golden(gpu, precision, frozen):
+def test_timed_async_path_config2_iteration0_golden(gpu, precision, frozen, lanes, monkeypatch):
     """The path bench.py times (train_step_async -> _device_core -> _interleaved_DA, two streams, cached weight planes) on
     iteration 0 of F3 directly against the reference-generated scalars and samples; then iteration 1 for the trainable-A
     variant (the golden trajectory updates A after iteration 0... allow_ASR_update_iter=0 means from iteration 1 on)."""
     from aas_enhancement_amd import ops
     from aas_enhancement_amd.trainer_AAS import Trainer
+    monkeypatch.setenv("AAS_TWO_LANES", lanes)      # both device-resident schedules (equal shapes pick the batched one by default)
     z = load("f3_aas_config2.npz")
     tr = Trainer(cfg(lr=float(z["lr"]), nFeat=80, rnn_size=500, allow_ASR_update_iter=10 ** 9 if frozen else 0), None, models=_config2_models())
     tr.kt = float(z["kt0"])
@@ -175,6 +177,36 @@ def test_alternating_async_and_sync_steps_match_sync_only(gpu):
         if k in NOISE_PARAMS:
             continue
         assert rel_err(res["mixed"][1][k], v) < 1e-3, k
+
+
+def test_two_lane_schedule_on_ragged_pair_matches_synchronous_step(gpu):
+    """Noisy and clean batches of different padded length (what real loaders deliver): train_step_async takes the two-lane
+    schedule (E fwd || D(clean) fwd, D(enhanced) || A, E bwd || D(clean) bwd); same trajectory as the synchronous step's
+    two-pass branch, which the F1 goldens pin."""
+    from aas_enhancement_amd.trainer_AAS import Trainer
+    z = load("f1_aas_tiny.npz")
+    c = make_batch(3, 8, [52, 47, 41], 4000)
+    cl = (torch.from_numpy(c["inputs"]), None, torch.from_numpy(c["pct"]), None, torch.from_numpy(c["mask"]))
+    res = {}
+    for mode in ("sync", "lanes"):
+        tr = Trainer(cfg(lr=float(z["cfg_lr"]), allow_ASR_update_iter=0), None, models=build_tiny(z))
+        tr.kt = float(z["kt0"])
+        out = []
+        for it in range(3):
+            ny = batch_from(z, "it%d.ny." % it)
+            if mode == "sync":
+                r = tr.train_step(ny, cl, it, log_norms=False)
+            else:
+                tr.train_step_async(ny, cl, it)
+                assert tr._kt_dev_live          # really the device-resident path, not the synchronous fallback
+                r = tr.read_scalars()
+            out.append([r[k] for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt", "conv_measure")])
+        res[mode] = (np.asarray(out), {k: v.detach().clone() for m in (tr.G, tr.D, tr.ASR) for k, v in m.state_dict().items()})
+    assert np.allclose(res["sync"][0], res["lanes"][0], rtol=2e-4), (res["sync"][0], res["lanes"][0])
+    for k, v in res["sync"][1].items():
+        if k in NOISE_PARAMS:
+            continue
+        assert rel_err(res["lanes"][1][k], v) < 1e-3, k
 
 
 def test_exchange_timeout_raises_with_layer_name(gpu):
