@@ -19,6 +19,8 @@ def collect(d, counter):
                 continue
             name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
             name = re.sub(r"^void ", "", name).split("(")[0]
+            if "rnn_" in name:   # the same persistent kernel runs at several batch sizes: tell them apart by their grid
+                name += " grid=%s" % r.get("Grid_Size", "?")
             key = (name, r.get("Dispatch_Id"))
             acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"])   # one row per XCD / dimension instance: sum them
     per = {}
@@ -38,7 +40,17 @@ def main():
         wa = sum(w) / len(w) if w else 0.0
         kernels[name] = {"FETCH_SIZE_KiB_avg": fa, "WRITE_SIZE_KiB_avg": wa, "dispatches": max(len(f), len(w)),
                          "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `%s`" % cmd,
+    # launch classes of bench.py's roofline object (ops.Profiler names) -> kernel instances (persistent grids: P x Q x 2 x threads)
+    classes = {"lstm_bwd[N=60,H=500]": "rnn_bwd_rs_kernel<1, 32, 4> grid=65536", "lstm_bwd[N=30,H=500]": "rnn_bwd_rs_kernel<1, 32, 4> grid=65536",
+               "gru_bwd[N=30,H=1000]": "rnn_bwd_rs_kernel<3, 32, 8> grid=65536", "lstm_fwd[N=60,H=500]": "rnn_fwd32_kernel<0, 2, 0> grid=65536",
+               "lstm_fwd[N=30,H=500]": "rnn_split_kernel<0, 1, 4> grid=65536", "gru_fwd[N=30,H=1000]": "rnn_fwd32_kernel<2, 4, 2> grid=65536",
+               "gemm_planes_wgrad": "gemm_planes_kernel<128, 128, 2, 2, true>", "gemm_planes": "gemm_planes_kernel<256, 256, 4, 2, true>"}
+    by_class = {}
+    for cname, kname in classes.items():
+        hit = [v for k, v in kernels.items() if k == kname or (kname.split(" grid=")[0] == k.split(" grid=")[0] and cname.startswith(("lstm", "gru")) and len([x for x in kernels if x.split(" grid=")[0] == k.split(" grid=")[0]]) == 1)]
+        if hit:
+            by_class[cname] = dict(hit[0], kernel=kname)
+    json.dump({"by_class": by_class, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `%s`" % cmd,
                "units": "KiB per dispatch; fetched bytes = 2 x FETCH_SIZE x 1024 (gfx950 wide-read correction), written bytes = WRITE_SIZE x 1024",
                "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:

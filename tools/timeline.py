@@ -26,10 +26,11 @@ def main():
         if last is None or t - last > 5e6:
             steps.append(t)
         last = t
-    if len(steps) < 12:
+    if len(steps) < 8:
         print("too few steps found (%d)" % len(steps)); return
-    lo, hi = steps[8], steps[8 + 8]       # 8 steady-state steps
-    nsteps = 8
+    nsteps = min(8, len(steps) - 5)
+    first = len(steps) - 1 - nsteps        # the last `nsteps` complete steps of the run (steady state)
+    lo, hi = steps[first], steps[first + nsteps]
     win = [r for r in rows if r[0] >= lo and r[1] <= hi]
     span = (hi - lo) / 1e6
     print("window: %d steps, %.2f ms / step, %d launches / step" % (nsteps, span / nsteps, len(win) / nsteps))
@@ -62,7 +63,7 @@ def main():
     for key, ms in sorted(hist.items(), key=lambda kv: -kv[1]):
         print("  %-8s %-5s %-6s %8.3f ms" % (key[0], key[1], key[2], ms / nsteps))
     # Gantt of the persistent launches of one step (offsets from the step's first kernel)
-    one = [r for r in rows if r[0] >= steps[10] and r[0] < steps[11]]
+    one = [r for r in rows if r[0] >= steps[first + 1] and r[0] < steps[first + 2]]
     if one:
         t0 = one[0][0]
         print("\nrecurrent launches of one step (start ms, duration ms, queue, kernel):")
