@@ -154,8 +154,23 @@ def wgrad_stream(dev):
     return s
 
 
+# A trainer may hold back the weight-gradient products of a backward pass (DEFER_WGRAD) and release them later with
+# flush_deferred_wgrad(): the products are HBM-heavy and, queued beside a latency-bound BPTT chain that is on the step's
+# critical path, they slow its cross-CU exchange (D's BPTT launches at N=60: 0.96 ms alone, up to 1.9 ms beside them).
+DEFER_WGRAD = [False]
+_deferred = []
+
+
+def flush_deferred_wgrad():
+    """Queue the held-back weight-gradient products (on the weight-gradient stream, in the order they were produced)."""
+    todo, _deferred[:] = list(_deferred), []
+    for fn in todo:
+        fn()
+
+
 def sync_wgrad():
     """Make the current stream wait for every side-stream weight-gradient product issued so far."""
+    flush_deferred_wgrad()
     for s in _wgrad_streams.values():
         torch.cuda.current_stream().wait_stream(s)
 
@@ -652,14 +667,21 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         side = wgrad_stream(dev)
         ev = torch.cuda.Event()
         ev.record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(ev)
-            wgrads(direct, True)
-            if WGRAD_HOOK[0] is not None:
-                WGRAD_HOOK[0](direct)
+        hook = WGRAD_HOOK[0]
+
+        def run():
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                wgrads(direct, True)
+                if hook is not None:
+                    hook(direct)
         for t_ in (dgx, dgh, dgp, dghp, x, hout):
             if t_ is not None:
                 t_.record_stream(side)
+        if DEFER_WGRAD[0]:
+            _deferred.append(run)      # (the closure keeps the layer's operands alive until it runs)
+        else:
+            run()
         return dx, None, None, None, None
     outs = [torch.empty((GH, I), device=dev, dtype=torch.float32), torch.empty((GH, H), device=dev, dtype=torch.float32),
             torch.empty((GH, I), device=dev, dtype=torch.float32), torch.empty((GH, H), device=dev, dtype=torch.float32)]

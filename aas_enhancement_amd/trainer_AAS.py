@@ -371,8 +371,14 @@ class Trainer(object):
         if overlap:  # two chains of persistent launches side by side, half the chip each
             ops.set_rnn_cu_limit(ops.device_cus() // 2)
         if self._interleave_ok():
-            l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, None, ctc_meta, None, None, None,
-                                                                            scales=scales)
+            # the discriminator's weight-gradient products are held back while the two BPTT chains run (they slow the chains'
+            # cross-CU exchange) and released into E's backward phase, where half of the chip has little else to do
+            ops.DEFER_WGRAD[0] = os.environ.get("AAS_DEFER_WGRAD", "1") == "1"
+            try:
+                l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, None, ctc_meta, None, None, None,
+                                                                                scales=scales)
+            finally:
+                ops.DEFER_WGRAD[0] = False
         else:
             if overlap:
                 acoustic = self._acoustic_branch(enhanced, None, None, None, None, ctc_meta, scale=scales[2])
@@ -383,16 +389,18 @@ class Trainer(object):
             if acoustic is None:
                 acoustic = self._acoustic_branch(enhanced, None, None, None, None, ctc_meta, scale=scales[2])
             prob, l_CTC, leaf_a = acoustic
-        if dp.active:   # D's small parameters (the layer buckets are already in flight): overlaps E's backward
-            self._reducer.flush(self._flat["D"])
         torch.cuda.current_stream().wait_stream(self._side)
-        if dp.active and asr_steps:
-            self._reducer.flush(self._flat["A"])
         # E's BPTT launches are capped too: the CUs they leave free run E's weight-gradient GEMMs (side stream), which would
         # otherwise wait for each fully-resident 512-thread launch to retire
         ops.set_rnn_cu_limit(int(os.environ.get("AAS_EBWD_CUS", "128")))
         leaf_a.grad.record_stream(torch.cuda.current_stream())
-        enhanced.backward(ops.add3(leaf.grad, leaf_a.grad))
+        gsum = ops.add3(leaf.grad, leaf_a.grad)
+        ops.flush_deferred_wgrad()
+        if dp.active:   # D's (and a trainable A's) small parameters; their layer buckets are in flight: overlaps E's backward
+            self._reducer.flush(self._flat["D"])
+            if asr_steps:
+                self._reducer.flush(self._flat["A"])
+        enhanced.backward(gsum)
         return enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC
 
     def _lanes_ok(self, same_shape=True):
