@@ -36,6 +36,7 @@ SIGNATURES = {
     "aas_split_planes_t2": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
     "aas_transpose_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64],
     "aas_swap01_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int],
+    "aas_add3_planes_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     "aas_add3_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64],
     "aas_scale_rows_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int],
     "aas_axpby_f32": [c_vp, c_vp, c_vp, c_f32, c_f32, c_i64],

@@ -269,6 +269,48 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
+// out[r][k] = a[r][k] + b[r][k] (+ c[r][k]) AND its operand planes in one pass: the direction sum + residual of a recurrent
+// layer (model.py:85,104,223-226) is the next layer's input, i.e. the A operand of its input projection.
+__global__ __launch_bounds__(256) void add3_planes_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                          float* __restrict__ out, int64_t R, int K, int Kp, char* __restrict__ planes) {
+    const int cpr = Kp / 8;
+    const int64_t total = R * cpr;
+    const bool vec = (K & 3) == 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int k = (int)(i - r * cpr) * 8;
+        float v[8];
+        const int64_t o = r * K + k;
+        if (vec && k + 8 <= K) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 x = *reinterpret_cast<const f32x4*>(a + o + 4 * h) + *reinterpret_cast<const f32x4*>(b + o + 4 * h);
+                if (c) x += *reinterpret_cast<const f32x4*>(c + o + 4 * h);
+                *reinterpret_cast<f32x4*>(out + o + 4 * h) = x;
+                v[4 * h] = x[0]; v[4 * h + 1] = x[1]; v[4 * h + 2] = x[2]; v[4 * h + 3] = x[3];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = 0.f;
+                if (k + e < K) {
+                    v[e] = a[o + e] + b[o + e] + (c ? c[o + e] : 0.f);
+                    out[o + e] = v[e];
+                }
+            }
+        }
+        unsigned short h[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split2(v[e], h[e], l[e]);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 hv = {h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16)};
+        const u32x4 lv = {l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16)};
+        char* po = planes + r * (int64_t)Kp * 4 + (k >> 5) * 128 + (k & 31) * 2;
+        *reinterpret_cast<u32x4*>(po) = hv;
+        *reinterpret_cast<u32x4*>(po + 64) = lv;
+    }
+}
+
 // Transposing split of a time-major matrix: src[(t*nb + n)*ld + c] -> planes[c][t*nbp + n] for c < Cc (plane rows, pitch
 // Kp); the pad columns (n >= nb inside a time block, and everything from T*nbp to Kp) are written as zeros.  One
 // workgroup transposes a 64 (k positions) x 64 (source columns) tile through LDS, so both the fp32 reads and the bf16
@@ -337,6 +379,20 @@ __global__ __launch_bounds__(256) void planes_t_kernel(const char* __restrict__ 
 }
 
 }  // namespace
+
+extern "C" int aas_add3_planes_f32(aasStream_t stream, float* out, const float* a, const float* b, const float* c, int64_t rows, int K, int Kp,
+                                   void* planes) {
+    AAS_CHECK(out && a && b && planes && rows >= 0 && K >= 1 && Kp >= K && Kp % 32 == 0, "aas_add3_planes_f32: bad arguments (K=%d Kp=%d)", K, Kp);
+    AAS_CHECK(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0,
+              "aas_add3_planes_f32: operands must be 16-byte aligned");
+    if (rows == 0) return 0;
+    const int64_t total = rows * (Kp / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(add3_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, out, rows, K, Kp, (char*)planes);
+    AAS_LAUNCH_CHECK("aas_add3_planes_f32");
+    return 0;
+}
 
 extern "C" int aas_planes_transpose(aasStream_t stream, const void* src_planes, int64_t src_ld, int T, int nb, int nbp, int C, int64_t Kp,
                                     void* planes, const float* row_scale) {

@@ -120,6 +120,8 @@ class FlatBuffers(object):
             # marks the parameter for ops._BiRNNLayer: its weight gradients may be accumulated straight into .grad on the
             # side stream, because whoever owns these buffers joins that stream (ops.sync_wgrad) before reading them
             p._aas_flat_grad = True
+            p._aas_flat_ref = self      # ops caches weight operand planes per (address, version, self.version)
+        self.version = 0                # bumped by optim.FlatAdam: its HIP kernel does not touch torch's version counters
         self.bind_grads()
 
     def bind_grads(self):
@@ -180,12 +182,26 @@ class BucketReducer(object):
         self.done[id(f)].append((lo, hi))
 
     def flush(self, flat):
-        pos = 0
-        for lo, hi in sorted(self.done[id(flat)]) + [(flat.flat_g.numel(), flat.flat_g.numel())]:
-            if lo > pos:
-                self.handles.append(self.dp.allreduce_sum_(flat.flat_g[pos:lo], async_op=True))
-            pos = max(pos, hi)
-        self.done[id(flat)] = [(0, flat.flat_g.numel())]
+        """Reduce every range of `flat` no bucket covered.  Issued from the weight-gradient stream (behind the products
+        queued there so far, which may include these ranges when a layer was too small for a bucket) after an event of the
+        calling stream (where autograd accumulated the small parameters' gradients): the caller's stream is not held up."""
+        def issue():
+            pos = 0
+            for lo, hi in sorted(self.done[id(flat)]) + [(flat.flat_g.numel(), flat.flat_g.numel())]:
+                if lo > pos:
+                    self.handles.append(self.dp.allreduce_sum_(flat.flat_g[pos:lo], async_op=True))
+                pos = max(pos, hi)
+            self.done[id(flat)] = [(0, flat.flat_g.numel())]
+        if flat.flat_g.is_cuda:
+            from . import ops
+            side = ops.wgrad_stream(flat.flat_g.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                issue()
+        else:
+            issue()
 
     def wait(self):
         for h in self.handles:

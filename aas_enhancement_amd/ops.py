@@ -346,6 +346,16 @@ def add3(a, b, c=None):
     return out
 
 
+def add3_planes(a, b, c, K):
+    """out = a + b (+ c) [..., K] plus its operand planes, attached to the result as `_aas_planes` for the next layer."""
+    out = torch.empty_like(a)
+    rows = a.numel() // K
+    Kp = _kp(K)
+    buf = torch.empty((rows, 2 * Kp), device=a.device, dtype=torch.bfloat16)
+    check(lib().aas_add3_planes_f32(stream(), ptr(out), ptr(a), ptr(b), ptr(c), rows, K, Kp, ptr(buf)), "aas_add3_planes_f32")
+    return out, Planes(buf, rows, K, Kp)
+
+
 def scale_rows(x, scale, nb, out=None):
     """out[(t,n), :] = x[(t,n), :] * scale[n] (time-major rows); out=None -> new tensor, out=x -> in place."""
     C = x.shape[-1] if x.dim() == 2 else x.numel() // (x.shape[0] * x.shape[1])
@@ -455,11 +465,62 @@ PLANES_BWD = [os.environ.get("AAS_PLANES_BWD", "1") == "1"]   # their input-grad
 PLANES_EMIT = [os.environ.get("AAS_PLANES_EMIT", "1") == "1"]  # the BPTT kernels write d(gates) as operand planes (no fp32, no split)
 
 
-def _wih_t_planes(w_ih, w_ih_r, GH, I):
-    """[W_ih ; W_ih_rev]^T as planes [I rows][k = d*GH + g] (the B operand of dx = d(gates) W_ih); frozen weights once."""
+def _plane_sig(w_ih, w_ih_r, GH, I, tag):
+    """(cacheable, signature) of a weight-plane cache entry.  The planes hang on the weight tensor itself and are valid while
+    its storage address and version are unchanged: torch's version counter (bumped by every in-place torch write, e.g.
+    load_state_dict) and, for parameters re-homed in dist.FlatBuffers, the buffer's own counter that optim.FlatAdam bumps
+    (its HIP kernel writes through raw pointers).  Frozen weights are therefore split once, trainable ones once per
+    optimiser step - by refresh_weight_planes(), right after the step and off the critical path.  (Not a table keyed by
+    address: addresses are reused by other tensors.)"""
+    flat = getattr(w_ih, "_aas_flat_ref", None)
     frozen = not (w_ih.requires_grad or w_ih_r.requires_grad)
-    sig = (w_ih.data_ptr(), w_ih._version, w_ih_r.data_ptr(), w_ih_r._version, GH, I, "T")
-    ent = getattr(w_ih, "_aas_planes_t", None) if frozen else None
+    sig = (w_ih.data_ptr(), w_ih._version, w_ih_r.data_ptr(), w_ih_r._version, GH, I, tag, flat.version if flat is not None else None)
+    return (frozen or flat is not None) and not torch.cuda.is_current_stream_capturing(), sig
+
+
+def _wih_planes(w_ih, w_ih_r, GH, I):
+    """[W_ih ; W_ih_rev] as planes [2*GH rows][I] (the B operand of the input projections of both directions)."""
+    ok, sig = _plane_sig(w_ih, w_ih_r, GH, I, "N")
+    ent = getattr(w_ih, "_aas_planes", None) if ok else None
+    if ent is not None and ent[0] == sig:
+        return ent[1]
+    Kp = _kp(I)
+    buf = torch.empty((2 * GH, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
+    check(lib().aas_split_planes(stream(), ptr(w_ih), I, GH, I, Kp, ptr(buf), None, 0), "aas_split_planes")
+    check(lib().aas_split_planes(stream(), ptr(w_ih_r), I, GH, I, Kp, buf.data_ptr() + GH * Kp * 4, None, 0), "aas_split_planes")
+    wb = Planes(buf, 2 * GH, I, Kp)
+    if ok:
+        try:
+            w_ih._aas_planes = (sig, wb)
+        except Exception:  # noqa: BLE001  (a tensor type that takes no attributes: just do not cache)
+            pass
+    return wb
+
+
+def refresh_weight_planes(module):
+    """Re-split the input weights of every recurrent layer of `module` into their operand planes (forward and transposed)
+    on the weight-gradient stream: call right after the optimiser step; the next forward joins that stream (sync_wgrad)."""
+    dev = next(module.parameters()).device
+    main, side = torch.cuda.current_stream(), wgrad_stream(dev)
+    ev = torch.cuda.Event()
+    ev.record(main)
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        for m in module.modules():
+            if getattr(m, "_aas_layer_id", None) is None:
+                continue
+            w, wr = m.weight_ih_l0, m.weight_ih_l0_reverse
+            GH, I = w.shape
+            if _precision[0] == 1 and PLANES_PRE[0] and I >= 64:
+                for t_ in (_wih_planes(w, wr, GH, I).buf,) + ((_wih_t_planes(w, wr, GH, I).buf,) if (PLANES_BWD[0] and w.requires_grad) else ()):
+                    t_.record_stream(main)
+
+
+def _wih_t_planes(w_ih, w_ih_r, GH, I):
+    """[W_ih ; W_ih_rev]^T as planes [I rows][k = d*GH + g] (the B operand of dx = d(gates) W_ih)."""
+    ok, sig = _plane_sig(w_ih, w_ih_r, GH, I, "T")
+    frozen = ok
+    ent = getattr(w_ih, "_aas_planes_t", None) if ok else None
     if ent is not None and ent[0] == sig:
         return ent[1]
     Kp = _kp(2 * GH)
@@ -488,25 +549,10 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0):
         # plane GEMM: x and [W_ih; W_ih_rev] as pre-split bf16 planes (one HBM-bound pass each; frozen weights are
         # split once), then one LDS-DMA-staged launch for both directions: pre[tn, d*GH + g]
         GH = G * H
-        xa = split_planes(x2, T * N, I)
-        # frozen weights are split once: the planes hang on the weight tensor itself and are valid while its storage
-        # address and version counter (bumped by every in-place torch write, e.g. load_state_dict) are unchanged.  (Not a
-        # table keyed by address: addresses are reused by other tensors.)
-        frozen = not (w_ih.requires_grad or w_ih_r.requires_grad)
-        sig = (w_ih.data_ptr(), w_ih._version, w_ih_r.data_ptr(), w_ih_r._version, GH, I)
-        ent = getattr(w_ih, "_aas_planes", None) if frozen else None
-        wb = ent[1] if ent is not None and ent[0] == sig else None
-        if wb is None:
-            Kp = _kp(I)
-            buf = torch.empty((2 * GH, 2 * Kp), device=dev, dtype=torch.bfloat16)
-            check(lib().aas_split_planes(stream(), ptr(w_ih), I, GH, I, Kp, ptr(buf), None, 0), "aas_split_planes")
-            check(lib().aas_split_planes(stream(), ptr(w_ih_r), I, GH, I, Kp, buf.data_ptr() + GH * Kp * 4, None, 0), "aas_split_planes")
-            wb = Planes(buf, 2 * GH, I, Kp)
-            if frozen and not torch.cuda.is_current_stream_capturing():
-                try:
-                    w_ih._aas_planes = (sig, wb)
-                except Exception:  # noqa: BLE001  (a tensor type that takes no attributes: just do not cache)
-                    pass
+        xa = getattr(x, "_aas_planes", None)       # the producing layer's direction sum may have written them already
+        if xa is None or xa.rows != T * N or xa.K != I:
+            xa = split_planes(x2, T * N, I)
+        wb = _wih_planes(w_ih, w_ih_r, GH, I)
         gemm_planes(T * N, 2 * GH, xa.Kp, xa, wb, pre, 2 * GH)
     elif dw > 0 and dw % 4 == 0:
         # both directions in ONE batched launch: same A, B strided by the distance between the two weight tensors
@@ -701,7 +747,12 @@ class _BiRNNLayer(torch.autograd.Function):
         x = _c(x)
         w_ih, w_hh, w_ih_r, w_hh_r = _c(w_ih), _c(w_hh), _c(w_ih_r), _c(w_hh_r)
         hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid)
-        y = add3(hout[0], hout[1], x if residual else None)
+        T_, N_, H_ = hout.shape[1], hout.shape[2], hout.shape[3]
+        if _precision[0] == 1 and PLANES_PRE[0] and T_ * N_ >= 1024 and H_ >= 64 and H_ % 4 == 0:
+            y, yp = add3_planes(hout[0], hout[1], x if residual else None, H_)
+            y._aas_planes = yp        # consumed by the next recurrent layer's input projection (same Python object is passed on)
+        else:
+            y = add3(hout[0], hout[1], x if residual else None)
         ctx.kind, ctx.residual = kind, residual
         ctx.save_for_backward(x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst if cst is not None else hout)
         return y

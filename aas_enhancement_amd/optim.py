@@ -52,6 +52,7 @@ class FlatAdam(object):
             self._t_dev.fill_(float(self.step_count))   # keep the device counter of step_dev() in step (paths may alternate)
         ops.adam_step(self.flat.flat_p, self.flat.flat_g, self.m, self.v, self.vmax, self.lr, self.betas[0],
                       self.betas[1], self.eps, self.step_count, self.amsgrad, grad_scale)
+        self.flat.version += 1
 
     # ---- torch.optim.Adam-shaped state (the `optim_dict` of a DeepSpeech package, model.py:393-394 / train.py:170) -------
     def state_dict(self):
@@ -94,3 +95,4 @@ class FlatAdam(object):
         ops.adam_step_dev(self.flat.flat_p, self.flat.flat_g, self.m, self.v, self.vmax, self.betas[0], self.betas[1],
                           self.eps, self._hyper, self.amsgrad, grad_scale)
         self.step_count += 1
+        self.flat.version += 1

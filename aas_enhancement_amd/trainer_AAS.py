@@ -283,6 +283,9 @@ class Trainer(object):
         optimizer_d.step()
         if optimizer_asr is not None and iter > c.allow_ASR_update_iter:
             optimizer_asr.step()
+            ops.refresh_weight_planes(self.ASR)
+        ops.refresh_weight_planes(self.G)
+        ops.refresh_weight_planes(self.D)
         # one packed device->host read for the three scalars the controller / log need
         packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), l_CTC.detach().reshape(())])
         l_adv_ny_G_data, l_adv_cl_data, l_ctc_data = dp.reduce_scalars(packed).tolist()
@@ -341,6 +344,10 @@ class Trainer(object):
         optimizer_d.step_dev()
         if asr_steps:
             optimizer_asr.step_dev()
+        # the updated weights' operand planes for the next step, off the critical path (weight-gradient stream)
+        for net, on in ((self.G, True), (self.D, True), (self.ASR, asr_steps)):
+            if on and not capturing:
+                ops.refresh_weight_planes(net)
         if not dp.active:   # controller + log scalars in one tiny launch
             ops.began_step(l_adv_ny_G, l_adv_cl, l_CTC, self._kt_dev, self._g_out, self.gamma, self.lb, n_glob)
             return enhanced, prob

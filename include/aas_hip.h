@@ -84,6 +84,10 @@ int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K,
 int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
                     float* C, int64_t ldc, const float* bias, const float* addend, int64_t ldd, int accumulate,
                     int batch, int64_t strideA, int64_t strideB, int64_t strideC);
+/* out[rows,K] = a + b (+ c) and, in the same pass, its operand planes (what aas_split_planes would make of `out`): the
+ * direction sum + residual of one recurrent layer (model.py:85,104,223-226) is the A operand of the next layer's projection. */
+int aas_add3_planes_f32(aasStream_t stream, float* out, const float* a, const float* b, const float* c, int64_t rows, int K, int Kp,
+                        void* planes);
 /* aas_split_planes_t with PLANES as the source: planes[c][t*nbp + n] = split((hi + lo)(row (t, n), column c) * row_scale[n])
  * for the row-major operand planes [T*nb rows][src_ld] that aas_lstm_bwd_planes / aas_gru_bwd_planes write. */
 int aas_planes_transpose(aasStream_t stream, const void* src_planes, int64_t src_ld, int T, int nb, int nbp, int C, int64_t Kp,
