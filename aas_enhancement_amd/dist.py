@@ -28,7 +28,9 @@ class DPContext(object):
 
     @property
     def active(self):
-        return self.world > 1
+        # AAS_DP_FORCE=1: run the data-parallel code path (collectives, global normalisers, bucket reducer) on a one-rank
+        # group too - how the RCCL calls are exercised on a single-GPU test box
+        return self.world > 1 or (os.environ.get("AAS_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized())
 
     def _dev(self, like=None):
         if like is not None:

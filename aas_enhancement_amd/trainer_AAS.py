@@ -380,7 +380,7 @@ class Trainer(object):
         if self._interleave_ok():
             # the discriminator's weight-gradient products are held back while the two BPTT chains run (they slow the chains'
             # cross-CU exchange) and released into E's backward phase, where half of the chip has little else to do
-            ops.DEFER_WGRAD[0] = os.environ.get("AAS_DEFER_WGRAD", "1") == "1"
+            ops.DEFER_WGRAD[0] = os.environ.get("AAS_DEFER_WGRAD", "0") == "1"   # (measured: no gain, 19.0 vs 19.2 ms - kept as a switch)
             try:
                 l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, None, ctc_meta, None, None, None,
                                                                                 scales=scales)
