@@ -40,6 +40,7 @@ struct LP {
     const float* mel_w;      // [n_mels][MAXW]
     float* out;              // [N, n_mels, T]
     int N, S, T, n_mels, tiles_per_utt;
+    int flags;               // ablation (aas_set_debug_flags): 1 no staging loads, 2 no fold, 4 no MFMA, 8 no mel, 16 no output stores (timing only)
 };
 
 __device__ __forceinline__ void split2(float x, unsigned short& h, unsigned short& l) {
@@ -49,7 +50,7 @@ __device__ __forceinline__ void split2(float x, unsigned short& h, unsigned shor
     l = __builtin_bit_cast(unsigned short, lb);
 }
 
-__global__ __launch_bounds__(256, 1) void lmfb320_kernel(LP p) {
+__global__ __launch_bounds__(256, 2) void lmfb320_kernel(LP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* a_hi = smem;                                        // [16][A_STRIDE]
     char* a_lo = a_hi + TF * A_STRIDE;
@@ -95,10 +96,42 @@ __global__ __launch_bounds__(256, 1) void lmfb320_kernel(LP p) {
     __syncthreads();
 
     const int total = p.N * p.tiles_per_utt;
-    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
-        const int n = tile / p.tiles_per_utt, t0 = (tile - n * p.tiles_per_utt) * TF;
-        int Sn = p.lens ? p.lens[n] : p.S;
+    // Software pipeline: the samples of tile i+1 are fetched into registers (3 x 16 bytes per thread) while tile i is folded,
+    // multiplied and written; they go to LDS at the top of the next iteration.  Interior tiles (no reflection, no batch
+    // padding inside) take aligned 16-byte loads; the first / last tiles of an utterance take the scalar reflecting path.
+    constexpr int NV = (NSAMP / 4 + 255) / 256;               // float4 loads per thread (680 vectors per tile)
+    f32x4 pre[NV];
+    bool pre_vec = false;
+    auto tile_coords = [&](int tile, int& n, int& t0, int& Sn) {
+        n = tile / p.tiles_per_utt;
+        t0 = (tile - n * p.tiles_per_utt) * TF;
+        Sn = p.lens ? p.lens[n] : p.S;
         if (Sn > p.S) Sn = p.S;
+    };
+    auto prefetch = [&](int tile) {
+        pre_vec = false;
+        if (tile >= total || (p.flags & 1)) return;
+        int n, t0, Sn;
+        tile_coords(tile, n, t0, Sn);
+        const int first = t0 * HOP - HOP;                     // wave index of seg[0]
+        if (first >= 0 && first + NSAMP <= Sn && ((p.S & 3) == 0)) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.wave + (int64_t)n * p.S + first);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int idx = tid + v * 256;
+                if (idx < NSAMP / 4) pre[v] = src[idx];
+            }
+            pre_vec = true;
+        }
+    };
+    // each workgroup takes a CONTIGUOUS run of tiles: consecutive tiles of an utterance write the two 64-byte halves of the
+    // same output lines and read adjacent (overlapping) sample ranges - close in time on one CU, they merge in its L2
+    const int per = (total + gridDim.x - 1) / gridDim.x;
+    const int tile_end = min(total, ((int)blockIdx.x + 1) * per);
+    prefetch(blockIdx.x * per < tile_end ? blockIdx.x * per : total);
+    for (int tile = blockIdx.x * per; tile < tile_end; ++tile) {
+        int n, t0, Sn;
+        tile_coords(tile, n, t0, Sn);
         const int Tn = 1 + Sn / HOP;                          // this utterance's frames; the rest of [0, T) is zero
         const int nf = min(TF, p.T - t0);
         if (t0 >= Tn || Sn <= HOP) {                          // whole tile in the batch padding
@@ -106,18 +139,29 @@ __global__ __launch_bounds__(256, 1) void lmfb320_kernel(LP p) {
                 const int m = i / nf, f = i - m * nf;
                 p.out[((int64_t)n * p.n_mels + m) * p.T + t0 + f] = 0.f;
             }
+            prefetch(tile + 1 < tile_end ? tile + 1 : total);
             continue;
         }
         // ---- stage: samples t0*160 - 160 .. of the centre-padded utterance (reflect at both of ITS ends)
-        const float* w = p.wave + (int64_t)n * p.S;
-        for (int i = tid; i < NSAMP; i += 256) {
-            int j = t0 * HOP + i - HOP;
-            if (j < 0) j = -j;
-            if (j >= Sn) j = 2 * (Sn - 1) - j;
-            seg[i] = (j >= 0 && j < Sn) ? w[j] : 0.f;
+        if (pre_vec) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int idx = tid + v * 256;
+                if (idx < NSAMP / 4) reinterpret_cast<f32x4*>(seg)[idx] = pre[v];
+            }
+        } else if (!(p.flags & 1)) {
+            const float* w = p.wave + (int64_t)n * p.S;
+            for (int i = tid; i < NSAMP; i += 256) {
+                int j = t0 * HOP + i - HOP;
+                if (j < 0) j = -j;
+                if (j >= Sn) j = 2 * (Sn - 1) - j;
+                seg[i] = (j >= 0 && j < Sn) ? w[j] : 0.f;
+            }
         }
+        prefetch(tile + 1 < tile_end ? tile + 1 : total);
         __syncthreads();
         // ---- window + two folds + bf16 hi/lo split -> A planes [frame][segment][k]
+        if (!(p.flags & 2))
         for (int i = tid; i < TF * 81; i += 256) {
             const int f = i / 81, j = i - f * 81;
             const float* x = seg + f * HOP;
@@ -159,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void lmfb320_kernel(LP p) {
         }
         __syncthreads();
         // ---- MFMA: C[frame][column] for this wave's column groups, real and imaginary part in the same lane
-        {
+        if (!(p.flags & 4)) {
             const int fr = lane & 15, kc = (lane >> 4) * 16;  // A fragment: frame row, 16-byte k chunk
             bf16x8 are[3][2], aim[3][2];
 #pragma unroll
@@ -199,13 +243,13 @@ __global__ __launch_bounds__(256, 1) void lmfb320_kernel(LP p) {
             const bool live = f < nf && (t0 + f) < Tn;
             for (int m = tid >> 4; m < p.n_mels; m += 16) {
                 float acc = 0.f;
-                if (live) {
+                if (live && !(p.flags & 8)) {
                     const int s0 = ms[m], cnt = ms[p.n_mels + m];
                     const float* pr = P + f * P_STRIDE + s0;
                     const float* wr = mw + m * MAXW;
                     for (int q = 0; q < cnt; ++q) acc = fmaf(pr[q], wr[q], acc);
                 }
-                if (f < nf) p.out[((int64_t)n * p.n_mels + m) * p.T + t0 + f] = live ? log1pf(acc) : 0.f;
+                if (f < nf && !(p.flags & 16)) p.out[((int64_t)n * p.n_mels + m) * p.T + t0 + f] = live ? log1pf(acc) : 0.f;
             }
         }
         // (the next tile's staging writes `seg`, its fold writes the A planes: both were last read before the barrier above;
@@ -224,6 +268,7 @@ extern "C" int aas_lmfb320_fwd(aasStream_t stream, const float* wave, const int*
     AAS_CHECK((reinterpret_cast<uintptr_t>(tables) & 15) == 0, "aas_lmfb320_fwd: tables must be 16-byte aligned");
     LP p;
     p.wave = wave; p.lens = d_lens; p.tab = (const unsigned short*)tables; p.win = window; p.mel_start = mel_start; p.mel_cnt = mel_cnt;
+    p.flags = aas_debug_flags_value();
     p.mel_w = mel_w; p.out = out; p.N = N; p.S = S; p.T = 1 + S / HOP; p.n_mels = n_mels; p.tiles_per_utt = cdiv(p.T, TF);
     const size_t lds = 2 * (size_t)TF * A_STRIDE + sizeof(float) * (NSAMP + TF * P_STRIDE + WIN + (size_t)n_mels * MAXW) + sizeof(int) * 2 * n_mels;
     static bool attr_done = false;
