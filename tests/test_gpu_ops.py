@@ -391,3 +391,134 @@ def test_lmfb_vs_numpy(ops):
     assert rel_err(f, ref) < 1e-3
     f40 = LMFB(n_mels=40).cuda()(torch.from_numpy(wave[:1, :1000]).cuda())
     assert rel_err(f40, lmfb_np.lmfb(wave[0, :1000], n_mels=40)[None]) < 1e-3
+
+
+def test_round2_plane_ops(ops):
+    """Entry points added for the plane-GEMM backward path, each against a float64 restatement: fused direction sum + planes,
+    planes -> transposed planes (with per-utterance weights), block-strided transposed split, the multi-problem GEMM."""
+    from aas_enhancement_amd._lib import check, lib, ptr, stream
+    T, nb, C1, C2 = 7, 30, 136, 72
+    a, b, c = R(T * nb, C1, seed=1).cuda(), R(T * nb, C1, seed=2).cuda(), R(T * nb, C1, seed=3).cuda()
+    y, yp = ops.add3_planes(a, b, c, C1)
+    assert torch.equal(y, a + b + c)
+    assert (yp.to_float()[:, :C1] - y).abs().max() <= 2.0 ** -17 * y.abs().max() and yp.to_float()[:, C1:].abs().max() == 0
+    y2, yp2 = ops.add3_planes(a, b, None, C1)
+    assert torch.equal(y2, a + b)
+    # planes -> transposed planes with row weights == aas_split_planes_t of the fp32 tensor
+    rs = (torch.rand(nb) + 0.5).cuda()
+    nbp = 32
+    Kp = ops._kp(T * nbp + nbp)
+    want = torch.zeros(C1, Kp, dtype=torch.float64)
+    want[:, :T * nbp].view(C1, T, nbp)[:, :, :nb] = (y.double().cpu().view(T, nb, C1) * rs.double().cpu().view(1, nb, 1)).permute(2, 0, 1)
+    out = torch.empty((C1, 2 * Kp), device="cuda", dtype=torch.bfloat16)
+    check(lib().aas_planes_transpose(stream(), ptr(yp.buf), yp.Kp, T, nb, nbp, C1, Kp, ptr(out), ptr(rs)), "aas_planes_transpose")
+    got = ops.Planes(out, C1, T * nbp, Kp).to_float().double().cpu()
+    assert (got - want).abs().max() <= 2.0 ** -15 * want.abs().max()
+    assert got.view(C1, -1)[:, T * nbp:].abs().max() == 0
+    # block-strided transposed split: two [G, I] tensors `tstride` apart (either sign) -> [I rows][k = d*G + g]
+    G, I = 40, 24
+    flat = R(4 * G * I, seed=5).cuda()
+    for first, second in ((0, 2 * G * I), (3 * G * I, G * I)):
+        w0, w1 = flat[first:first + G * I].view(G, I), flat[second:second + G * I].view(G, I)
+        Kp2 = ops._kp(2 * G)
+        buf = torch.empty((I, 2 * Kp2), device="cuda", dtype=torch.bfloat16)
+        ops.split_planes_t_into(buf, w0, 2, G, G, I, Kp2, ld=I, tstride=second - first)
+        gotw = ops.Planes(buf, I, 2 * G, Kp2).to_float()[:, :2 * G]
+        wantw = torch.cat([w0, w1], 0).t()
+        assert (gotw - wantw).abs().max() <= 2.0 ** -17 * wantw.abs().max()
+    # multi-problem GEMM: 3 accumulating products with their own operands in one launch
+    M, N, K = 150, 70, 96
+    As = [ops.split_planes(R(M, K, seed=10 + i).cuda(), M, K) for i in range(3)]
+    Bs = [ops.split_planes(R(N, K, seed=20 + i).cuda(), N, K) for i in range(3)]
+    Cs = [torch.full((M, N), float(i), device="cuda") for i in range(3)]
+    ops.gemm_planes_multi(M, N, As[0].Kp, [(x.buf.data_ptr(), z_.buf.data_ptr(), c_.data_ptr()) for x, z_, c_ in zip(As, Bs, Cs)], As[0].Kp, Bs[0].Kp, N)
+    for i in range(3):
+        want_c = float(i) + As[i].to_float().double() @ Bs[i].to_float().double().t()
+        assert rel_err(Cs[i], want_c) < 2e-5, i
+
+
+@pytest.mark.parametrize("kind,T,N,H", [("lstm", 40, 30, 64), ("gru", 35, 30, 96), ("lstm", 200, 30, 500)])
+def test_bptt_plane_output_equals_fp32_output(ops, kind, T, N, H):
+    """aas_lstm_bwd_planes / aas_gru_bwd_planes: d(gates) written straight as operand planes == split of the fp32 d(gates) the
+    plain entry points write (same kernel, same arithmetic, other store form), pads zero."""
+    from aas_enhancement_amd._lib import lib, ptr, stream
+    G = 4 if kind == "lstm" else 3
+    x = R(T, N, H, seed=1, scale=0.5).cuda()
+    w = [(R(G * H, H, seed=2 + i) / H ** 0.5).cuda() for i in range(4)]
+    hout, gact, cst = ops._birnn_fwd(kind, x, *w)
+    dy = R(T, N, H, seed=9).cuda()
+    sync, xc = ops._sync_buf(x.device), ops._xchg_buf(x.device, T, N, H, G)
+    GH = G * H
+    Kp = ops._kp(2 * GH)
+    dgx, dgh = torch.empty(T, N, 2, GH, device="cuda"), torch.empty(T, N, 2, GH, device="cuda")
+    pg, ph = torch.full((T * N, 2 * Kp), 7.0, device="cuda", dtype=torch.bfloat16), torch.full((T * N, 2 * Kp), 7.0, device="cuda", dtype=torch.bfloat16)
+    L = lib()
+    if kind == "lstm":
+        assert L.aas_lstm_bwd(stream(), T, N, H, ptr(dy), ptr(w[1]), ptr(w[3]), ptr(gact), ptr(cst), ptr(dgx), ptr(sync), ptr(xc)) == 0
+        assert L.aas_lstm_bwd_planes(stream(), T, N, H, ptr(dy), ptr(w[1]), ptr(w[3]), ptr(gact), ptr(cst), ptr(pg), Kp, ptr(sync), ptr(xc)) == 0
+        pairs = [(pg, dgx)]
+    else:
+        assert L.aas_gru_bwd(stream(), T, N, H, ptr(dy), ptr(w[1]), ptr(w[3]), ptr(hout), ptr(gact), ptr(dgx), ptr(dgh), ptr(sync), ptr(xc)) == 0
+        assert L.aas_gru_bwd_planes(stream(), T, N, H, ptr(dy), ptr(w[1]), ptr(w[3]), ptr(hout), ptr(gact), ptr(pg), ptr(ph), Kp, ptr(sync), ptr(xc)) == 0
+        pairs = [(pg, dgx), (ph, dgh)]
+    torch.cuda.synchronize()
+    assert not ops.rnn_timeout_flag()
+    for planes, f32 in pairs:
+        got = ops.Planes(planes, T * N, 2 * GH, Kp).to_float()
+        want = f32.view(T * N, 2 * GH)
+        # the exchanged partial sums arrive in a different order run to run (ring), so compare at split precision, not bitwise
+        assert (got[:, :2 * GH] - want).abs().max() <= 3e-5 * want.abs().max()
+        assert got[:, 2 * GH:].abs().max() == 0
+    # exact-fp32 mode has no plane-emitting kernel: the entry point says so (rc 3) and leaves the buffer alone
+    ops.set_precision(0)
+    try:
+        rc = (L.aas_lstm_bwd_planes(stream(), T, N, H, ptr(dy), ptr(w[1]), ptr(w[3]), ptr(gact), ptr(cst), ptr(pg), Kp, ptr(sync), ptr(xc)) if kind == "lstm"
+              else L.aas_gru_bwd_planes(stream(), T, N, H, ptr(dy), ptr(w[1]), ptr(w[3]), ptr(hout), ptr(gact), ptr(pg), ptr(ph), Kp, ptr(sync), ptr(xc)))
+        assert rc == 3
+    finally:
+        ops.set_precision(1)
+
+
+def test_batchnorm_split_entry_points_and_adam_tick(ops):
+    """aas_bn_stats + aas_bn_apply (+ the backward pair) with the local row count == the fused aas_bn_fwd / aas_bn_bwd; with
+    doubled sums and a doubled device row count == BatchNorm over the batch repeated twice (what two equal ranks all-reduce to);
+    aas_adam_tick / aas_began_step against python arithmetic."""
+    from aas_enhancement_amd._lib import check, lib, ptr, stream
+    Rr, C = 300, 70
+    x, dy = R(Rr, C, seed=1, scale=2.0).cuda(), R(Rr, C, seed=2).cuda()
+    g, b = (torch.rand(C) + 0.5).cuda(), R(C, seed=3).cuda()
+    y = ops.batchnorm_rows(x.clone().requires_grad_(True), g, b, None, None, 1e-5, 0.1, 128.0)
+    L = lib()
+    red = torch.empty(2 * C + 1, device="cuda", dtype=torch.float64)
+    stats = torch.empty(4, C, device="cuda")
+    y2 = torch.empty_like(x)
+    check(L.aas_bn_stats(stream(), ptr(x), Rr, C, ptr(red)))
+    check(L.aas_bn_apply(stream(), ptr(x), ptr(y2), Rr, C, ptr(g), ptr(b), 1e-5, 128.0, ptr(stats), None, None, 0.1, ptr(red), None))
+    assert torch.equal(y2, y.detach())
+    red[:2 * C] *= 2.0
+    red[2 * C] = 2.0 * Rr
+    y3 = torch.empty_like(x)
+    check(L.aas_bn_apply(stream(), ptr(x), ptr(y3), Rr, C, ptr(g), ptr(b), 1e-5, 128.0, ptr(stats), None, None, 0.1, ptr(red), ptr(red[2 * C:])))
+    xx = torch.cat([x, x], 0).cpu()
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(xx, None, None, g.cpu(), b.cpu(), True, 0.1, 1e-5), 128.0)[:Rr]
+    assert rel_err(y3, ref) < 1e-5
+    # backward pair, global sums = 2 x local (two identical ranks): dx equals the doubled-batch BatchNorm's, dgamma/dbeta stay local
+    loc = torch.empty(2 * C, device="cuda", dtype=torch.float64)
+    check(L.aas_bn_bwd_reduce(stream(), ptr(x), ptr(dy), Rr, C, ptr(g), ptr(b), 128.0, ptr(stats), ptr(loc)))
+    glob = loc * 2.0
+    dx, dg_, db_ = torch.empty_like(x), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    check(L.aas_bn_bwd_apply(stream(), ptr(x), ptr(dy), ptr(dx), Rr, C, ptr(g), ptr(b), 128.0, ptr(stats), ptr(dg_), ptr(db_), 0, ptr(glob), ptr(loc), ptr(red[2 * C:])))
+    xr = xx.clone().requires_grad_(True)
+    gr, br = g.cpu().clone().requires_grad_(True), b.cpu().clone().requires_grad_(True)
+    out = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5), 128.0)
+    out.backward(torch.cat([dy, dy], 0).cpu())
+    assert rel_err(dx, xr.grad[:Rr]) < 2e-4
+    assert rel_err(dg_, gr.grad / 2) < 2e-4 and rel_err(db_, br.grad / 2) < 2e-4
+    # Adam tick and BEGAN controller
+    t = torch.full((1,), 6.0, device="cuda", dtype=torch.float64)
+    hy = torch.zeros(2, device="cuda")
+    ops.adam_tick(t, 1e-3, 0.5, 0.999, hy)
+    assert float(t) == 7.0 and float(hy[0]) == pytest.approx(1e-3 / (1 - 0.5 ** 7), rel=1e-6) and float(hy[1]) == pytest.approx((1 - 0.999 ** 7) ** 0.5, rel=1e-6)
+    kt, o6 = torch.full((1,), 0.9995, device="cuda", dtype=torch.float64), torch.zeros(6, device="cuda", dtype=torch.float64)
+    ops.began_step(torch.tensor(3.0).cuda(), torch.tensor(8.0).cuda(), torch.tensor(5.0).cuda(), kt, o6, 0.5, 0.001, 30.0)
+    assert float(kt) == pytest.approx(min(1.0, 0.9995 + 0.001 * (0.5 * 8.0 - 3.0))) and o6.tolist() == pytest.approx([3.0, 8.0, 5.0, float(kt), 150.0, 30.0])
