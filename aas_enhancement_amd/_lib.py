@@ -70,7 +70,7 @@ SIGNATURES = {
     "aas_edit_distance": [c_vp, c_int, c_vp, c_int],
     "aas_adam_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_f32],
     "aas_adam_dev_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_int, c_f32],
-    "aas_adam_tick": [c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
+    "aas_adam_tick": [c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_vp],
     "aas_began_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double],
     "aas_lmfb320_fwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp],
     "aas_lmfb_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],

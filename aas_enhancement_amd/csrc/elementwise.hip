@@ -323,9 +323,9 @@ __global__ void began_step_kernel(const float* __restrict__ l_ny, const float* _
 }
 }  // namespace
 
-extern "C" int aas_adam_tick(aasStream_t stream, double* d_step, float lr, float beta1, float beta2, float* d_hyper) {
+extern "C" int aas_adam_tick(aasStream_t stream, double* d_step, double lr, double beta1, double beta2, float* d_hyper) {
     AAS_CHECK(d_step && d_hyper, "aas_adam_tick: null pointer");
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_step, (double)lr, (double)beta1, (double)beta2, d_hyper);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_step, lr, beta1, beta2, d_hyper);
     AAS_LAUNCH_CHECK("aas_adam_tick");
     return 0;
 }

@@ -267,8 +267,9 @@ int aas_adam_dev_f32(aasStream_t stream, float* p, const float* g, float* m, flo
                      int64_t n, float beta1, float beta2, float eps, const float* d_hyper, int amsgrad,
                      float grad_scale);
 
-/* d_step[0] += 1 (device-resident step counter, double) and d_hyper = {lr/(1-b1^t), sqrt(1-b2^t)} for aas_adam_dev_f32. */
-int aas_adam_tick(aasStream_t stream, double* d_step, float lr, float beta1, float beta2, float* d_hyper);
+/* d_step[0] += 1 (device-resident step counter, double) and d_hyper = {lr/(1-b1^t), sqrt(1-b2^t)} for aas_adam_dev_f32,
+ * evaluated in double from double hyper-parameters like torch.optim.Adam's host-side bias corrections. */
+int aas_adam_tick(aasStream_t stream, double* d_step, double lr, double beta1, double beta2, float* d_hyper);
 /* BEGAN proportional controller on the device (trainer_AAS.py:190-194): kt <- clip(kt + lambda_k (gamma L_cl - L_ny_G), 0, 1)
  * from device-resident loss scalars; d_out6 = [L_ny_G, L_cl, L_ctc, kt, sum += L_ctc * n_batch, sum += n_batch] (the
  * last two feed the running CTC average of the log line, :169-170,198-203). */

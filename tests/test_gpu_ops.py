@@ -437,7 +437,7 @@ def test_round2_plane_ops(ops):
         assert rel_err(Cs[i], want_c) < 2e-5, i
 
 
-@pytest.mark.parametrize("kind,T,N,H", [("lstm", 40, 30, 64), ("gru", 35, 30, 96), ("lstm", 200, 30, 500)])
+@pytest.mark.parametrize("kind,T,N,H", [("lstm", 40, 30, 64), ("gru", 35, 30, 100), ("lstm", 200, 30, 500)])
 def test_bptt_plane_output_equals_fp32_output(ops, kind, T, N, H):
     """aas_lstm_bwd_planes / aas_gru_bwd_planes: d(gates) written straight as operand planes == split of the fp32 d(gates) the
     plain entry points write (same kernel, same arithmetic, other store form), pads zero."""
@@ -468,7 +468,7 @@ def test_bptt_plane_output_equals_fp32_output(ops, kind, T, N, H):
         want = f32.view(T * N, 2 * GH)
         # the exchanged partial sums arrive in a different order run to run (ring), so compare at split precision, not bitwise
         assert (got[:, :2 * GH] - want).abs().max() <= 3e-5 * want.abs().max()
-        assert got[:, 2 * GH:].abs().max() == 0
+        assert Kp == 2 * GH or got[:, 2 * GH:].abs().max() == 0
     # exact-fp32 mode has no plane-emitting kernel: the entry point says so (rc 3) and leaves the buffer alone
     ops.set_precision(0)
     try:
