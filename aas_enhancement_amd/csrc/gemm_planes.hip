@@ -449,7 +449,11 @@ extern "C" int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const vo
         }
     }
     int rc;
-    if (big) rc = launch_planes<256, 256, 4, 2, true>(p, grid, s);
+    // 128 x 256 tiles when they still give half a chip a tile each (the persistent launches of the step hold the other half):
+    // half the re-reads of the tall operand (input gradients: d(gates) planes [T*N, 2GH]) and one round of tiles instead of two
+    const bool wide = !big && p.splitk == 1 && N >= 256 && (int64_t)cdiv(M, 128) * cdiv(N, 256) * batch >= 90 && !(p.flags & 2048);
+    if (wide) { grid = dim3(cdiv(N, 256), cdiv(M, 128), batch); rc = launch_planes<128, 256, 2, 2, true>(p, grid, s); }
+    else if (big) rc = launch_planes<256, 256, 4, 2, true>(p, grid, s);
     else if (p.splitk > 1) rc = launch_planes<128, 128, 2, 2, false>(p, grid, s);
     else rc = launch_planes<128, 128, 2, 2, true>(p, grid, s);
     AAS_CHECK(rc == 0, "aas_gemm_planes: could not raise the dynamic LDS limit");
@@ -490,7 +494,9 @@ extern "C" int aas_gemm_planes_multi(aasStream_t stream, int M, int N, int K, in
         if (sk > 1) { p.splitk = sk; grid.z = count * sk; }
     }
     int rc;
-    if (big) rc = launch_planes<256, 256, 4, 2, true>(p, grid, s);
+    const bool wide = !big && p.splitk == 1 && N >= 256 && (int64_t)cdiv(M, 128) * cdiv(N, 256) * count >= 90 && !(p.flags & 2048);
+    if (wide) { grid = dim3(cdiv(N, 256), cdiv(M, 128), count); rc = launch_planes<128, 256, 2, 2, true>(p, grid, s); }
+    else if (big) rc = launch_planes<256, 256, 4, 2, true>(p, grid, s);
     else if (p.splitk > 1) rc = launch_planes<128, 128, 2, 2, false>(p, grid, s);
     else rc = launch_planes<128, 128, 2, 2, true>(p, grid, s);
     AAS_CHECK(rc == 0, "aas_gemm_planes_multi: could not raise the dynamic LDS limit");
