@@ -449,9 +449,9 @@ extern "C" int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const vo
         }
     }
     int rc;
-    // 128 x 256 tiles when they still give half a chip a tile each (the persistent launches of the step hold the other half):
-    // half the re-reads of the tall operand (input gradients: d(gates) planes [T*N, 2GH]) and one round of tiles instead of two
-    const bool wide = !big && p.splitk == 1 && N >= 256 && (int64_t)cdiv(M, 128) * cdiv(N, 256) * batch >= 90 && !(p.flags & 2048);
+    // 128 x 256 tiles (debug bit 2048; OFF by default): half the re-reads of the tall operand and one round of tiles instead of
+    // two on half a chip, but measured SLOWER inside the step (19.7 vs 19.0 ms: 98 KB of LDS = one workgroup per CU)
+    const bool wide = !big && p.splitk == 1 && N >= 256 && (int64_t)cdiv(M, 128) * cdiv(N, 256) * batch >= 90 && (p.flags & 2048);
     if (wide) { grid = dim3(cdiv(N, 256), cdiv(M, 128), batch); rc = launch_planes<128, 256, 2, 2, true>(p, grid, s); }
     else if (big) rc = launch_planes<256, 256, 4, 2, true>(p, grid, s);
     else if (p.splitk > 1) rc = launch_planes<128, 128, 2, 2, false>(p, grid, s);
@@ -494,7 +494,7 @@ extern "C" int aas_gemm_planes_multi(aasStream_t stream, int M, int N, int K, in
         if (sk > 1) { p.splitk = sk; grid.z = count * sk; }
     }
     int rc;
-    const bool wide = !big && p.splitk == 1 && N >= 256 && (int64_t)cdiv(M, 128) * cdiv(N, 256) * count >= 90 && !(p.flags & 2048);
+    const bool wide = !big && p.splitk == 1 && N >= 256 && (int64_t)cdiv(M, 128) * cdiv(N, 256) * count >= 90 && (p.flags & 2048);
     if (wide) { grid = dim3(cdiv(N, 256), cdiv(M, 128), count); rc = launch_planes<128, 256, 2, 2, true>(p, grid, s); }
     else if (big) rc = launch_planes<256, 256, 4, 2, true>(p, grid, s);
     else if (p.splitk > 1) rc = launch_planes<128, 128, 2, 2, false>(p, grid, s);
