@@ -61,6 +61,10 @@ class Trainer(object):
         self._opts = None
         self._flat = None
         self.dp = None
+        # a parameter of D is used from two streams when the step switches schedules: autograd synchronises the accumulation
+        # correctly and says so once per process; the notice is not actionable here
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
     def build_model(self):
         print("initialize enhancement & discriminator model")
