@@ -91,6 +91,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, c_int)
+        if os.environ.get("AAS_DEBUG_FLAGS"):             # A/B kernel-selection bits of aas_set_debug_flags (include/aas_hip.h)
+            L.aas_set_debug_flags(int(os.environ["AAS_DEBUG_FLAGS"]))
         if os.environ.get("AAS_PRECISION") in ("0", "1"):  # 0 = exact fp32 MFMA, 1 = split-bf16 (library default)
             L.aas_set_precision(int(os.environ["AAS_PRECISION"]))
         _lib = L

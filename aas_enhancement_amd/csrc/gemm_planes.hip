@@ -31,6 +31,7 @@ struct PG {
     int accumulate, splitk, batch;
     int64_t sA, sB, sC;     // batch strides (elements)
     int flags;
+    int gx, gy, tiles, per; // XCD-aware launch (per > 0): 1-D grid of 8*per workgroups, workgroup L -> tile (L%8)*per + L/8
     int multi;              // > 0: `multi` independent problems with their own operand / result pointers (Am/Bm/Cm)
     const char *Am[4], *Bm[4];
     float* Cm[4];
@@ -59,8 +60,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_planes_kernel(PG p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int z = blockIdx.z;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): with the XCD-aware launch, XCD x takes a
+    // CONTIGUOUS run of tiles (n fastest, then m, then problem), so an A row block is fetched by one XCD only (its n-tiles
+    // are neighbours in the run) and a B tile once per XCD instead of once per m-tile.
+    int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+    if (p.per > 0) {
+        const int L = blockIdx.x, q = (L & 7) * p.per + (L >> 3);
+        if (q >= p.tiles) return;
+        bx = q % p.gx;
+        const int t = q / p.gx;
+        by = t % p.gy;
+        z = t / p.gy;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     int kbeg = 0, kend = p.K;
     const int bz = z / p.splitk, kz = z - bz * p.splitk;
     if (p.splitk > 1) {
@@ -219,8 +231,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_planes_kernel(PG p) {
 }
 
 template <int BM, int BN, int WM, int WN, bool SWAP>
-int launch_planes(const PG& p, dim3 grid, hipStream_t s) {
+int launch_planes(PG p, dim3 grid, hipStream_t s) {
     constexpr int LDS = 2 * (BM * 128 + BN * 128);
+    p.per = 0;
+    if (p.splitk == 1 && !(p.flags & 4096)) {   // XCD-aware tile order (debug bit 4096: plain 3-D grid)
+        p.gx = grid.x; p.gy = grid.y; p.tiles = grid.x * grid.y * grid.z;
+        p.per = (p.tiles + 7) / 8;
+        grid = dim3(8 * p.per);
+    }
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_kernel<BM, BN, WM, WN, SWAP>),

@@ -36,7 +36,8 @@ int aas_device_cus(void);
  *   GEMM kernels: 16 skip the MFMAs, 32 skip the stores, 64 skip the loads, 128 epilogue only.
  * Kernel-selection bits (results unchanged): 32 plain first exchange load in the forward kernels, 256 all-gather
  *   BPTT instead of the reduce-scatter kernel, 512 16-unit slices, 8192 poll before streaming in the reduce-scatter
- *   BPTT, 1024 128x128 tiles instead of 256x256 and 2048 128x256 instead of 128x128 in aas_gemm_planes, 16384 the general (any S) CTC kernel even when S <= 64. */
+ *   BPTT, 1024 128x128 tiles instead of 256x256 and 2048 128x256 instead of 128x128 in aas_gemm_planes, 4096 plain
+ *   3-D grid instead of the XCD-aware tile order in aas_gemm_planes, 16384 the general (any S) CTC kernel even when S <= 64. */
 int aas_set_debug_flags(int flags);
 /* Tag (>= 1) of the persistent recurrent launches queued after the call.  Every bounded spin in those kernels gives
  * up after ~0.5 s and stores the tag of its launch in a sticky error word at byte 4096 of the launch's `sync` buffer
