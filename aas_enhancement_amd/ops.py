@@ -434,6 +434,7 @@ class _LinearRows(torch.autograd.Function):
         x2 = x.view(-1, x.shape[-1])
         y = linear_fwd(x2, W2, _c(b) if b is not None else None)
         ctx.save_for_backward(x2, W2)
+        ctx.params = (W, b)          # the nn.Parameters themselves (direct accumulation into their flat-buffer .grad)
         ctx.rs, ctx.nb = rs, (x.shape[1] if x.dim() == 3 else 1)
         ctx.wshape = W.shape
         ctx.has_b = b is not None
@@ -444,14 +445,46 @@ class _LinearRows(torch.autograd.Function):
     def backward(ctx, gy):
         x2, W2 = ctx.saved_tensors
         gy2 = _c(gy).view(-1, W2.shape[0])
+        W, b = ctx.params
+        need_dw = ctx.needs_input_grad[1]
+        need_db = ctx.has_b and ctx.needs_input_grad[2]
+        # Parameter gradients off the critical path: when W (and b) live in a flat gradient buffer, dW = gy^T x and db =
+        # colsum(gy) are accumulated straight into .grad on the weight-gradient stream (joined by ops.sync_wgrad before the
+        # optimiser reads them); only dx, which the rest of the backward pass waits for, stays on this stream.
+        direct = (DIRECT_WGRAD[0] and need_dw and getattr(W, "_aas_flat_grad", False) and W.grad is not None and W.grad.is_contiguous()
+                  and (not need_db or (getattr(b, "_aas_flat_grad", False) and b.grad is not None)))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _, _ = linear_bwd(x2, W2, gy2, need_dx=True, need_db=False, need_dw=False)
+        if direct:
+            main = torch.cuda.current_stream()
+            side = wgrad_stream(gy2.device)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            rs, nb = ctx.rs, ctx.nb
+            gW = W.grad.view(W2.shape[0], -1)
+            gb = b.grad if need_db else None
+            R_, K_, N_ = x2.shape[0], x2.shape[1], W2.shape[0]
+
+            def run():
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    g2 = scale_rows(gy2, rs, nb) if rs is not None else gy2
+                    gemm(TN, N_, K_, R_, g2, N_, x2, K_, gW, K_, accumulate=True)
+                    if gb is not None:
+                        check(lib().aas_colsum_f32(stream(), ptr(g2), R_, N_, N_, ptr(gb), 1), "aas_colsum_f32")
+            for t_ in (gy2, x2):
+                t_.record_stream(side)
+            if DEFER_WGRAD[0]:
+                _deferred.append(run)
+            else:
+                run()
+            return (dx.view(ctx.xshape) if dx is not None else None), None, None, None
         if ctx.rs is None:
-            dx, dW, db = linear_bwd(x2, W2, gy2, need_dx=ctx.needs_input_grad[0], need_db=ctx.has_b and ctx.needs_input_grad[2],
-                                    need_dw=ctx.needs_input_grad[1])
+            _, dW, db = linear_bwd(x2, W2, gy2, need_dx=False, need_db=need_db, need_dw=need_dw)
         else:  # per-utterance weights on the parameter gradients only
-            dx, _, _ = linear_bwd(x2, W2, gy2, need_dx=ctx.needs_input_grad[0], need_db=False, need_dw=False)
             gys = scale_rows(gy2, ctx.rs, ctx.nb)
-            _, dW, db = linear_bwd(x2, W2, gys, need_dx=False, need_db=ctx.has_b and ctx.needs_input_grad[2],
-                                   need_dw=ctx.needs_input_grad[1])
+            _, dW, db = linear_bwd(x2, W2, gys, need_dx=False, need_db=need_db, need_dw=need_dw)
         return (dx.view(ctx.xshape) if dx is not None else None), (dW.view(ctx.wshape) if dW is not None else None), db, None
 
 
