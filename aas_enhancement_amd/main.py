@@ -31,6 +31,9 @@ def main(config):
     # one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE come from the launcher's environment.  Every rank reads the same
     # manifests with the same seed, so all ranks draw the same global minibatch and keep their strided shard of it.
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and config.trainer not in ("AAS", "acoustic_supervision"):
+        raise NotImplementedError("data parallel training is implemented for --trainer AAS / acoustic_supervision (and am_train); "
+                                  "%r would train the full batch on every rank" % config.trainer)
     if world > 1:
         import torch.distributed as dist
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
