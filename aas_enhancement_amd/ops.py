@@ -133,6 +133,7 @@ def device_cus():
 # (autograd gets None for those inputs): they are only needed at the optimiser step, so they overlap the next
 # layer's persistent BPTT launch instead of sitting on the backward critical path.  sync_wgrad() joins.
 DIRECT_WGRAD = [True]    # kill switch; the path is taken only for parameters re-homed by dist.FlatBuffers (_aas_flat_grad)
+LINEAR_DIRECT = [os.environ.get("AAS_LINEAR_DIRECT", "1") == "1"]   # pointwise linear layers take the same side-stream path
 WGRAD_HOOK = [None]      # callable(list of .grad views) run on the side stream after a layer's products are queued
 _SKIP_WGRAD = bool(int(__import__('os').environ.get('AAS_SKIP_WGRAD', '0')))
 _wgrad_streams = {}
@@ -451,7 +452,7 @@ class _LinearRows(torch.autograd.Function):
         # Parameter gradients off the critical path: when W (and b) live in a flat gradient buffer, dW = gy^T x and db =
         # colsum(gy) are accumulated straight into .grad on the weight-gradient stream (joined by ops.sync_wgrad before the
         # optimiser reads them); only dx, which the rest of the backward pass waits for, stays on this stream.
-        direct = (DIRECT_WGRAD[0] and need_dw and getattr(W, "_aas_flat_grad", False) and W.grad is not None and W.grad.is_contiguous()
+        direct = (DIRECT_WGRAD[0] and LINEAR_DIRECT[0] and need_dw and getattr(W, "_aas_flat_grad", False) and W.grad is not None and W.grad.is_contiguous()
                   and (not need_db or (getattr(b, "_aas_flat_grad", False) and b.grad is not None)))
         dx = None
         if ctx.needs_input_grad[0]:
