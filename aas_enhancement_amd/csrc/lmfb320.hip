@@ -6,10 +6,12 @@
 //     e[j] = x'[j] + x'[320-j], o[j] = x'[j] - x'[320-j]      (1 <= j <= 159; e[0] = x'[0], e[160] = x'[160])
 //     ee[j] = e[j] + e[160-j] (0<=j<=80, ee[80] = e[80])   eo[j] = e[j] - e[160-j] (0<=j<=79)
 //     oe[j] = o[j] - o[160-j] (1<=j<=79)                   oo[j] = o[j] + o[160-j] (1<=j<=80, oo[80] = o[80])
+//     (all four operands are stored at k = j; table rows outside a segment's j range are zero)
 //     Re X[2c]   = sum_j ee[j] cos(2 pi j 2c / 320)         Re X[2c+1] = sum_j eo[j] cos(2 pi j (2c+1) / 320)
 //     Im X[2c]   = -sum_j oe[j] sin(2 pi j 2c / 320)        Im X[2c+1] = -sum_j oo[j] sin(2 pi j (2c+1) / 320)
 // i.e. four products of [frames, <=81] x [<=81, <=81] instead of one [frames, 320] x [320, 322]: 4x fewer MFMA flops.
-// The hamming window is applied to the samples (it is not symmetric under j -> 160-j, so it cannot live in the tables).
+// The hamming window is applied to the folded samples (w[320-j] = w[j] and w[160+j] = w[160-j], so each first-fold pair shares
+// one weight; it is not symmetric under j -> 160-j, so it cannot live in the tables).
 //
 // One persistent workgroup per CU (256 threads).  Each wave keeps ITS column groups' table fragments (bf16 hi | lo, the
 // split-bf16 product hi*hi + lo*hi + hi*lo used everywhere in this library) in REGISTERS for the whole launch - 144 VGPRs
@@ -95,6 +97,10 @@ __global__ __launch_bounds__(256, 2) void lmfb320_kernel(LP p) {
     }
     __syncthreads();
 
+    // fold role of this thread (constant over the launch): j pair and first frame, window weights in registers
+    const int fold_fg = tid / 41, fj0 = 2 * (tid - fold_fg * 41);
+    const bool fold_on = fold_fg < 6;
+    const float fw[4] = {wl[fj0], wl[160 - fj0], wl[fj0 + 1], wl[159 - fj0]};
     const int total = p.N * p.tiles_per_utt;
     // Software pipeline: the samples of tile i+1 are fetched into registers (3 x 16 bytes per thread) while tile i is folded,
     // multiplied and written; they go to LDS at the top of the next iteration.  Interior tiles (no reflection, no batch
@@ -160,45 +166,37 @@ __global__ __launch_bounds__(256, 2) void lmfb320_kernel(LP p) {
         }
         prefetch(tile + 1 < tile_end ? tile + 1 : total);
         __syncthreads();
-        // ---- window + two folds + bf16 hi/lo split -> A planes [frame][segment][k]
-        if (!(p.flags & 2))
-        for (int i = tid; i < TF * 81; i += 256) {
-            const int f = i / 81, j = i - f * 81;
-            const float* x = seg + f * HOP;
-            const float a = x[j] * wl[j];
-            const float c = x[160 - j] * wl[160 - j];
-            float b = 0.f, d = 0.f;
-            if (j >= 1) {
-                b = x[320 - j] * wl[320 - j];
-                d = x[160 + j] * wl[160 + j];
-            }
-            float ee, eo, oe, oo;
-            if (j == 80) {                                    // the pair (80, 240) folds onto itself
-                ee = a + b; oo = a - b; eo = 0.f; oe = 0.f;
-            } else {
-                const float e1 = a + b, e2 = c + d, o1 = a - b, o2 = c - d;
-                ee = e1 + e2; eo = e1 - e2; oe = o1 - o2; oo = o1 + o2;
-            }
-            unsigned short h, l;
-            char* rh = a_hi + f * A_STRIDE;
-            char* rl = a_lo + f * A_STRIDE;
-            split2(ee, h, l);
-            *reinterpret_cast<unsigned short*>(rh + (0 * SEGK + j) * 2) = h;
-            *reinterpret_cast<unsigned short*>(rl + (0 * SEGK + j) * 2) = l;
-            if (j <= 79) {
-                split2(eo, h, l);
-                *reinterpret_cast<unsigned short*>(rh + (1 * SEGK + j) * 2) = h;
-                *reinterpret_cast<unsigned short*>(rl + (1 * SEGK + j) * 2) = l;
-            }
-            if (j >= 1 && j <= 79) {
-                split2(oe, h, l);
-                *reinterpret_cast<unsigned short*>(rh + (2 * SEGK + j - 1) * 2) = h;
-                *reinterpret_cast<unsigned short*>(rl + (2 * SEGK + j - 1) * 2) = l;
-            }
-            if (j >= 1) {
-                split2(oo, h, l);
-                *reinterpret_cast<unsigned short*>(rh + (3 * SEGK + j - 1) * 2) = h;
-                *reinterpret_cast<unsigned short*>(rl + (3 * SEGK + j - 1) * 2) = l;
+        // ---- window + two folds + bf16 hi/lo split -> A planes [frame][segment][k = j]
+        // thread -> (pair of neighbouring j: j0 = 2 jp, j1 = j0 + 1; frames fg, fg+6, fg+12): the window weights sit in
+        // registers, the four segments are written as 4-byte hi / lo pairs.  Values at k positions whose table row is zero
+        // (k = 0 of the sine segments, k = 80 of segments 1 and 2, k = 81) are harmless and left as computed.
+        if (!(p.flags & 2) && fold_on) {
+            for (int f = fold_fg; f < TF; f += 6) {
+                const float* x = seg + f * HOP;
+                // the periodic hamming window is symmetric in both folds' pairs: w[320-j] = w[j], w[160+j] = w[160-j]
+                const float a0 = x[fj0], c0 = x[160 - fj0];
+                const float b0 = fj0 >= 1 ? x[320 - fj0] : 0.f, d0 = fj0 >= 1 ? x[160 + fj0] : 0.f;
+                const float a1 = x[fj0 + 1], b1 = x[319 - fj0], c1 = x[159 - fj0], d1 = x[161 + fj0];
+                float v0[4], v1[4];
+                {
+                    const float e1 = (a0 + b0) * fw[0], e2 = (c0 + d0) * fw[1], o1 = (a0 - b0) * fw[0], o2 = (c0 - d0) * fw[1];
+                    const bool mid = fj0 == 80;                 // the pair (80, 240) folds onto itself
+                    v0[0] = mid ? e1 : e1 + e2; v0[1] = e1 - e2; v0[2] = o1 - o2; v0[3] = mid ? o1 : o1 + o2;
+                }
+                {
+                    const float e1 = (a1 + b1) * fw[2], e2 = (c1 + d1) * fw[3], o1 = (a1 - b1) * fw[2], o2 = (c1 - d1) * fw[3];
+                    v1[0] = e1 + e2; v1[1] = e1 - e2; v1[2] = o1 - o2; v1[3] = o1 + o2;
+                }
+                char* rh = a_hi + f * A_STRIDE + fj0 * 2;
+                char* rl = a_lo + f * A_STRIDE + fj0 * 2;
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) {
+                    unsigned short h0, l0, h1, l1;
+                    split2(v0[sgm], h0, l0);
+                    split2(v1[sgm], h1, l1);
+                    *reinterpret_cast<unsigned*>(rh + sgm * SEGK * 2) = (unsigned)h0 | ((unsigned)h1 << 16);
+                    *reinterpret_cast<unsigned*>(rl + sgm * SEGK * 2) = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
             }
         }
         __syncthreads();

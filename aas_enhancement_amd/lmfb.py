@@ -50,16 +50,16 @@ def dft_table(win):
 
 def folded_dft_tables():
     """bf16 hi | lo twiddles of the twice-folded 320-point real DFT (csrc/lmfb320.hip): uint16 [2, 4, 96, 96] =
-    [plane][segment][column c][k]; segment 0: cos(2 pi j 2c / 320), j = k <= 80, c <= 80; 1: cos(2 pi j (2c+1) / 320),
-    j = k <= 79, c <= 79; 2: sin(2 pi j 2c / 320), j = k+1 <= 79; 3: sin(2 pi j (2c+1) / 320), j = k+1 <= 80; zero elsewhere."""
+    [plane][segment][column c][k = j]; segment 0: cos(2 pi j 2c / 320), j <= 80, c <= 80; 1: cos(2 pi j (2c+1) / 320),
+    j <= 79, c <= 79; 2: sin(2 pi j 2c / 320), 1 <= j <= 79; 3: sin(2 pi j (2c+1) / 320), 1 <= j <= 80; zero elsewhere."""
     tab = np.zeros((4, 96, 96), np.float64)
     c = np.arange(96)[:, None].astype(np.float64)
     k = np.arange(96)[None, :].astype(np.float64)
     w = 2.0 * np.pi / 320.0
     tab[0] = np.where((c <= 80) & (k <= 80), np.cos(w * k * 2 * c), 0.0)
     tab[1] = np.where((c <= 79) & (k <= 79), np.cos(w * k * (2 * c + 1)), 0.0)
-    tab[2] = np.where((c <= 80) & (k <= 78), np.sin(w * (k + 1) * 2 * c), 0.0)
-    tab[3] = np.where((c <= 79) & (k <= 79), np.sin(w * (k + 1) * (2 * c + 1)), 0.0)
+    tab[2] = np.where((c <= 80) & (k >= 1) & (k <= 79), np.sin(w * k * 2 * c), 0.0)
+    tab[3] = np.where((c <= 79) & (k >= 1) & (k <= 80), np.sin(w * k * (2 * c + 1)), 0.0)
     t32 = torch.from_numpy(tab.astype(np.float32))
     hi = t32.to(torch.bfloat16)
     lo = (t32 - hi.float()).to(torch.bfloat16)

@@ -290,8 +290,9 @@ int aas_lmfb_fwd(aasStream_t stream, const float* wave, int N, int S, int win, i
  * hop = 160; AM_training/train.py:39-42) and for batches of utterances of DIFFERENT lengths: d_lens[n] (device, may be
  * NULL = S) valid samples of utterance n; frames t >= 1 + d_lens[n]/160 are written as zeros, reflect padding is at the
  * utterance's own ends.  Constant tables from the caller (aas_enhancement_amd/lmfb.py):
- *   tables     [2 (bf16 hi, lo)][4 segments][96 columns][96 k] bf16: cos(2 pi j 2c/320), cos(2 pi j (2c+1)/320),
- *              sin(2 pi (j+1) 2c/320), sin(2 pi (j+1) (2c+1)/320) - the twiddles of the twice-folded real DFT;
+ *   tables     [2 (bf16 hi, lo)][4 segments][96 columns c][96 k = j] bf16: cos(2 pi j 2c/320) (j <= 80), cos(2 pi j (2c+1)/320)
+ *              (j <= 79), sin(2 pi j 2c/320) (1 <= j <= 79), sin(2 pi j (2c+1)/320) (1 <= j <= 80), zero elsewhere - the
+ *              twiddles of the twice-folded real DFT;
  *   window     [320] hamming (periodic);  mel_start / mel_cnt [n_mels] first bin and width of each triangular filter,
  *   mel_w      [n_mels][mel_maxw = 24] its weights. */
 int aas_lmfb320_fwd(aasStream_t stream, const float* wave, const int* d_lens, int N, int S, int n_mels,
