@@ -25,6 +25,32 @@ from .model import DeepSpeech, L1Loss_mask, stackedBRNN, supported_rnns
 from .utils import AverageMeter, _get_variable_nograd, _get_variable_volatile, attach_n_valid
 
 
+class _LazyScales(object):
+    """(w_adversarial / nElement_noisy, w_adversarial / nElement_clean, w_acoustic / N) from counts that are all-reduced on an
+    auxiliary stream: whichever stream reads a scale first waits for that stream's event (device side, not host side), so the
+    collective's latency hides behind the forward passes queued in the meantime."""
+
+    def __init__(self, dp, cnt, config, aux):
+        main = torch.cuda.current_stream()
+        aux.wait_stream(main)                      # the upload of `cnt`
+        with torch.cuda.stream(aux):
+            dp.reduce_scalars(cnt)
+            self.vals = ((config.w_adversarial / cnt[1]).float(), (config.w_adversarial / cnt[2]).float(), (config.w_acoustic / cnt[0]).float())
+            self.cnt = cnt
+            self.ev = torch.cuda.Event()
+            self.ev.record(aux)
+        for t_ in self.vals + (cnt,):
+            t_.record_stream(main)
+
+    def __getitem__(self, i):
+        torch.cuda.current_stream().wait_event(self.ev)
+        return self.vals[i]
+
+    def count(self, i):
+        torch.cuda.current_stream().wait_event(self.ev)
+        return self.cnt[i]
+
+
 class Trainer(object):
     def __init__(self, config, data_loader=None, models=None):
         self.config = config
@@ -324,9 +350,12 @@ class Trainer(object):
         dev = inputs.device
         if dp.active:
             cnt = self._upload_small(torch.tensor([float(N), float(nv_ny), float(nv_cl)], dtype=torch.float64), dev)
-            dp.reduce_scalars(cnt)                       # global N, nElement(noisy), nElement(clean): stays on the device
-            scales = ((c.w_adversarial / cnt[1]).float(), (c.w_adversarial / cnt[2]).float(), (c.w_acoustic / cnt[0]).float())
-            n_glob = cnt[0]
+            # global N, nElement(noisy), nElement(clean): all-reduced asynchronously and kept on the device; the loss scales are
+            # only formed when the first loss needs them (after the forward passes), so the collective's latency hides behind E
+            if getattr(self, "_aux_stream", None) is None:
+                self._aux_stream = torch.cuda.Stream()
+            scales = _LazyScales(dp, cnt, c, self._aux_stream)
+            n_glob = scales
             self._reducer.begin()
             ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
         else:
@@ -363,8 +392,8 @@ class Trainer(object):
         self._g_out[:3].copy_(packed)
         self._g_out[3:4].copy_(self._kt_dev)
         # running CTC average of the log line (ctc_tr_local.update(l_ctc, N) every iteration, :169-170) kept on the device
-        self._g_out[4:5].add_(packed[2] * n_glob)
-        self._g_out[5:6].add_(n_glob)
+        self._g_out[4:5].add_(packed[2] * n_glob.count(0))
+        self._g_out[5:6].add_(n_glob.count(0))
         return enhanced, prob
 
     def _batched_D_core(self, inputs, cl_inputs, scales, ctc_meta, asr_steps):
