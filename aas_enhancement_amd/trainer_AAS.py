@@ -384,16 +384,24 @@ class Trainer(object):
         if not dp.active:   # controller + log scalars in one tiny launch
             ops.began_step(l_adv_ny_G, l_adv_cl, l_CTC, self._kt_dev, self._g_out, self.gamma, self.lb, n_glob)
             return enhanced, prob
+        # data parallel: the three loss scalars are all-reduced and kt advanced on the auxiliary stream - the main stream goes
+        # straight on to the next step and only waits for this event where kt is read (the weight-gradient scaling of D)
+        main, aux = torch.cuda.current_stream(), self._aux_stream
         packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), l_CTC.detach().reshape(())]).double()
-        dp.reduce_scalars(packed)   # every loss is already divided by its GLOBAL normaliser: the sum over ranks is the loss
-        # Proportional Control Theory (:190-194) on the device
-        bal = self.gamma * packed[1] - packed[0]
-        self._kt_dev.copy_(torch.clamp(self._kt_dev + self.lb * bal, 0.0, 1.0))
-        self._g_out[:3].copy_(packed)
-        self._g_out[3:4].copy_(self._kt_dev)
-        # running CTC average of the log line (ctc_tr_local.update(l_ctc, N) every iteration, :169-170) kept on the device
-        self._g_out[4:5].add_(packed[2] * n_glob.count(0))
-        self._g_out[5:6].add_(n_glob.count(0))
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            dp.reduce_scalars(packed)   # every loss is already divided by its GLOBAL normaliser: the sum over ranks is the loss
+            # Proportional Control Theory (:190-194) on the device
+            bal = self.gamma * packed[1] - packed[0]
+            self._kt_dev.copy_(torch.clamp(self._kt_dev + self.lb * bal, 0.0, 1.0))
+            self._g_out[:3].copy_(packed)
+            self._g_out[3:4].copy_(self._kt_dev)
+            # running CTC average of the log line (ctc_tr_local.update(l_ctc, N) every iteration, :169-170) kept on the device
+            self._g_out[4:5].add_(packed[2] * n_glob.count(0))
+            self._g_out[5:6].add_(n_glob.count(0))
+            self._kt_ev = torch.cuda.Event()
+            self._kt_ev.record(aux)
+        packed.record_stream(aux)
         return enhanced, prob
 
     def _batched_D_core(self, inputs, cl_inputs, scales, ctc_meta, asr_steps):
@@ -405,6 +413,7 @@ class Trainer(object):
         leaf = enhanced.detach().requires_grad_(True)
         overlap = self._overlap_asr()
         acoustic = None
+        self._wait_kt()
         rs = torch.empty(N + cl_inputs.size(0), device=dev, dtype=torch.float32)
         rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
         rs[N:] = 1.0
@@ -473,6 +482,7 @@ class Trainer(object):
         ops.set_rnn_cu_limit(int(os.environ.get("AAS_LANE_CUS", "0")) or ops.device_cus() // 2)
         if dp.active:
             self._reducer.expect(self._flat["D"], 2)      # every D layer is back-propagated twice: reduce after the second
+        self._wait_kt()
         rs = (-self._kt_dev).to(torch.float32).expand(N).contiguous()
 
         def alternate(gen_main, gen_side):
@@ -512,6 +522,12 @@ class Trainer(object):
         if dp.active:
             self._reducer.flush(self._flat["D"])
         return enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC
+
+    def _wait_kt(self):
+        """The device-resident kt (and the scalars of the last step) may still be in flight on the auxiliary stream (data parallel)."""
+        ev = getattr(self, "_kt_ev", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def _ensure_dev_state(self, dev):
         if getattr(self, "_kt_dev", None) is None:
@@ -580,6 +596,7 @@ class Trainer(object):
     def read_scalars(self):
         """One D2H copy of (l_adv_ny_G, l_adv_cl, l_ctc, kt) of the last train_step_async; updates the host-side kt and the
         running CTC average, and (it is a synchronisation point) raises if a persistent kernel timed out or the run diverged."""
+        self._wait_kt()
         l_adv_ny_G, l_adv_cl, l_ctc, kt, ctc_sum, ctc_n = self._g_out.tolist()
         self._g_out[4:6].zero_()
         ops.check_rnn_health((l_adv_ny_G, l_adv_cl, l_ctc))
