@@ -22,14 +22,14 @@ import torch
 from . import ops
 from .ctc import CTCLoss
 from .decoder import GreedyDecoder
-from .dist import BucketReducer, DPContext, FlatBuffers
+from .dist import BucketReducer, DeviceCounts, DPContext, FlatBuffers
 from .model import DeepSpeech, supported_rnns
 from .optim import FlatAdam
 from .utils import AverageMeter, _get_variable_nograd
 
 
 class AMTrainer(object):
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), dp=None, labels=None):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), dp=None, labels=None, sync_bn=False):
         self.model = model
         self.criterion = CTCLoss()
         ops.name_layers(model, "A")
@@ -37,6 +37,8 @@ class AMTrainer(object):
         self.opt = FlatAdam(self.flat, lr=lr, betas=betas, amsgrad=False)
         self.dp = dp or DPContext.from_env()
         self._reducer = BucketReducer(self.dp, [self.flat]) if self.dp.active else None
+        # data parallel: BatchNorm statistics over the GLOBAL batch (default: local-batch statistics per rank)
+        ops.SYNC_BN[0] = self.dp if (self.dp.active and sync_bn) else None
         self.decoder = GreedyDecoder(labels if labels is not None else DeepSpeech.get_labels(model))
         self.losses = AverageMeter()
 
@@ -48,7 +50,10 @@ class AMTrainer(object):
         t_out = self.model.output_length(inputs.size(2))
         sizes = input_percentages.clone().mul_(int(t_out)).int()
         meta = self.criterion.prepare(targets, sizes, target_sizes, inputs.device)
-        N_glob = self.dp.global_counts([N])[0] if self.dp.active else N
+        if self.dp.active:   # global batch size as a device scalar (no host sync before the step is queued)
+            if getattr(self, "_aux", None) is None:
+                self._aux = torch.cuda.Stream()
+            counts = DeviceCounts(self.dp, [N], inputs.device, self._aux)
         ops.sync_wgrad()
         self.flat.zero_grad()
         if self._reducer is not None:
@@ -56,7 +61,8 @@ class AMTrainer(object):
             ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
         try:
             out = self.model(inputs).transpose(0, 1)
-            loss = self.criterion(out, targets, sizes, target_sizes, prepared=meta) / N_glob
+            loss = self.criterion(out, targets, sizes, target_sizes, prepared=meta)
+            loss = loss * (1.0 / counts.get(0)).float() if self.dp.active else loss / N
             loss.backward()
             ops.sync_wgrad()
             if self._reducer is not None:
@@ -234,6 +240,7 @@ def main(argv=None):
     ap.add_argument("--no_sortagrad", dest="sortagrad", action="store_false")
     ap.add_argument("--seed", default=123456, type=int)
     ap.add_argument("--dist_backend", default="nccl")
+    ap.add_argument("--sync_bn", action="store_true", help="data parallel: all-reduce the BatchNorm statistics (global-batch BN)")
     a = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
@@ -256,7 +263,7 @@ def main(argv=None):
         model = DeepSpeech(rnn_hidden_size=a.rnn_size, rnn_layers=a.rnn_layers, rnn_type=supported_rnns[a.rnn_type.lower()], labels=labels,
                            kernel_sz=a.conv_kernel, stride=a.conv_stride, map=a.conv_map, cnn_layers=a.conv_layers, nFreq=a.nFreq)
         weights_init(model)
-        tr, start_epoch, hist = AMTrainer(model.cuda(), lr=a.lr, labels=labels), 0, None
+        tr, start_epoch, hist = AMTrainer(model.cuda(), lr=a.lr, labels=labels, sync_bn=a.sync_bn), 0, None
     n_train = (len(dl._ds["ny/train"]) + a.batch_size - 1) // a.batch_size
     if not (a.sortagrad and start_epoch == 0):
         dl._sp["ny/train"].shuffle()

@@ -95,6 +95,31 @@ class DPContext(object):
         return (inputs.index_select(0, idx.to(inputs.device)), tg, pct.index_select(0, idx), tsz.index_select(0, idx), m)
 
 
+class DeviceCounts(object):
+    """SUM over ranks of a few per-rank counts (N, nElement ...) WITHOUT a host synchronisation: the values go up through a
+    pinned buffer, are all-reduced on an auxiliary stream and stay on the device as fp64 scalars; a stream that reads one
+    waits for that stream's event.  (global_counts() returns python ints instead and therefore blocks the host until the
+    device has caught up - fine for a logging path, not at the top of a training step.)"""
+
+    def __init__(self, dp, values, device, aux_stream, pinned=None):
+        host = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        if pinned is not None:
+            pinned[:host.numel()].copy_(host)
+            host = pinned[:host.numel()]
+        main = torch.cuda.current_stream()
+        aux_stream.wait_stream(main)
+        with torch.cuda.stream(aux_stream):
+            self.t = host.to(device, non_blocking=True)
+            dp.reduce_scalars(self.t)
+            self.ev = torch.cuda.Event()
+            self.ev.record(aux_stream)
+        self.t.record_stream(main)
+
+    def get(self, i):
+        torch.cuda.current_stream().wait_event(self.ev)
+        return self.t[i]
+
+
 class _Done(object):
     def wait(self):
         return True

@@ -124,3 +124,58 @@ def test_trainer_dp_two_ranks_equals_single(mode):
         if mode == "syncbn":
             assert np.abs(prob - prob_ref[:, rank::2]).max() < 1e-3 * np.abs(prob_ref).max()
     assert np.array_equal(res[0][2], res[1][2])  # identical parameters on every rank
+
+
+def _am_model():
+    import torch.nn as nn
+    from aas_enhancement_amd import prng
+    from aas_enhancement_amd.model import DeepSpeech
+    from tests.helpers import LABELS, load_sd
+    A = DeepSpeech(nn.GRU, LABELS, 12, 3, True, 11, 2, 8, 2, nFreq=8)
+    load_sd(A, {k: torch.from_numpy(v) for k, v in prng.fill_state_dict(A.state_dict(), 21, conv_std=0.1).items()}, strict=False)
+    return A.cuda()
+
+
+def _am_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"] = str(rank); os.environ["WORLD_SIZE"] = str(world)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from aas_enhancement_amd.am_train import AMTrainer
+        from aas_enhancement_amd.dist import DPContext
+        tr = AMTrainer(_am_model(), lr=1e-3, dp=DPContext.from_env(), sync_bn=True)
+        ny, _ = _batches()
+        shard = tr.dp.shard_collated(ny)
+        out = [tr.train_step(shard)["loss"] for _ in range(2)]
+        q.put((rank, out, tr.flat.flat_p.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_am_trainer_dp_with_syncbn_equals_single():
+    """AM pre-training step (config 5's per-GPU step) data parallel: global batch size as a device scalar, bucketed all-reduce of
+    A's gradients, SyncBN - 2 ranks x 2 utterances == 1 rank x 4 utterances (loss and parameters after two Adam steps)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_am_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from aas_enhancement_amd.am_train import AMTrainer
+    tr = AMTrainer(_am_model(), lr=1e-3)
+    ny, _ = _batches()
+    ref = [tr.train_step(ny)["loss"] for _ in range(2)]
+    want = tr.flat.flat_p.detach().cpu().numpy()
+    for rank, out, par in res:
+        assert np.allclose(out, ref, rtol=2e-4), (rank, out, ref)
+        d_ = np.abs(par - want)
+        assert float((d_ > 2e-4).mean()) < 5e-3 and float(d_.max()) < 4.1e-3, rank   # (Adam sign flips of noise-level gradients)
+    assert np.array_equal(res[0][2], res[1][2])
