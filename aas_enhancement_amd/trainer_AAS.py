@@ -509,7 +509,7 @@ class Trainer(object):
             prob = out_a.transpose(0, 1)
             l_CTC = ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) * scales[2]
         # ---- their backward passes, alternating (nodes pop in reverse creation order, each on its forward's stream)
-        torch.autograd.backward([l_adv_ny_G, l_CTC])
+        self._backward_pair(l_adv_ny_G, l_CTC, main, side)
         if dp.active and asr_steps:
             with torch.cuda.stream(side):
                 self._reducer.flush(self._flat["A"])
@@ -742,9 +742,26 @@ class Trainer(object):
                 l_CTC = ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) * scales[2]
             else:
                 l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / N_glob
-        side.wait_stream(main)   # the combined backward is issued from the main stream's context
-        torch.autograd.backward([l_adv_ny_G + l_adv_cl, l_CTC])
+        self._backward_pair(l_adv_ny_G + l_adv_cl, l_CTC, main, side)
         return l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a
+
+    def _backward_pair(self, loss_main, loss_side, main, side):
+        """ONE autograd call over two losses whose graphs live on two streams, without tying the streams together.
+        The engine makes every root's consumer wait for the stream that is current when backward() is called (it assumes the
+        root gradients were produced there): called from the main stream, the side chain's backward would wait for everything
+        queued on main - i.e. the acoustic backward for the tail of D's forward.  So the root gradients are created on the
+        streams of their losses and the call is issued from a stream that has nothing queued."""
+        if os.environ.get("AAS_NEUTRAL_BWD", "1") != "1":
+            side.wait_stream(main)
+            torch.autograd.backward([loss_main, loss_side])
+            return
+        if getattr(self, "_neutral_stream", None) is None:
+            self._neutral_stream = torch.cuda.Stream()
+        g_main = torch.ones_like(loss_main)
+        with torch.cuda.stream(side):
+            g_side = torch.ones_like(loss_side)
+        with torch.cuda.stream(self._neutral_stream):
+            torch.autograd.backward([loss_main, loss_side], [g_main, g_side])
 
     def _interleave_ok(self):
         c = self.config
