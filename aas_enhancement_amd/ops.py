@@ -662,6 +662,10 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
             with _timed("rnn", "gru_bwd[N=%d,H=%d]" % (N, H), rflops, T):
                 check(lib().aas_gru_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(dgx),
                                         ptr(dgh), ptr(sync), ptr(xchg)), "aas_gru_bwd")
+    # the weight-gradient products (side stream) only need the BPTT launch's output: their event is recorded here, BEFORE the
+    # input-gradient GEMM is queued, so they may start beside it
+    ev_bptt = torch.cuda.Event()
+    ev_bptt.record(torch.cuda.current_stream())
     x2 = x.view(T * N, I)
     dx = None
     if need_dx:
@@ -745,8 +749,9 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     if direct is not None:
         main = torch.cuda.current_stream()
         side = wgrad_stream(dev)
-        ev = torch.cuda.Event()
-        ev.record(main)
+        ev = ev_bptt if os.environ.get("AAS_WGRAD_EARLY", "1") == "1" else torch.cuda.Event()
+        if ev is not ev_bptt:
+            ev.record(main)
         hook = WGRAD_HOOK[0]
 
         def run():
