@@ -374,9 +374,11 @@ class Trainer(object):
         finally:
             ops.WGRAD_HOOK[0] = None
         optimizer_g.step_dev()
-        optimizer_d.step_dev()
-        if asr_steps:
-            optimizer_asr.step_dev()
+        if not getattr(self, "_early_adam", False):
+            optimizer_d.step_dev()
+            if asr_steps:
+                optimizer_asr.step_dev()
+        self._early_adam = False
         # the updated weights' operand planes for the next step, off the critical path (weight-gradient stream)
         for net, on in ((self.G, True), (self.D, True), (self.ASR, asr_steps)):
             if on and not capturing:
@@ -449,6 +451,18 @@ class Trainer(object):
             self._reducer.flush(self._flat["D"])
             if asr_steps:
                 self._reducer.flush(self._flat["A"])
+        elif os.environ.get("AAS_EARLY_ADAM", "1") == "1" and not torch.cuda.is_current_stream_capturing():
+            # D's (and a trainable A's) gradients are complete once the products queued on the weight-gradient stream have run:
+            # their Adam steps and weight-plane refreshes go onto that stream now and overlap E's backward instead of
+            # following it (every parameter gradient of D is produced on that stream; A's BatchNorm / conv / fc ones on `side`)
+            wg = ops.wgrad_stream(leaf.device)
+            if asr_steps:
+                wg.wait_stream(self._side)
+            with torch.cuda.stream(wg):
+                self._opts[2].step_dev()
+                if asr_steps:
+                    self._opts[1].step_dev()
+            self._early_adam = True
         enhanced.backward(gsum)
         return enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC
 
