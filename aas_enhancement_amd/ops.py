@@ -749,7 +749,9 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     if direct is not None:
         main = torch.cuda.current_stream()
         side = wgrad_stream(dev)
-        ev = ev_bptt if os.environ.get("AAS_WGRAD_EARLY", "1") == "1" else torch.cuda.Event()
+        # (plane path only: the fp32 path scales d(gates) IN PLACE for the per-utterance weights, which must not overlap the
+        #  input-gradient GEMM that reads them)
+        ev = ev_bptt if (use_planes and T > 1 and os.environ.get("AAS_WGRAD_EARLY", "1") == "1") else torch.cuda.Event()
         if ev is not ev_bptt:
             ev.record(main)
         hook = WGRAD_HOOK[0]
