@@ -31,6 +31,7 @@ SIGNATURES = {
     "aas_gemm_planes": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                         c_int, c_i64, c_i64, c_i64],
     "aas_gemm_planes_multi": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64],
+    "aas_gemm_planes_tn": [c_vp, c_int] + [c_vp] * 18 + [c_int, c_int, c_vp, c_int],
     "aas_split_planes": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_int],
     "aas_split_planes_t": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
     "aas_split_planes_t2": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],

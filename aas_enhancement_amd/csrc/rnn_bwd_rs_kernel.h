@@ -22,11 +22,15 @@
 #pragma once
 #include "rnn_split_kernel.h"
 
+#ifndef AAS_GRU_BWD_LKS
+#define AAS_GRU_BWD_LKS 2
+#endif
+
 namespace {
 
 // MODE = LSTM_BWD or GRU_BWD; U = units per workgroup (16: 256 threads, 32: 512 threads - half as many slices, so
 // half the exchanged bytes chip-wide); NTW = 16-column result tiles per wave (P <= 4*NTW)
-template <int MODE, int U, int NTW>
+template <int MODE, int U, int NTW, int LKSP = -1>
 __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     using C = Cfg<MODE>;
     constexpr int G = C::G;
@@ -42,8 +46,8 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     __shared__ __attribute__((aligned(16))) unsigned short a_lo[2][16][RS_LDA];
     // the 1000-unit GRU at U = 32 needs 192 VGPRs for its W fragments alone (of 256 at two waves per SIMD): the lo
     // fragments of its last k-step live in LDS instead (64 KB, re-read once per step) so that nothing spills
-    constexpr int LKS = (!LSTM && U == 32 && NTW == 8) ? 1 : 0;
-    __shared__ u32x4 bl_lds[LKS ? NTW : 1][LKS ? THREADS : 1];
+    constexpr int LKS = LKSP >= 0 ? LKSP : ((!LSTM && U == 32 && NTW == 8) ? AAS_GRU_BWD_LKS : 0);
+    __shared__ u32x4 bl_lds[LKS ? LKS * NTW : 1][LKS ? THREADS : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pslice = blockIdx.x, qg = blockIdx.y, d = blockIdx.z;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                 }
                 const u32x4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
                 bh[ks][nt] = __builtin_bit_cast(bf16x8, hv);
-                if (ks >= KSTEPS - LKS) bl_lds[LKS ? nt : 0][LKS ? tid : 0] = lv;
+                if (ks >= KSTEPS - LKS) bl_lds[LKS ? (ks - (KSTEPS - LKS)) * NTW + nt : 0][LKS ? tid : 0] = lv;
                 else bl[ks][nt] = __builtin_bit_cast(bf16x8, lv);
             }
     }
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
 #pragma unroll
                     for (int ks = 0; ks < KSTEPS; ++ks) {
                         bf16x8 blv;
-                        if (ks >= KSTEPS - LKS) blv = __builtin_bit_cast(bf16x8, bl_lds[LKS ? nt : 0][LKS ? tid : 0]);
+                        if (ks >= KSTEPS - LKS) blv = __builtin_bit_cast(bf16x8, bl_lds[LKS ? (ks - (KSTEPS - LKS)) * NTW + nt : 0][LKS ? tid : 0]);
                         else blv = bl[ks][nt];
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks][nt], al[ks], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blv, ah[ks], acc, 0, 0, 0);
@@ -361,7 +365,10 @@ int launch_rs(const RnnP& p, hipStream_t s) {
     dim3 grid(p.P, p.Q, 2), block(16 * U);
     if (p.P <= 8) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 2>), grid, block, 0, s, p);
     else if (p.P <= 16) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 4>), grid, block, 0, s, p);
-    else if (p.P <= 32) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 8>), grid, block, 0, s, p);
+    else if (p.P <= 32) {
+        if (MODE == GRU_BWD && U == 32 && (p.flags & 32768)) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 8, 1>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 8>), grid, block, 0, s, p);
+    }
     else if (U == 16 && p.P <= 64) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, 16, 16>), grid, block, 0, s, p);
     else return -1;
     return 0;

@@ -139,8 +139,27 @@ _SKIP_WGRAD = bool(int(__import__('os').environ.get('AAS_SKIP_WGRAD', '0')))
 _wgrad_streams = {}
 
 
+def _cu_masked_stream(dev, ncus):
+    """A HIP stream whose kernels may only run on the first `ncus` bits of the queue's CU mask (hipExtStreamCreateWithCUMask;
+    the driver deals the mask bits round-robin over the XCDs, so N bits = N/8 CUs of every XCD)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (device_cus() + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(min(ncus, 32 * words)):
+        mask[i // 32] |= 1 << (i % 32)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 def wgrad_stream(dev):
     s = _wgrad_streams.get(dev)
+    if s is None and int(os.environ.get("AAS_WGRAD_CUS", "0")) > 0:
+        s = _wgrad_streams[dev] = _cu_masked_stream(dev, int(os.environ["AAS_WGRAD_CUS"]))
     if s is None:
         # lowest priority: when a persistent recurrent launch and queued weight-gradient blocks compete for CUs, the
         # recurrent grid (which must become fully resident) is dispatched first
@@ -293,6 +312,34 @@ def gemm_planes_multi(M, N, K, items, lda, ldb, ldc):
     arr = lambda k: (ctypes.c_void_p * n)(*[int(it[k]) for it in items])
     with _timed("gemm", "gemm_planes_wgrad", 2.0 * M * N * K * n):
         check(lib().aas_gemm_planes_multi(stream(), M, N, K, n, arr(0), arr(1), arr(2), lda, ldb, ldc), "aas_gemm_planes_multi")
+
+
+_zero_blocks = {}
+
+
+def _zero512(dev):
+    z = _zero_blocks.get(dev)
+    if z is None:
+        z = _zero_blocks[dev] = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    return z
+
+
+def gemm_planes_tn(problems, Ns, Nb, dev, accumulate=True):
+    """Weight-gradient style products straight from ROW-MAJOR planes (include/aas_hip.h: aas_gemm_planes_tn), <= 8 per launch.
+    Each problem is a dict: A, B (device byte addresses of row 0 of the planes), lda, ldb (bytes per plane row), acols, bcols
+    (plane columns), acol0, M, N, K, C0, C1 (device addresses; C1 = 0 when msplit >= M), msplit, ldc, n0, ta, tb, alpha
+    (a device float tensor or None)."""
+    import ctypes
+    n = len(problems)
+    vp = lambda k: (ctypes.c_void_p * n)(*[int(pr[k]) if pr.get(k) else None for pr in problems])
+    ci = lambda k: (ctypes.c_int * n)(*[int(pr[k]) for pr in problems])
+    c64 = lambda k: (ctypes.c_int64 * n)(*[int(pr[k]) for pr in problems])
+    al = (ctypes.c_void_p * n)(*[pr["alpha"].data_ptr() if pr.get("alpha") is not None else None for pr in problems])
+    flops = sum(2.0 * pr["M"] * pr["N"] * pr["K"] for pr in problems)
+    with _timed("gemm", "gemm_planes_wgrad", flops):
+        check(lib().aas_gemm_planes_tn(stream(), n, vp("A"), vp("B"), vp("C0"), vp("C1"), al, ci("M"), ci("N"), ci("K"), ci("msplit"),
+                                       ci("acol0"), ci("n0"), ci("ta"), ci("tb"), c64("lda"), ci("acols"), c64("ldb"), ci("bcols"),
+                                       c64("ldc"), Ns, Nb, ptr(_zero512(dev)), int(accumulate)), "aas_gemm_planes_tn")
 
 
 def gemm_planes(M, N, K, A, B, C, ldc, bias=None, addend=None, ldd=0, accumulate=False, batch=1, sA=0, sB=0, sC=0,

@@ -765,6 +765,12 @@ class Trainer(object):
         root gradients were produced there): called from the main stream, the side chain's backward would wait for everything
         queued on main - i.e. the acoustic backward for the tail of D's forward.  So the root gradients are created on the
         streams of their losses and the call is issued from a stream that has nothing queued."""
+        if os.environ.get("AAS_PAIR_BWD", "1") == "0":
+            # two independent backward calls, each issued from (and confined to) the stream of its chain
+            with torch.cuda.stream(side):
+                loss_side.backward()
+            loss_main.backward()
+            return
         if os.environ.get("AAS_NEUTRAL_BWD", "1") != "1":
             side.wait_stream(main)
             torch.autograd.backward([loss_main, loss_side])
@@ -774,7 +780,8 @@ class Trainer(object):
         g_main = torch.ones_like(loss_main)
         with torch.cuda.stream(side):
             g_side = torch.ones_like(loss_side)
-        with torch.cuda.stream(self._neutral_stream):
+        caller = side if os.environ.get("AAS_BWD_FROM", "neutral") == "side" else self._neutral_stream
+        with torch.cuda.stream(caller):
             torch.autograd.backward([loss_main, loss_side], [g_main, g_side])
 
     def _interleave_ok(self):

@@ -37,7 +37,8 @@ int aas_device_cus(void);
  * Kernel-selection bits (results unchanged): 32 plain first exchange load in the forward kernels, 256 all-gather
  *   BPTT instead of the reduce-scatter kernel, 512 16-unit slices, 8192 poll before streaming in the reduce-scatter
  *   BPTT, 1024 128x128 tiles instead of 256x256 and 2048 128x256 instead of 128x128 in aas_gemm_planes, 4096 plain
- *   3-D grid instead of the XCD-aware tile order in aas_gemm_planes, 16384 the general (any S) CTC kernel even when S <= 64. */
+ *   3-D grid instead of the XCD-aware tile order in aas_gemm_planes, 16384 the general (any S) CTC kernel even when S <= 64,
+ *   32768 the 1000-unit GRU BPTT kernel with one (not two) k-steps of lo weight fragments in LDS (the older, spilling variant). */
 int aas_set_debug_flags(int flags);
 /* Tag (>= 1) of the persistent recurrent launches queued after the call.  Every bounded spin in those kernels gives
  * up after ~0.5 s and stores the tag of its launch in a sticky error word at byte 4096 of the launch's `sync` buffer
@@ -98,6 +99,19 @@ int aas_planes_transpose(aasStream_t stream, const void* src_planes, int64_t src
  * bidirectional recurrent layer (dW_ih, dW_hh per direction; model.py:73-74,94-95 backward) run as one launch. */
 int aas_gemm_planes_multi(aasStream_t stream, int M, int N, int K, int count, const void* const* h_A,
                           const void* const* h_B, float* const* h_C, int64_t lda, int64_t ldb, int64_t ldc);
+/* The weight-gradient products of a recurrent layer (dW = d(gates)^T x, d(gates)^T h_{t-+1}; model.py:73-74,94-95 backward)
+ * straight from ROW-MAJOR planes, no transposed copies:  C_i[m][n] (+)= alpha_i * sum_{r' < K_i} A_i[ra(r')][acol0_i + m] * B_i[rb(r')][n],
+ * with the row map r' -> (t, n) = (r' / Ns, r' % Ns), ra = (t + ta_i)*Nb + n0_i + n, rb = (t + tb_i)*Nb + n0_i + n: the rows of
+ * one utterance class of every time step (a batched discriminator pass = two problems with alpha = -kt / 1, trainer_AAS.py:137-
+ * 151), time shifts for the recurrent weights.  A_i, B_i: interleaved planes (layout of aas_split_planes), lda / ldb BYTES per
+ * row (multiples of 128), acols / bcols valid plane columns; rows m < msplit_i go to C0_i, the rest to C1_i (the two directions'
+ * weights are separate tensors); alpha_i: device scalar or NULL (= 1); all tables are HOST arrays of `count` (<= 8) entries;
+ * zero512: >= 512 zero bytes on the device (source of masked rows / columns). */
+int aas_gemm_planes_tn(aasStream_t stream, int count, const void* const* h_A, const void* const* h_B, float* const* h_C0,
+                       float* const* h_C1, const float* const* h_alpha, const int* h_M, const int* h_N, const int* h_K,
+                       const int* h_msplit, const int* h_acol0, const int* h_n0, const int* h_ta, const int* h_tb,
+                       const int64_t* h_lda, const int* h_acols, const int64_t* h_ldb, const int* h_bcols,
+                       const int64_t* h_ldc, int Ns, int Nb, const void* zero512, int accumulate);
 int aas_split_planes(aasStream_t stream, const float* src, int64_t ld, int64_t rows, int K, int Kp, void* planes,
                      const float* row_scale, int nb);
 int aas_split_planes_t(aasStream_t stream, const float* src, int64_t ld, int T, int nb, int nbp, int C, int64_t Kp,

@@ -308,6 +308,58 @@ def test_gemm_planes_vs_fp64(ops, M, N, K):
     assert rel_err(C, C0.double() + ref) < 2e-5
 
 
+@pytest.mark.parametrize("T,Nb,GH,I,H", [(37, 6, 104, 80, 24), (50, 60, 2000, 500, 500), (9, 3, 40, 72, 8)])
+def test_gemm_planes_tn_vs_fp64(ops, T, Nb, GH, I, H):
+    """aas_gemm_planes_tn: the weight-gradient products from ROW-MAJOR planes (transposing LDS reads): both directions of
+    dW_ih in one problem (result rows split over two tensors), dW_hh per direction with its time shift and a column base in
+    the middle of a 32-column block, utterance classes with their own device-scalar alpha, K not a multiple of 32, poisoned
+    (NaN) rows outside the reduction, accumulate on / off."""
+    dev = "cuda"
+    R_ = T * Nb
+    dg = R(R_, 2 * GH, seed=11).to(dev)
+    x = R(R_, I, seed=12).to(dev)
+    hf, hr = R(R_, H, seed=13).to(dev), R(R_, H, seed=14).to(dev)
+    hf[(T - 1) * Nb:] = float("nan")          # the rows the recurrent kernel never publishes stay poisoned
+    hr[:Nb] = float("nan")
+    pd, px = ops.split_planes(dg, R_, 2 * GH), ops.split_planes(x, R_, I)
+    ph = ops.split_planes(torch.cat([hf, hr], 0), 2 * R_, H)
+    kt = torch.tensor([0.37], device=dev)
+    nkt = -kt
+    Na = Nb // 2 if Nb >= 2 else Nb
+    classes = [(0, Na, nkt), (Na, Nb - Na, None)] if Nb - Na > 0 else [(0, Nb, nkt)]
+    outs = [torch.full((GH, I), 3.0, device=dev), torch.full((GH, H), 3.0, device=dev), torch.full((GH, I), 3.0, device=dev),
+            torch.full((GH, H), 3.0, device=dev)]
+    ref = [o.double().clone() for o in outs]
+    d3, x3 = dg.double().view(T, Nb, 2 * GH), x.double().view(T, Nb, I)
+    hf3, hr3 = hf.double().view(T, Nb, H), hr.double().view(T, Nb, H)
+    for n0, ns, al in classes:
+        a = 1.0 if al is None else float(al)
+        sl = slice(n0, n0 + ns)
+        ref[0] += a * torch.einsum("tng,tni->gi", d3[:, sl, :GH], x3[:, sl])
+        ref[2] += a * torch.einsum("tng,tni->gi", d3[:, sl, GH:], x3[:, sl])
+        ref[1] += a * torch.einsum("tng,tnh->gh", d3[1:, sl, :GH], hf3[:-1, sl])
+        ref[3] += a * torch.einsum("tng,tnh->gh", d3[:-1, sl, GH:], hr3[1:, sl])
+    row = lambda pl: pl.Kp * 4
+    for (n0, ns, al) in classes:
+        common = dict(A=pd.buf.data_ptr(), lda=row(pd), acols=pd.Kp, n0=n0, alpha=al)
+        probs = [dict(common, B=px.buf.data_ptr(), ldb=row(px), bcols=px.Kp, acol0=0, M=2 * GH, N=I, K=T * ns, C0=outs[0].data_ptr(),
+                      C1=outs[2].data_ptr(), msplit=GH, ldc=I, ta=0, tb=0),
+                 dict(common, B=ph.buf.data_ptr(), ldb=row(ph), bcols=ph.Kp, acol0=0, M=GH, N=H, K=(T - 1) * ns, C0=outs[1].data_ptr(),
+                      C1=0, msplit=GH, ldc=H, ta=1, tb=0),
+                 dict(common, B=ph.buf.data_ptr() + R_ * row(ph), ldb=row(ph), bcols=ph.Kp, acol0=GH, M=GH, N=H, K=(T - 1) * ns,
+                      C0=outs[3].data_ptr(), C1=0, msplit=GH, ldc=H, ta=0, tb=1)]
+        ops.gemm_planes_tn(probs, ns, Nb, torch.device(dev), accumulate=True)
+    for o, r in zip(outs, ref):
+        assert torch.isfinite(o).all()
+        assert rel_err(o, r) < 2e-5
+    # overwrite form
+    o2 = torch.full((2 * GH, I), 5.0, device=dev)
+    ops.gemm_planes_tn([dict(A=pd.buf.data_ptr(), lda=row(pd), acols=pd.Kp, n0=0, alpha=None, B=px.buf.data_ptr(), ldb=row(px),
+                             bcols=px.Kp, acol0=0, M=2 * GH, N=I, K=R_, C0=o2.data_ptr(), C1=0, msplit=2 * GH, ldc=I, ta=0, tb=0)],
+                       Nb, Nb, torch.device(dev), accumulate=False)
+    assert rel_err(o2, dg.double().t() @ x.double()) < 2e-5
+
+
 def test_split_planes_transposed(ops):
     """aas_split_planes_t: time-major [T*nb, C] -> planes[c][t*nbp + n] with per-utterance weights and zero pads; used as
     both operands of a weight-gradient product dW = (rs * dg)^T x."""

@@ -53,11 +53,14 @@ def main():
     ap.add_argument("--gflags", default="0")
     ap.add_argument("--skip-rnn", action="store_true")
     ap.add_argument("--cus", type=int, default=0, help="aas_set_rnn_cu_limit for the recurrent launches")
+    ap.add_argument("--only", default="", help="comma list of case indices (0 lstm30, 1 gru30, 2 lstm60)")
     a = ap.parse_args()
     L = _lib.lib()
     L.aas_set_precision(a.precision)
     L.aas_set_rnn_cu_limit(a.cus)
     cases = [("lstm", 200, 30, 500), ("gru", 85, 30, 1000), ("lstm", 200, 60, 500)]
+    if a.only:
+        cases = [cases[int(i)] for i in a.only.split(",")]
     for kind, T, N, H in ([] if a.skip_rnn else cases):
         f, b = rnn_case(kind, T, N, H)
         for fl in [int(v) for v in a.flags.split(",")]:

@@ -17,7 +17,7 @@ def main():
     rows.sort()
     t_begin, t_end = rows[0][0], max(r[1] for r in rows)
     print("kernels: %d, span %.1f ms" % (len(rows), (t_end - t_begin) / 1e6))
-    adam = [r for r in rows if "adam" in r[2]]
+    adam = [r for r in rows if "began_step" in r[2]] or [r for r in rows if "adam" in r[2]]   # one per step when present
     # steady-state window: between the Adam launches of two steps in the middle of the run
     ad = sorted(set(r[0] for r in adam))
     steps = []
