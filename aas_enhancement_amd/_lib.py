@@ -31,6 +31,8 @@ SIGNATURES = {
     "aas_gemm_planes": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                         c_int, c_i64, c_i64, c_i64],
     "aas_gemm_planes_multi": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64],
+    "aas_rnn_last_fwd_h_pitch": [],
+    "aas_set_wgrad_wg_cap": [c_int],
     "aas_gemm_planes_tn": [c_vp, c_int] + [c_vp] * 18 + [c_int, c_int, c_vp, c_int],
     "aas_split_planes": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_int],
     "aas_split_planes_t": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
@@ -92,6 +94,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, c_int)
+        if os.environ.get("AAS_WGRAD_WGS"):               # grid cap of the row-major weight-gradient GEMM (0 = none)
+            L.aas_set_wgrad_wg_cap(int(os.environ["AAS_WGRAD_WGS"]))
         if os.environ.get("AAS_DEBUG_FLAGS"):             # A/B kernel-selection bits of aas_set_debug_flags (include/aas_hip.h)
             L.aas_set_debug_flags(int(os.environ["AAS_DEBUG_FLAGS"]))
         if os.environ.get("AAS_PRECISION") in ("0", "1"):  # 0 = exact fp32 MFMA, 1 = split-bf16 (library default)

@@ -63,6 +63,12 @@ extern "C" int aas_set_rnn_cu_limit(int cus) {
 // stores this value (>= 1) in the sticky error word of its sync buffer, so the host can name the layer.
 static int g_rnn_tag = 1;
 int aas_rnn_launch_tag_value() { return g_rnn_tag; }
+static int g_wgrad_cap = 0;
+int aas_wgrad_wg_cap() { return g_wgrad_cap; }
+extern "C" int aas_set_wgrad_wg_cap(int workgroups) { g_wgrad_cap = workgroups < 0 ? 0 : workgroups; return 0; }
+static int g_fwd_h_pitch = 0;
+void aas_note_fwd_h_planes(int pitch_bytes) { g_fwd_h_pitch = pitch_bytes; }
+extern "C" int aas_rnn_last_fwd_h_pitch(void) { return g_fwd_h_pitch; }
 extern "C" int aas_set_rnn_launch_tag(int tag) {
     if (tag < 1) {
         aas_set_error("aas_set_rnn_launch_tag: tag must be >= 1");

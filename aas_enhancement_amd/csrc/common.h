@@ -14,6 +14,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 void aas_set_error(const char* fmt, ...);
 int aas_debug_flags_value();
 int aas_precision_value();
+int aas_wgrad_wg_cap();                       // 0 = no cap on the grid of aas_gemm_planes_tn
+void aas_note_fwd_h_planes(int pitch_bytes);  // what the last forward recurrent launch left in its exchange buffer (0: nothing usable)
 int aas_rnn_launch_tag_value();  // >= 1: what a timed-out persistent launch leaves in its sticky error word
 int aas_rnn_cus();  // aas_device_cus() capped by aas_set_rnn_cu_limit()
 

@@ -41,7 +41,7 @@ struct PTN {
     int64_t lda[MAXP], ldb[MAXP], ldc[MAXP];   // lda / ldb: BYTES per plane row; ldc: elements
     int Ns, Nb;
     const char* zero;
-    int accumulate, flags, per, tiles;
+    int accumulate, flags, per, tiles, maxwg;
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* a) {
@@ -66,8 +66,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_planes_tn_kernel(PTN p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int L = blockIdx.x, qt = (L & 7) * p.per + (L >> 3);   // XCD x takes a contiguous run of tiles
-    if (qt >= p.tiles) return;
+    // XCD x (workgroups with blockIdx % 8 == x) takes the contiguous run of tiles [x*per, (x+1)*per); with a capped grid a
+    // workgroup walks its XCD's run in strides of gridDim/8
+    for (int slot = blockIdx.x >> 3; slot < p.per; slot += gridDim.x >> 3) {
+    const int qt = (blockIdx.x & 7) * p.per + slot;
+    if (qt >= p.tiles) break;
+    __syncthreads();             // (the previous tile's LDS reads are done before this tile's first writes)
     int pr = 0;
     while (pr + 1 < p.nprob && qt >= p.tile0[pr + 1]) ++pr;
     const int qq = qt - p.tile0[pr];
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_planes_tn_kernel(PTN p) {
             }
         }
     }
+    }   // tiles of this workgroup
 }
 
 }  // namespace
@@ -264,8 +269,11 @@ extern "C" int aas_gemm_planes_tn(aasStream_t stream, int count, const void* con
                   "aas_gemm_planes_tn: could not raise the dynamic LDS limit");
         attr_done = true;
     }
-    if (p.flags & 65536) hipLaunchKernelGGL(gemm_planes_tn_kernel<4>, dim3(8 * p.per), dim3(256), LDS, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gemm_planes_tn_kernel<8>, dim3(8 * p.per), dim3(512), LDS, (hipStream_t)stream, p);
+    int grid = 8 * p.per;
+    const int cap = aas_wgrad_wg_cap();     // > 0: at most this many workgroups (a multiple of 8), each walking several tiles
+    if (cap > 0 && grid > cap) grid = cap < 8 ? 8 : cap / 8 * 8;
+    if (p.flags & 65536) hipLaunchKernelGGL(gemm_planes_tn_kernel<4>, dim3(grid), dim3(256), LDS, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_planes_tn_kernel<8>, dim3(grid), dim3(512), LDS, (hipStream_t)stream, p);
     AAS_LAUNCH_CHECK("aas_gemm_planes_tn");
     return 0;
 }

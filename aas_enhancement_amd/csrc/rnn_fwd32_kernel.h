@@ -281,6 +281,8 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
     p.rpg = rpg;
     const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
     AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes, s));
+    // one launch covers the batch: afterwards the buffer holds h_t of every step but each direction's last as operand planes
+    aas_note_fwd_h_planes(p.N <= qmax * rpg ? (Hp / 32) * 128 : 0);
     for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {
         p.n0 = n0;
         const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
@@ -304,6 +306,7 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
 
 template <int MODE>
 int run_fwd_any(const char* name, RnnP p, hipStream_t s) {
+    aas_note_fwd_h_planes(0);
     if (p.xchg && aas_precision_value() != 0) {
         const int rc = run_fwd32<MODE>(name, p, s);
         if (rc >= 0) return rc;

@@ -450,6 +450,7 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
     pick_groups(p.P, p.N, cus, mt, rpg);
     p.rpg = rpg;
     const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
+    if (FWD) aas_note_fwd_h_planes(p.N <= qmax * rpg ? ((kxp + 31) / 32) * 128 : 0);   // (chunked launches re-poison the buffer)
     for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {
         p.n0 = n0;
         const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
@@ -470,6 +471,7 @@ int run_any(const char* name, RnnP p, hipStream_t s) {
         const int rc = run_split<MODE>(name, p, s);
         if (rc >= 0) return rc;
     }
+    aas_note_fwd_h_planes(0);
     return run<MODE>(name, p, s);
 }
 

@@ -123,6 +123,11 @@ def set_rnn_cu_limit(cus):
     check(lib().aas_set_rnn_cu_limit(int(cus)), "aas_set_rnn_cu_limit")
 
 
+def set_wgrad_cap(workgroups):
+    """Grid cap of the row-major weight-gradient GEMMs queued from now on (0 = none); include/aas_hip.h: aas_set_wgrad_wg_cap."""
+    lib().aas_set_wgrad_wg_cap(int(workgroups))
+
+
 def device_cus():
     return int(lib().aas_device_cus())
 
@@ -154,6 +159,18 @@ def _cu_masked_stream(dev, ncus):
     if rc != 0:
         raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
     return torch.cuda.ExternalStream(h.value, device=dev)
+
+
+def chain_stream(dev=None):
+    """A stream for a chain of persistent recurrent launches (the critical path of a step): highest priority, so that its
+    workgroups are dispatched before queued weight-gradient blocks whenever CUs free up (AAS_CHAIN_PRIO=0: default priority)."""
+    prio = 0
+    if os.environ.get("AAS_CHAIN_PRIO", "1") == "1":
+        try:
+            prio = min(torch.cuda.Stream.priority_range())
+        except Exception:  # noqa: BLE001
+            prio = 0
+    return torch.cuda.Stream(device=dev, priority=prio)
 
 
 def wgrad_stream(dev):
@@ -617,8 +634,12 @@ def _wih_t_planes(w_ih, w_ih_r, GH, I):
     return wt
 
 
-def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0):
-    """x [T,N,I] -> (pre, hout[2,T,N,H], gact, cst)."""
+TN_WGRAD = [os.environ.get("AAS_TN_WGRAD", "1") == "1"]   # weight-gradient products from row-major planes (aas_gemm_planes_tn)
+
+
+def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None):
+    """x [T,N,I] -> (hout[2,T,N,H], gact, cst).  keep: a dict that receives what the layer's weight-gradient products can
+    reuse: 'xp' = the input's operand planes, 'hx' / 'hpitch' = the forward launch's exchange buffer (h_t as planes)."""
     T, N, I = x.shape
     G = 4 if kind == "lstm" else 3
     H = w_hh.shape[1]
@@ -633,6 +654,8 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0):
         xa = getattr(x, "_aas_planes", None)       # the producing layer's direction sum may have written them already
         if xa is None or xa.rows != T * N or xa.K != I:
             xa = split_planes(x2, T * N, I)
+        if keep is not None:
+            keep["xp"] = xa
         wb = _wih_planes(w_ih, w_ih_r, GH, I)
         gemm_planes(T * N, 2 * GH, xa.Kp, xa, wb, pre, 2 * GH)
     elif dw > 0 and dw % 4 == 0:
@@ -645,7 +668,10 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0):
     hout = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
     gact = torch.empty((2, T, N, 4 * H), device=dev, dtype=torch.float32)
     sync = _sync_buf(dev)
-    xchg = _xchg_buf(dev, T, N, H, G)
+    if keep is not None and _precision[0] == 1:   # a buffer of the layer's own: it is read again by the backward pass
+        xchg = torch.empty(int(lib().aas_rnn_xchg_bytes(T, N, H, G)), dtype=torch.uint8, device=dev)
+    else:
+        xchg = _xchg_buf(dev, T, N, H, G)
     rflops = 2.0 * 2 * T * N * H * G * H  # both directions, T steps of [N,H]x[H,G*H]
     lib().aas_set_rnn_launch_tag(2 * lid if lid else 1)
     if kind == "lstm":
@@ -658,11 +684,15 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0):
         with _timed("rnn", "gru_fwd[N=%d,H=%d]" % (N, H), rflops, T):
             check(lib().aas_gru_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync),
                                     ptr(xchg)), "aas_gru_fwd")
+    if keep is not None and _precision[0] == 1:
+        pitch = int(lib().aas_rnn_last_fwd_h_pitch())
+        if pitch > 0:
+            keep["hx"], keep["hpitch"] = xchg, pitch
     return hout, gact, cst
 
 
 def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residual, need_dx=True, need_dw=True, rs=None,
-               direct=None, lid=0):
+               direct=None, lid=0, keep=None):
     T, N, I = x.shape
     G = 4 if kind == "lstm" else 3
     H = w_hh.shape[1]
@@ -772,10 +802,43 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
             if t_ is not None:
                 t_.record_stream(torch.cuda.current_stream())
 
+    def wgrads_tn(out):
+        """The same products straight from ROW-MAJOR planes: d(gates) as the BPTT kernel wrote it, the input planes of the
+        forward projection, h_t as the forward recurrent launch published it - no transposed copies (aas_gemm_planes_tn).
+        Per-utterance weights: one problem set per utterance class, its weight as the product's alpha.  False when the
+        layer does not have every operand in that form (the transposed-plane path runs instead)."""
+        if not (TN_WGRAD[0] and keep and dgp is not None and "xp" in keep and "hx" in keep):
+            return False
+        classes = [(0, N, None)] if rs is None else getattr(rs, "_aas_classes", None)
+        if not classes:
+            return False
+        xp, hx, hpitch = keep["xp"], keep["hx"], keep["hpitch"]
+        if xp.rows != R or xp.K != I or hpitch < 4 * H or not all(o.is_contiguous() for o in out):
+            return False
+        a_x, a_h = dgp.data_ptr(), dghp.data_ptr()
+        lda = 4 * Kpg
+        # one launch per class: the classes accumulate into the SAME results (read-modify-write epilogue), launches are ordered
+        for n0, ns, alpha in classes:
+            base = dict(lda=lda, acols=Kpg, n0=n0, alpha=alpha)
+            probs = [dict(base, A=a_x, B=xp.buf.data_ptr(), ldb=4 * xp.Kp, bcols=xp.Kp, acol0=0, M=2 * GH, N=I, K=T * ns,
+                          C0=out[0].data_ptr(), C1=out[2].data_ptr(), msplit=GH, ldc=I, ta=0, tb=0),
+                     # forward direction: sum_{t>=1} dg[t]^T h_f[t-1]; reverse: sum_{t<=T-2} dg[t]^T h_r[t+1]
+                     dict(base, A=a_h, B=hx.data_ptr(), ldb=hpitch, bcols=hpitch // 4, acol0=0, M=GH, N=H, K=(T - 1) * ns,
+                          C0=out[1].data_ptr(), C1=0, msplit=GH, ldc=H, ta=1, tb=0),
+                     dict(base, A=a_h, B=hx.data_ptr() + R * hpitch, ldb=hpitch, bcols=hpitch // 4, acol0=GH, M=GH, N=H,
+                          K=(T - 1) * ns, C0=out[3].data_ptr(), C1=0, msplit=GH, ldc=H, ta=0, tb=1)]
+            gemm_planes_tn(probs, ns, N, dev, accumulate=True)
+        cur = torch.cuda.current_stream()
+        for t_ in (dgp, dghp, xp.buf, hx):
+            t_.record_stream(cur)
+        return True
+
     def wgrads(out, acc):
         if _SKIP_WGRAD:  # timing experiment only (AAS_SKIP_WGRAD=1): how much of the step the weight-gradient products hold
             return
         if use_planes and acc and T > 1:
+            if wgrads_tn(out):
+                return
             return wgrads_planes(out)
         if rs is not None:  # per-utterance weights on the parameter gradients only (dx used the unscaled d(gates))
             scale_rows(dgx, rs, N, out=dgx)
@@ -809,7 +872,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
                 wgrads(direct, True)
                 if hook is not None:
                     hook(direct)
-        for t_ in (dgx, dgh, dgp, dghp, x, hout):
+        for t_ in (dgx, dgh, dgp, dghp, x, hout) + ((keep["xp"].buf if "xp" in keep else None, keep.get("hx")) if keep else ()):
             if t_ is not None:
                 t_.record_stream(side)
         if DEFER_WGRAD[0]:
@@ -834,7 +897,10 @@ class _BiRNNLayer(torch.autograd.Function):
         ctx.params = (w_ih, w_hh, w_ih_r, w_hh_r)  # the nn.Parameters themselves (for the direct-accumulate path)
         x = _c(x)
         w_ih, w_hh, w_ih_r, w_hh_r = _c(w_ih), _c(w_hh), _c(w_ih_r), _c(w_hh_r)
-        hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid)
+        trainable = any(ctx.needs_input_grad[1:5])    # (grad mode is off inside forward(): ask the context)
+        ctx.keep = {} if (TN_WGRAD[0] and trainable and PLANES_BWD[0] and PLANES_EMIT[0]
+                          and not torch.cuda.is_current_stream_capturing()) else None
+        hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid, keep=ctx.keep)
         T_, N_, H_ = hout.shape[1], hout.shape[2], hout.shape[3]
         if _precision[0] == 1 and PLANES_PRE[0] and T_ * N_ >= 1024 and H_ >= 64 and H_ % 4 == 0:
             y, yp = add3_planes(hout[0], hout[1], x if residual else None, H_)
@@ -855,7 +921,8 @@ class _BiRNNLayer(torch.autograd.Function):
                 direct = gr
         dx, a, b, c, d = _birnn_bwd(ctx.kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, ctx.residual,
                                     need_dx=ctx.needs_input_grad[0], need_dw=any(ctx.needs_input_grad[1:5]), rs=ctx.rs,
-                                    direct=direct, lid=ctx.lid)
+                                    direct=direct, lid=ctx.lid, keep=ctx.keep)
+        ctx.keep = None
         return dx, a, b, c, d, None, None, None, None
 
 

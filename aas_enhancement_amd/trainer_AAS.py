@@ -247,6 +247,7 @@ class Trainer(object):
                 rs = torch.empty(Nn + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
                 rs[:Nn] = -float(self.kt)
                 rs[Nn:] = 1.0
+                rs._aas_classes = [(0, Nn, rs[0:1]), (Nn, cl_inputs.size(0), None)]
                 l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, N_glob, ctc_meta, targets, sizes,
                                                                                 target_sizes, mask=mask, cl_mask=cl_mask)
                 acoustic = (prob, l_CTC, leaf_a)
@@ -258,6 +259,7 @@ class Trainer(object):
                 rs = torch.empty(Nn + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
                 rs[:Nn] = -float(self.kt)
                 rs[Nn:] = 1.0
+                rs._aas_classes = [(0, Nn, rs[0:1]), (Nn, cl_inputs.size(0), None)]
                 ae = self.D(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
                 l_adv_ny_G, _ = self.diffLoss(ae[:Nn], leaf, mask)
                 l_adv_cl, _ = self.diffLoss(ae[Nn:], cl_inputs, cl_mask)
@@ -362,6 +364,10 @@ class Trainer(object):
             scales = (c.w_adversarial / nv_ny, c.w_adversarial / nv_cl, c.w_acoustic / N)
             n_glob = float(N)
         try:
+            # two chains of half-chip persistent launches run side by side: the weight-gradient GEMMs never take more than the
+            # other half of the CUs, so a recurrent launch always finds its CUs (AAS_WGRAD_WGS overrides)
+            if not os.environ.get("AAS_WGRAD_WGS"):
+                ops.set_wgrad_cap(ops.device_cus() // 2 if self._overlap_asr() else 0)
             if self._lanes_ok(tuple(cl_inputs.shape) == tuple(inputs.shape)):
                 enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC = self._two_lane_core(inputs, cl_inputs, scales, ctc_meta, asr_steps)
             else:
@@ -373,6 +379,8 @@ class Trainer(object):
                 self._reducer.wait()
         finally:
             ops.WGRAD_HOOK[0] = None
+            if not os.environ.get("AAS_WGRAD_WGS"):
+                ops.set_wgrad_cap(0)
         optimizer_g.step_dev()
         if not getattr(self, "_early_adam", False):
             optimizer_d.step_dev()
@@ -419,6 +427,8 @@ class Trainer(object):
         rs = torch.empty(N + cl_inputs.size(0), device=dev, dtype=torch.float32)
         rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
         rs[N:] = 1.0
+        # the two utterance classes of the batched pass and their weights (device scalars), for the row-major weight-gradient GEMM
+        rs._aas_classes = [(0, N, rs[0:1]), (N, cl_inputs.size(0), None)]
         if overlap:  # two chains of persistent launches side by side, half the chip each
             ops.set_rnn_cu_limit(ops.device_cus() // 2)
         if self._interleave_ok():
@@ -490,7 +500,7 @@ class Trainer(object):
         N, dev = inputs.size(0), inputs.device
         main = torch.cuda.current_stream()
         if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream()
+            self._side_stream = ops.chain_stream()
         side = self._side = self._side_stream
         side.wait_stream(main)
         ops.set_rnn_cu_limit(int(os.environ.get("AAS_LANE_CUS", "0")) or ops.device_cus() // 2)
@@ -498,6 +508,7 @@ class Trainer(object):
             self._reducer.expect(self._flat["D"], 2)      # every D layer is back-propagated twice: reduce after the second
         self._wait_kt()
         rs = (-self._kt_dev).to(torch.float32).expand(N).contiguous()
+        rs._aas_classes = [(0, N, rs[0:1])]
 
         def alternate(gen_main, gen_side):
             a = b = None
@@ -582,7 +593,20 @@ class Trainer(object):
         if not getattr(self, "_kt_dev_live", False):
             self._kt_dev.fill_(float(self.kt))   # another path advanced the host copy since
         self._kt_dev_live = True
-        enhanced, prob = self._device_core(inputs, cl_inputs, nv_ny, nv_cl, meta, it=iter)
+        if os.environ.get("AAS_MAIN_PRIO", "0") == "1":
+            # the whole step on a highest-priority stream of the trainer's own (the caller's stream has default priority, the
+            # same as the weight-gradient stream): joined with the caller's stream at both ends
+            if getattr(self, "_main_stream", None) is None:
+                self._main_stream = ops.chain_stream()
+            caller = torch.cuda.current_stream()
+            self._main_stream.wait_stream(caller)
+            with torch.cuda.stream(self._main_stream):
+                enhanced, prob = self._device_core(inputs, cl_inputs, nv_ny, nv_cl, meta, it=iter)
+            caller.wait_stream(self._main_stream)
+            for t_ in (enhanced, prob, inputs, cl_inputs):
+                t_.record_stream(self._main_stream)
+        else:
+            enhanced, prob = self._device_core(inputs, cl_inputs, nv_ny, nv_cl, meta, it=iter)
         return dict(enhanced=enhanced, prob=prob, scalars=self._g_out)
 
     def _upload_small(self, host, dev):
@@ -727,7 +751,7 @@ class Trainer(object):
         c = self.config
         main = torch.cuda.current_stream()
         if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream()
+            self._side_stream = ops.chain_stream()
         side = self._side = self._side_stream
         side.wait_stream(main)
         Nn = leaf.size(0)
@@ -808,7 +832,7 @@ class Trainer(object):
         # (each launch sized for the whole chip) the overlap measured nothing.  AAS_OVERLAP_ASR=0: one chain on the main stream.
         if self._overlap_asr():
             if getattr(self, "_side_stream", None) is None:
-                self._side_stream = torch.cuda.Stream()
+                self._side_stream = ops.chain_stream()
             self._side = self._side_stream
         else:
             self._side = torch.cuda.current_stream()

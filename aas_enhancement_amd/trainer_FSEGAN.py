@@ -92,6 +92,7 @@ class Trainer(object):
         rs = torch.empty(2 * N, device=leaf.device, dtype=torch.float32)
         rs[:N] = -float(self.kt)
         rs[N:] = 1.0
+        rs._aas_classes = [(0, N, rs[0:1]), (N, N, None)]   # the two utterance classes and their weights (ops.gemm_planes_tn)
         paired = torch.cat([torch.cat([leaf, mixture], 1), torch.cat([cleans, mixture], 1)], 0)   # forward_paired x 2 (model.py:233-238)
         ae = self.D(paired, wgrad_row_scale=rs)
         l_adv_ny_G, _ = self.diffLoss(ae[:N], leaf, mask)

@@ -44,6 +44,16 @@ int aas_set_debug_flags(int flags);
  * up after ~0.5 s and stores the tag of its launch in a sticky error word at byte 4096 of the launch's `sync` buffer
  * (never cleared by the library): the host reads it at its next synchronisation point and names the layer. */
 int aas_set_rnn_launch_tag(int tag);
+/* > 0 when the LAST aas_lstm_fwd / aas_gru_fwd call left h_t of every time step but each direction's last one in its
+ * exchange buffer as operand planes (rows [2][T][N], this many bytes per row, interleaved hi | lo per 32 units, pad units
+ * zero; the unpublished rows stay poisoned = NaN): the B operand of that layer's recurrent weight-gradient product
+ * (aas_gemm_planes_tn).  0: fp32 kernels ran, or the batch was processed in several launches. */
+int aas_rnn_last_fwd_h_pitch(void);
+/* Cap on the grid of the aas_gemm_planes_tn launches queued after the call (0 = none, the default: one workgroup per tile):
+ * with a cap each workgroup walks several tiles, so the weight-gradient products never hold more than `workgroups` CUs while
+ * a persistent recurrent launch waits to become resident.  The AAS step sets half of the CUs while its two chains of half-chip
+ * launches run (18.9 -> 18.5 ms / step at config 2); steps with a single chain leave it off (a cap only slows them down). */
+int aas_set_wgrad_wg_cap(int workgroups);
 /* Matrix-product operand precision: 0 = exact fp32-input MFMA; 1 (default) = split-bf16: each fp32 operand is
  * carried as bf16 hi + bf16 lo and the product as hi*hi + lo*hi + hi*lo with fp32 accumulation (~1e-5 relative,
  * fp32-class; 3 bf16 MFMAs instead of 16 fp32-MFMA issue slots). */
