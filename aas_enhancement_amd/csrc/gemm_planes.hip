@@ -473,6 +473,9 @@ extern "C" int aas_gemm_planes(aasStream_t stream, int M, int N, int K, const vo
     if (wide) { grid = dim3(cdiv(N, 256), cdiv(M, 128), batch); rc = launch_planes<128, 256, 2, 2, true>(p, grid, s); }
     else if (big) rc = launch_planes<256, 256, 4, 2, true>(p, grid, s);
     else if (p.splitk > 1) rc = launch_planes<128, 128, 2, 2, false>(p, grid, s);
+    // fewer than two tiles per CU: eight waves per workgroup (two per SIMD from ONE workgroup, wave tile 32 x 64) - with a
+    // single wave per SIMD nothing covers that wave's LDS and barrier waits (debug bit 131072: the four-wave form)
+    else if (blocks < 512 && !(p.flags & 131072)) rc = launch_planes<128, 128, 4, 2, true>(p, grid, s);
     else rc = launch_planes<128, 128, 2, 2, true>(p, grid, s);
     AAS_CHECK(rc == 0, "aas_gemm_planes: could not raise the dynamic LDS limit");
     AAS_LAUNCH_CHECK("aas_gemm_planes");

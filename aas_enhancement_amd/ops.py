@@ -123,8 +123,13 @@ def set_rnn_cu_limit(cus):
     check(lib().aas_set_rnn_cu_limit(int(cus)), "aas_set_rnn_cu_limit")
 
 
+_wgrad_cap = [0]
+UNCAPPED_LIDS = set()    # layer ids whose weight-gradient GEMMs ignore the cap (a step's LAST layer: no recurrent launch follows it)
+
+
 def set_wgrad_cap(workgroups):
     """Grid cap of the row-major weight-gradient GEMMs queued from now on (0 = none); include/aas_hip.h: aas_set_wgrad_wg_cap."""
+    _wgrad_cap[0] = int(workgroups)
     lib().aas_set_wgrad_wg_cap(int(workgroups))
 
 
@@ -581,6 +586,7 @@ def _wih_planes(w_ih, w_ih_r, GH, I):
     ok, sig = _plane_sig(w_ih, w_ih_r, GH, I, "N")
     ent = getattr(w_ih, "_aas_planes", None) if ok else None
     if ent is not None and ent[0] == sig:
+        _planes_ready(w_ih)
         return ent[1]
     Kp = _kp(I)
     buf = torch.empty((2 * GH, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
@@ -595,11 +601,33 @@ def _wih_planes(w_ih, w_ih_r, GH, I):
     return wb
 
 
+_refresh_streams = {}
+
+
+def refresh_stream(dev):
+    """The ONE utility stream per device (weight-plane refresh, the trainer's scalar reductions, the neutral caller of paired
+    backward passes).  Streams are multiplexed onto a handful of hardware queues: a fifth busy stream shared a queue with one
+    of the step's chains and serialised the step (18.0 -> 22.0 ms), so everything that is off the critical path shares this one."""
+    dev = torch.device("cuda", dev) if isinstance(dev, int) else dev
+    s = _refresh_streams.get(dev)
+    if s is None:
+        s = _refresh_streams[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def _planes_ready(w_ih):
+    """A cached plane set may still be in flight on the refresh stream: its consumer waits for the layer's own event."""
+    ev = getattr(w_ih, "_aas_planes_ready", None)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+
+
 def refresh_weight_planes(module):
     """Re-split the input weights of every recurrent layer of `module` into their operand planes (forward and transposed)
-    on the weight-gradient stream: call right after the optimiser step; the next forward joins that stream (sync_wgrad)."""
+    on a stream of their own, right after the optimiser step; every layer gets an event that its next use waits for, so the
+    next step starts as soon as ITS first layer's planes are there (not after all ~24 small launches of the three networks)."""
     dev = next(module.parameters()).device
-    main, side = torch.cuda.current_stream(), wgrad_stream(dev)
+    main, side = torch.cuda.current_stream(), refresh_stream(dev)
     ev = torch.cuda.Event()
     ev.record(main)
     with torch.cuda.stream(side):
@@ -610,8 +638,15 @@ def refresh_weight_planes(module):
             w, wr = m.weight_ih_l0, m.weight_ih_l0_reverse
             GH, I = w.shape
             if _precision[0] == 1 and PLANES_PRE[0] and I >= 64:
+                w._aas_planes_ready = None        # (the calls below must not wait for the previous refresh on this stream)
                 for t_ in (_wih_planes(w, wr, GH, I).buf,) + ((_wih_t_planes(w, wr, GH, I).buf,) if (PLANES_BWD[0] and w.requires_grad) else ()):
                     t_.record_stream(main)
+                done = torch.cuda.Event()
+                done.record(side)
+                try:
+                    w._aas_planes_ready = done
+                except Exception:  # noqa: BLE001
+                    side.synchronize()
 
 
 def _wih_t_planes(w_ih, w_ih_r, GH, I):
@@ -620,6 +655,7 @@ def _wih_t_planes(w_ih, w_ih_r, GH, I):
     frozen = ok
     ent = getattr(w_ih, "_aas_planes_t", None) if ok else None
     if ent is not None and ent[0] == sig:
+        _planes_ready(w_ih)
         return ent[1]
     Kp = _kp(2 * GH)
     buf = torch.empty((I, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
@@ -827,7 +863,12 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
                           C0=out[1].data_ptr(), C1=0, msplit=GH, ldc=H, ta=1, tb=0),
                      dict(base, A=a_h, B=hx.data_ptr() + R * hpitch, ldb=hpitch, bcols=hpitch // 4, acol0=GH, M=GH, N=H,
                           K=(T - 1) * ns, C0=out[3].data_ptr(), C1=0, msplit=GH, ldc=H, ta=0, tb=1)]
+            uncapped = _wgrad_cap[0] > 0 and lid in UNCAPPED_LIDS
+            if uncapped:
+                lib().aas_set_wgrad_wg_cap(0)
             gemm_planes_tn(probs, ns, N, dev, accumulate=True)
+            if uncapped:
+                lib().aas_set_wgrad_wg_cap(_wgrad_cap[0])
         cur = torch.cuda.current_stream()
         for t_ in (dgp, dghp, xp.buf, hx):
             t_.record_stream(cur)

@@ -355,7 +355,7 @@ class Trainer(object):
             # global N, nElement(noisy), nElement(clean): all-reduced asynchronously and kept on the device; the loss scales are
             # only formed when the first loss needs them (after the forward passes), so the collective's latency hides behind E
             if getattr(self, "_aux_stream", None) is None:
-                self._aux_stream = torch.cuda.Stream()
+                self._aux_stream = ops.refresh_stream(dev)
             scales = _LazyScales(dp, cnt, c, self._aux_stream)
             n_glob = scales
             self._reducer.begin()
@@ -368,6 +368,10 @@ class Trainer(object):
             # other half of the CUs, so a recurrent launch always finds its CUs (AAS_WGRAD_WGS overrides)
             if not os.environ.get("AAS_WGRAD_WGS"):
                 ops.set_wgrad_cap(ops.device_cus() // 2 if self._overlap_asr() else 0)
+                if getattr(self, "_g_first_lid", None) is None:   # E's first layer is back-propagated last: nothing left to protect
+                    self._g_first_lid = next((m._aas_layer_id for m in self.G.modules() if getattr(m, "_aas_layer_id", None) is not None), 0)
+                ops.UNCAPPED_LIDS.clear()
+                ops.UNCAPPED_LIDS.add(self._g_first_lid)
             if self._lanes_ok(tuple(cl_inputs.shape) == tuple(inputs.shape)):
                 enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC = self._two_lane_core(inputs, cl_inputs, scales, ctc_meta, asr_steps)
             else:
@@ -800,7 +804,7 @@ class Trainer(object):
             torch.autograd.backward([loss_main, loss_side])
             return
         if getattr(self, "_neutral_stream", None) is None:
-            self._neutral_stream = torch.cuda.Stream()
+            self._neutral_stream = ops.refresh_stream(torch.cuda.current_device())   # (one utility stream: the device has few hardware queues)
         g_main = torch.ones_like(loss_main)
         with torch.cuda.stream(side):
             g_side = torch.ones_like(loss_side)
