@@ -597,6 +597,7 @@ class Trainer(object):
         if not getattr(self, "_kt_dev_live", False):
             self._kt_dev.fill_(float(self.kt))   # another path advanced the host copy since
         self._kt_dev_live = True
+        self._host_ahead = True
         if os.environ.get("AAS_MAIN_PRIO", "0") == "1":
             # the whole step on a highest-priority stream of the trainer's own (the caller's stream has default priority, the
             # same as the weight-gradient stream): joined with the caller's stream at both ends
@@ -611,6 +612,7 @@ class Trainer(object):
                 t_.record_stream(self._main_stream)
         else:
             enhanced, prob = self._device_core(inputs, cl_inputs, nv_ny, nv_cl, meta, it=iter)
+        self._host_ahead = False
         return dict(enhanced=enhanced, prob=prob, scalars=self._g_out)
 
     def _upload_small(self, host, dev):
@@ -793,8 +795,13 @@ class Trainer(object):
         root gradients were produced there): called from the main stream, the side chain's backward would wait for everything
         queued on main - i.e. the acoustic backward for the tail of D's forward.  So the root gradients are created on the
         streams of their losses and the call is issued from a stream that has nothing queued."""
-        if os.environ.get("AAS_PAIR_BWD", "1") == "0":
-            # two independent backward calls, each issued from (and confined to) the stream of its chain
+        mode = os.environ.get("AAS_PAIR_BWD", "auto")
+        if mode == "0" or (mode == "auto" and (getattr(self, "_host_ahead", False) or self.dp.active)):
+            # Two independent backward calls, each issued from (and confined to) the stream of its chain: nothing ties the
+            # chains together.  Right whenever the host queues ahead of the device (train_step_async), where the order in
+            # which the host queues the two chains does not matter; and data parallel, where the utility stream that the
+            # paired call is issued from also carries the collectives (the acoustic backward then waited for the end of D's
+            # forward: 19.3 vs 18.4 ms / step with one-rank RCCL).
             with torch.cuda.stream(side):
                 loss_side.backward()
             loss_main.backward()

@@ -23,6 +23,12 @@ def main():
     from aas_enhancement_amd import ops
     from aas_enhancement_amd.trainer_AAS import Trainer
     dev = torch.device("cuda", 0)
+    if os.environ.get("AAS_DP_FORCE") == "1":     # one-rank RCCL: the data-parallel code path on one GPU
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
     cfg = types.SimpleNamespace(lr=1e-5, beta1=0.5, beta2=0.999, optimizer="adam", batch_size=30, expnum=0, lambda_k=0.001, gamma=0.5,
                                 gpu=0, load_path="", mode="train", write_log=False, w_adversarial=1.0, w_acoustic=1.0,
                                 allow_ASR_update_iter=10 ** 9, schedule="fused")
