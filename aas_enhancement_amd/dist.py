@@ -177,6 +177,15 @@ class BucketReducer(object):
     def __init__(self, dp, flats):
         self.dp, self.flats = dp, list(flats)
         self.handles, self.done = [], {}
+        self.deferred = set()
+
+    def defer_layer(self, grads):
+        """The layer with these gradients is the LAST one of a step's backward pass: its bucket would be followed at once by
+        flush() of its neighbours in the buffer, so it is left to flush() - one collective for the contiguous range instead
+        of two or three small ones at the exposed end of the step."""
+        f, lo, hi, n = self._locate(grads)
+        if f is not None:
+            self.deferred.add((id(f), lo))
 
     def begin(self):
         self.handles = []
@@ -202,6 +211,8 @@ class BucketReducer(object):
         if f is None or hi - lo != n or n < self.MIN_ELEMS:
             return
         k = (id(f), lo)
+        if k in self.deferred:
+            return
         self.seen[k] = self.seen.get(k, 0) + 1
         if self.seen[k] < self.expected.get(id(f), 1):
             return

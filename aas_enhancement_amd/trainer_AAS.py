@@ -359,6 +359,11 @@ class Trainer(object):
             scales = _LazyScales(dp, cnt, c, self._aux_stream)
             n_glob = scales
             self._reducer.begin()
+            if not self._reducer.deferred:     # E's first recurrent layer is back-propagated last
+                first = next((m for m in self.G.modules() if getattr(m, "_aas_layer_id", None) is not None), None)
+                if first is not None:
+                    self._reducer.defer_layer([p_.grad for p_ in (first.weight_ih_l0, first.weight_hh_l0, first.weight_ih_l0_reverse,
+                                                                  first.weight_hh_l0_reverse) if p_.grad is not None])
             ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
         else:
             scales = (c.w_adversarial / nv_ny, c.w_adversarial / nv_cl, c.w_acoustic / N)
