@@ -371,13 +371,15 @@ class Trainer(object):
         try:
             # two chains of half-chip persistent launches run side by side: the weight-gradient GEMMs never take more than the
             # other half of the CUs, so a recurrent launch always finds its CUs (AAS_WGRAD_WGS overrides)
+            lanes = self._lanes_ok(tuple(cl_inputs.shape) == tuple(inputs.shape))
             if not os.environ.get("AAS_WGRAD_WGS"):
-                ops.set_wgrad_cap(ops.device_cus() // 2 if self._overlap_asr() else 0)
+                # (batched-D schedule only: with the two-lane schedule's three chains a cap costs more than it saves, 19.5 vs 18.6 ms)
+                ops.set_wgrad_cap(ops.device_cus() // 2 if (self._overlap_asr() and not lanes) else 0)
                 if getattr(self, "_g_first_lid", None) is None:   # E's first layer is back-propagated last: nothing left to protect
                     self._g_first_lid = next((m._aas_layer_id for m in self.G.modules() if getattr(m, "_aas_layer_id", None) is not None), 0)
                 ops.UNCAPPED_LIDS.clear()
                 ops.UNCAPPED_LIDS.add(self._g_first_lid)
-            if self._lanes_ok(tuple(cl_inputs.shape) == tuple(inputs.shape)):
+            if lanes:
                 enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC = self._two_lane_core(inputs, cl_inputs, scales, ctc_meta, asr_steps)
             else:
                 enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC = self._batched_D_core(inputs, cl_inputs, scales, ctc_meta, asr_steps)
