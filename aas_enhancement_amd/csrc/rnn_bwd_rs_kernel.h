@@ -50,7 +50,12 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     __shared__ u32x4 bl_lds[LKS ? LKS * NTW : 1][LKS ? THREADS : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pslice = blockIdx.x, qg = blockIdx.y, d = blockIdx.z;
+    // XCD-aware launch (p.xcd != 0; 8 (direction, row group) sets): 1-D grid, workgroup b -> set b % 8, slice b / 8.  Workgroups
+    // are dealt round-robin over the 8 XCDs, so the P workgroups of a set - the only ones that exchange data - share an XCD
+    // and its L2.
+    const int pslice = p.xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int qg = p.xcd ? (int)((blockIdx.x & 7) >> 1) : (int)blockIdx.y;
+    const int d = p.xcd ? (int)(blockIdx.x & 1) : (int)blockIdx.z;
     const int T = p.T, N = p.N, H = p.H, GH = G * H, P = p.P;
     const int u0 = pslice * U;
     const int q0 = p.n0 + qg * p.rpg;
@@ -88,6 +93,13 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                 if (ks >= KSTEPS - LKS) bl_lds[LKS ? (ks - (KSTEPS - LKS)) * NTW + nt : 0][LKS ? tid : 0] = lv;
                 else bl[ks][nt] = __builtin_bit_cast(bf16x8, lv);
             }
+    }
+    // plain (L2-resident) publish stores when the whole set shares an XCD (rnn_split_kernel.h: xcd_set_colocated)
+    __shared__ unsigned xcd_flag;
+    bool plain = false;
+    if (p.xcd) {
+        unsigned* tab = p.xchg + (int64_t)4 * p.N * p.P * p.P * U;   // behind the ring, poisoned by the same memset
+        plain = xcd_set_colocated(tab, (int)(blockIdx.x & 7), pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag) && !(p.flags & 524288);
     }
     // zero both A tiles once: pad rows / pad gate columns stay zero for the whole launch
     for (int i = tid; i < 2 * 16 * RS_LDA; i += THREADS) {
@@ -340,7 +352,8 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                     o.z = (__float_as_uint(acc[2]) & ~3u) | tag;
                     o.w = (__float_as_uint(acc[3]) & ~3u) | tag;
                     const unsigned boff = (unsigned)((((rblk + c) * P + pslice) * U + half * 16 + u4) * 4);
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 16);  // sc1: agent-scope write-through
+                    if (plain) __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 0);       // the line stays in this XCD's L2
+                    else __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 16);            // sc1: agent-scope write-through
                 }
             }
         }
@@ -363,6 +376,7 @@ inline size_t rs_ring_bytes(int N, int H, int U) {
 template <int MODE, int U>
 int launch_rs(const RnnP& p, hipStream_t s) {
     dim3 grid(p.P, p.Q, 2), block(16 * U);
+    if (p.xcd) grid = dim3(p.P * p.Q * 2);
     if (p.P <= 8) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 2>), grid, block, 0, s, p);
     else if (p.P <= 16) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 4>), grid, block, 0, s, p);
     else if (p.P <= 32) {
@@ -396,12 +410,15 @@ int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
         if (p.P * cdiv(p.N, cand) * 2 <= cus) { rpg = cand; break; }
     p.rpg = rpg;
     const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
-    AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, rbytes, s));      // tag 3 = "no step's value yet"
+    AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, rbytes + XCD_TAB_BYTES, s));      // tag 3 = "no step's value yet" (+ the XCC table)
     for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {
         p.n0 = n0;
         const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
         p.n1 = n0 + rows;
         p.Q = cdiv(rows, rpg);
+        // 8 (direction, row group) sets of at most 32 workgroups: XCD-aware grid (debug bit 262144: the plain 3-D grid,
+        // 524288: XCD-aware grid but write-through publish stores)
+        p.xcd = (p.Q * 2 == 8 && p.P <= 32 && !(p.flags & 262144)) ? 1 : 0;
         const int rc = (U == 32) ? launch_rs<MODE, 32>(p, s) : launch_rs<MODE, 16>(p, s);
         if (rc != 0) return -1;
         AAS_LAUNCH_CHECK(name);

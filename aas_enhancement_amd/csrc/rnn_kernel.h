@@ -50,6 +50,7 @@ struct RnnP {
     int rpg;             // batch rows per group (<= 16*MT): smaller groups = fewer exchanged bytes per workgroup
     int tag;             // written to the sticky error word when a bounded spin times out (aas_set_rnn_launch_tag)
     int flags;           // debug/ablation bits (aas_set_debug_flags): 1 no exchange loads, 2 no MFMA, 4 no wait, 8 no publish
+    int xcd;             // bit 0: XCD-aware 1-D grid (8 sets of P workgroups, a set per XCD class); bit 1: plain publish stores
 };
 
 __device__ __forceinline__ unsigned ld_cnt(const unsigned* p) {

@@ -7,7 +7,7 @@ extern "C" size_t aas_rnn_xchg_bytes(int T, int N, int H, int gates) {
     const size_t gather = (size_t)8 * T * N * ((size_t)gates * (H + 16) + 32);
     const size_t P = (size_t)(H + 15) / 16;                // 16-unit slices: the larger of the two ring shapes
     const size_t ring = (size_t)4 * N * P * P * 64;
-    return gather > ring ? gather : ring;
+    return (gather > ring ? gather : ring) + 8192;         // + the XCC table of the XCD-aware launches (rnn_split_kernel.h)
 }
 
 extern "C" int aas_lstm_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh, const float* w_hh_rev, float* hout,

@@ -38,6 +38,46 @@ __device__ __forceinline__ void st_sc1_u32(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- XCD co-location of an exchange set -----------------------------------------------------------------------------------
+// The P workgroups of one (direction, row group) set are the only ones that exchange data.  With the XCD-aware grid (8 sets,
+// workgroup b -> set b % 8, slice b / 8) they normally land on ONE XCD, and then the publish stores need not write through to
+// the fabric: a plain store is acknowledged by that XCD's L2, which also serves the consumers' L1-bypassing (sc1) loads -
+// LSTM BPTT 3.09 -> 2.65 us / step at N=30 and 4.74 -> 3.49 at N=60, bit-identical results.  Placement is not a contract, so
+// every workgroup publishes its XCC id (write-through) in a table behind the exchange data, reads its set's P entries back and
+// takes the plain-store path only if all agree; otherwise - or if the table read times out - the launch runs exactly as before.
+constexpr int XCD_TAB_BYTES = 8 * 64 * 4;
+
+__device__ __forceinline__ bool xcd_set_colocated(unsigned* tab, int set, int pslice, int P, unsigned* err, int tag, unsigned* lds_word) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xFu;
+        unsigned* row = tab + set * 64;
+        if (tid == 0) __hip_atomic_store(row + pslice, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned v = xcc, spins = 0;
+        bool ok = true;
+        while (true) {
+            v = (tid < P) ? __hip_atomic_load(row + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : xcc;
+            if (!__any(v == 0xFFFFFFFFu)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 255u) == 0 && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                                          __builtin_amdgcn_s_memrealtime() - t0 > 50000000ull)) {
+                if (tid == 0) __hip_atomic_store(err, (unsigned)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+        ok = ok && !__any(v != xcc);
+        if (tid == 0) *lds_word = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool r = *lds_word != 0u;
+    __syncthreads();
+    return r;
+}
+
 // MODE, MT = 16-row batch tiles per workgroup, KS = 32-wide k chunks per wave
 template <int MODE, int MT, int KS>
 __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""A/B of the XCD-aware recurrent launches: debug bit 262144 = the plain 3-D grid (write-through publish stores), 524288 = the
+XCD-aware grid with write-through stores, 0 = the default (XCD-aware grid, plain stores once a set is verified to share an XCD).
+Results must be bit-identical; timing printed.  python tools/xcd_check.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from aas_enhancement_amd import _lib, ops
+import rnn_bench
+
+
+def main():
+    L = _lib.lib()
+    L.aas_set_rnn_cu_limit(128)
+    for kind, T, N, H in (("lstm", 200, 30, 500), ("lstm", 200, 60, 500)):
+        G = 4
+        dev = "cuda"
+        torch.manual_seed(1)
+        x = torch.randn(T, N, H, device=dev) * 0.5
+        w = [torch.randn(G * H, H, device=dev) / H ** 0.5 for _ in range(4)]
+        hout, gact, cst = ops._birnn_fwd(kind, x, *w)
+        dy = torch.randn(T, N, H, device=dev)
+        sync = ops._sync_buf(x.device)
+        xc = ops._xchg_buf(x.device, T, N, H, G)
+        s, p = _lib.stream(), _lib.ptr
+        outs = {}
+        for fl in (262144, 524288, 0):
+            L.aas_set_debug_flags(fl)
+            dgx = torch.zeros(T, N, 2, G * H, device=dev)
+            b = lambda: L.aas_lstm_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(gact), p(cst), p(dgx), p(sync), p(xc))
+            t = rnn_bench.timeit(b, n=10)
+            torch.cuda.synchronize()
+            outs[fl] = dgx.clone()
+            print("%s N=%d flags=%7d  bwd %.3f ms (%.2f us/step)  timeout=%s  max|diff vs 3-D grid| %.3e" %
+                  (kind, N, fl, t, 1e3 * t / T, ops.rnn_timeout_flag(), (outs[fl] - outs[262144]).abs().max().item()), flush=True)
+        L.aas_set_debug_flags(0)
+
+
+if __name__ == "__main__":
+    main()
