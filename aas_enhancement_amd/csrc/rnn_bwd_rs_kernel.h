@@ -352,7 +352,8 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                     o.z = (__float_as_uint(acc[2]) & ~3u) | tag;
                     o.w = (__float_as_uint(acc[3]) & ~3u) | tag;
                     const unsigned boff = (unsigned)((((rblk + c) * P + pslice) * U + half * 16 + u4) * 4);
-                    if (plain) __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 0);       // the line stays in this XCD's L2
+                    if (plain && (p.flags & 1048576)) __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 1);   // (A/B: sc0)
+                    else if (plain) __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 0);       // the line stays in this XCD's L2
                     else __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 16);            // sc1: agent-scope write-through
                 }
             }

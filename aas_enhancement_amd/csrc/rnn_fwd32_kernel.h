@@ -24,7 +24,9 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
     __shared__ u32x4 bl_lds[LKS ? LKS * NT : 1][LKS ? 512 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pslice = blockIdx.x, qg = blockIdx.y, d = blockIdx.z;
+    const int pslice = p.xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;        // XCD-aware launch: see rnn_split_kernel.h
+    const int qg = p.xcd ? (int)((blockIdx.x & 7) >> 1) : (int)blockIdx.y;
+    const int d = p.xcd ? (int)(blockIdx.x & 1) : (int)blockIdx.z;
     const int T = p.T, N = p.N, H = p.H, GH = G * H;
     const int Hp = p.P * U;                              // padded unit pitch of the exchange rows
     const int u0 = pslice * U;
@@ -71,6 +73,12 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
     auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xq, 0, (int)((int64_t)2 * T * N * KC * 128), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     constexpr unsigned POISON = 0xFFFFFFFFu;
+    __shared__ unsigned xcd_flag;
+    bool plain = false;   // plain (L2-resident) publish stores once the set is verified to share an XCD
+    if (p.xcd) {
+        unsigned* tab = xq + (int64_t)2 * T * N * KC * 32;
+        plain = xcd_set_colocated(tab, (int)(blockIdx.x & 7), pslice, p.P, err, p.tag, &xcd_flag) && !(p.flags & 524288);
+    }
 
     // gate-math role: one (row, unit) per thread
     const int row = tid >> 5, u = tid & 31;
@@ -233,8 +241,13 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
             if (rowok && !(u & 1) && s + 1 < T && !(p.flags & 8)) {
                 const int64_t xr = ((int64_t)d * T + t) * N + gr;
                 unsigned* wq = xq + xr * KC * 32 + (unit / 32) * 32 + (unit % 32) / 2;
-                st_sc1_u32(wq, (mine & 0xFFFFu) | (other << 16));
-                st_sc1_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
+                if (plain) {
+                    st_sc0_u32(wq, (mine & 0xFFFFu) | (other << 16));
+                    st_sc0_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
+                } else {
+                    st_sc1_u32(wq, (mine & 0xFFFFu) | (other << 16));
+                    st_sc1_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
+                }
             }
         }
         if (ok) {
@@ -280,7 +293,7 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
         if (p.P * cdiv(p.N, cand) * 2 <= cus) { rpg = cand; break; }
     p.rpg = rpg;
     const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
-    AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes, s));
+    AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes + XCD_TAB_BYTES, s));
     // one launch covers the batch: afterwards the buffer holds h_t of every step but each direction's last as operand planes
     aas_note_fwd_h_planes(p.N <= qmax * rpg ? (Hp / 32) * 128 : 0);
     for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {
@@ -288,7 +301,12 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
         const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
         p.n1 = n0 + rows;
         p.Q = cdiv(rows, rpg);
+        // XCD-aware grid + L2-resident publish stores: only with <= 8 rows per group - in the all-gather every workgroup of a set
+        // reads the WHOLE exchanged block, and 16 readers on one L2 lose against 16 readers spread over eight at 16 rows per
+        // group (N=60: 3.65 -> 4.13 us / step; N=30 at 8 rows per group: 3.06 -> 2.74)
+        p.xcd = (p.Q * 2 == 8 && p.P <= 32 && rpg <= 8 && !(p.flags & 262144)) ? 1 : 0;
         dim3 grid(p.P, p.Q, 2), block(512);
+        if (p.xcd) grid = dim3(p.P * p.Q * 2);
         if constexpr (LSTM) {
             if (ks == 1) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 1, 0>), grid, block, 0, s, p);
             else if (ks == 2) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0>), grid, block, 0, s, p);

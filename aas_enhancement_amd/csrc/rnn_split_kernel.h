@@ -37,6 +37,10 @@ __device__ __forceinline__ void split_bf16(float x, unsigned& hi16, unsigned& lo
 __device__ __forceinline__ void st_sc1_u32(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// sc0: written through the CU's L1 at once, kept in the XCD's L2 (no write-through to the fabric)
+__device__ __forceinline__ void st_sc0_u32(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // ---- XCD co-location of an exchange set -----------------------------------------------------------------------------------
 // The P workgroups of one (direction, row group) set are the only ones that exchange data.  With the XCD-aware grid (8 sets,
@@ -93,7 +97,10 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     __shared__ float red2[DB ? 2 : 1][4][ROWS][LDR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pslice = blockIdx.x, qg = blockIdx.y, d = blockIdx.z;
+    // XCD-aware launch (p.xcd; forward modes, 8 sets): workgroup b -> set b % 8 = (row group, direction), slice b / 8
+    const int pslice = p.xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int qg = p.xcd ? (int)((blockIdx.x & 7) >> 1) : (int)blockIdx.y;
+    const int d = p.xcd ? (int)(blockIdx.x & 1) : (int)blockIdx.z;
     const int T = p.T, N = p.N, H = p.H, GH = G * H;
     const int Hp = p.P * U;                             // padded unit pitch of the exchange arrays
     const int u0 = pslice * U;
@@ -153,6 +160,12 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 
     unsigned long long ph[5] = {0, 0, 0, 0, 0};
     const bool stamp = (p.flags & 64) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    __shared__ unsigned xcd_flag;
+    bool plain = false;   // plain (L2-resident) publish stores once the set is verified to share an XCD (xcd_set_colocated)
+    if (FWD && p.xcd) {
+        unsigned* tab = p.xchg + xrows * KC * 32;          // behind the exchange rows, poisoned by the same memset
+        plain = xcd_set_colocated(tab, (int)(blockIdx.x & 7), pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag) && !(p.flags & 524288);
+    }
     for (int s = 0; s < T; ++s) {
         unsigned long long st0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull, st1 = st0, st2 = st0, st3 = st0;
         const int fwd_order = (d == 0) ? s : T - 1 - s;
@@ -410,8 +423,13 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                 if (rowok && !(u & 1) && s + 1 < T && !(p.flags & 8)) {  // the last step's output is not exchanged
                     const int k = g * Hp + unit;  // element index of the even unit of the pair within the exchanged row
                     unsigned* wq = xq + rbase_w + (k / 32) * 32 + (k % 32) / 2;
-                    st_sc1_u32(wq, (mine & 0xFFFFu) | (other << 16));
-                    st_sc1_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
+                    if (plain) {
+                        st_sc0_u32(wq, (mine & 0xFFFFu) | (other << 16));
+                        st_sc0_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
+                    } else {
+                        st_sc1_u32(wq, (mine & 0xFFFFu) | (other << 16));
+                        st_sc1_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
+                    }
                 }
             }
             // fp32 results for the rest of the layer (plain stores, off the exchange critical path)
@@ -446,6 +464,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 template <int MODE, int MT, int KS>
 int launch_sk(const RnnP& p, hipStream_t s) {
     dim3 grid(p.P, p.Q, 2);
+    if (p.xcd) grid = dim3(p.P * p.Q * 2);
     hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS>), grid, dim3(256), 0, s, p);
     return 0;
 }
@@ -496,8 +515,9 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
         const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
         p.n1 = n0 + rows;
         p.Q = cdiv(rows, rpg);
-        // poison the exchange arrays (hi | lo): a word is valid data once it is no longer 0xFFFFFFFF
-        AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes, s));
+        // poison the exchange arrays (hi | lo): a word is valid data once it is no longer 0xFFFFFFFF (+ the XCC table)
+        AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes + XCD_TAB_BYTES, s));
+        p.xcd = (FWD && p.Q * 2 == 8 && p.P <= 32 && rpg <= 8 && !(p.flags & 262144)) ? 1 : 0;   // (see rnn_fwd32_kernel.h)
         int rc = (mt == 1) ? launch_split_mt<MODE, 1>(p, ks_need, s) : launch_split_mt<MODE, 2>(p, ks_need, s);
         if (rc != 0) return -1;
         AAS_LAUNCH_CHECK(name);

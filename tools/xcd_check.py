@@ -37,6 +37,22 @@ def main():
             print("%s N=%d flags=%7d  bwd %.3f ms (%.2f us/step)  timeout=%s  max|diff vs 3-D grid| %.3e" %
                   (kind, N, fl, t, 1e3 * t / T, ops.rnn_timeout_flag(), (outs[fl] - outs[262144]).abs().max().item()), flush=True)
         L.aas_set_debug_flags(0)
+        for cus in (128, 0):
+            L.aas_set_rnn_cu_limit(cus)
+            pre = torch.randn(T, N, 2, G * H, device=dev)
+            fo = {}
+            for fl in (262144, 524288, 0):
+                L.aas_set_debug_flags(fl)
+                ho, ga, cs = torch.zeros_like(hout), torch.zeros_like(gact), torch.zeros_like(cst)
+                f = lambda: L.aas_lstm_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(ho), p(ga), p(cs), p(sync), p(xc))
+                t = rnn_bench.timeit(f, n=10)
+                torch.cuda.synchronize()
+                fo[fl] = (ho.clone(), cs.clone())
+                print("%s N=%d cus=%3d flags=%7d  fwd %.3f ms (%.2f us/step)  timeout=%s  max|diff vs 3-D grid| %.3e" %
+                      (kind, N, cus, fl, t, 1e3 * t / T, ops.rnn_timeout_flag(),
+                       max((fo[fl][0] - fo[262144][0]).abs().max().item(), (fo[fl][1] - fo[262144][1]).abs().max().item())), flush=True)
+            L.aas_set_debug_flags(0)
+        L.aas_set_rnn_cu_limit(128)
 
 
 if __name__ == "__main__":
