@@ -53,9 +53,13 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     // XCD-aware launch (p.xcd != 0; 8 (direction, row group) sets): 1-D grid, workgroup b -> set b % 8, slice b / 8.  Workgroups
     // are dealt round-robin over the 8 XCDs, so the P workgroups of a set - the only ones that exchange data - share an XCD
     // and its L2.
-    const int pslice = p.xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int qg = p.xcd ? (int)((blockIdx.x & 7) >> 1) : (int)blockIdx.y;
-    const int d = p.xcd ? (int)(blockIdx.x & 1) : (int)blockIdx.z;
+    // p.xcd == 2: 4 sets of (up to 64) workgroups, each spread over the XCD classes s and s + 4 (the 1000-unit GRU: a set is
+    // 32 workgroups, a launch beside another chain gets 16 CUs per XCD): set b % 4, slice 2*(b / 8) + (b % 8) / 4.  A partial
+    // block then stays in L2 exactly when its ONE consumer sits on the producer's XCD (per-consumer mask from the XCC table).
+    const int xset = p.xcd == 2 ? (int)(blockIdx.x & 3) : (int)(blockIdx.x & 7);
+    const int pslice = p.xcd == 2 ? (int)(2 * (blockIdx.x >> 3) + ((blockIdx.x & 7) >> 2)) : p.xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int qg = p.xcd ? (xset >> 1) : (int)blockIdx.y;
+    const int d = p.xcd ? (xset & 1) : (int)blockIdx.z;
     const int T = p.T, N = p.N, H = p.H, GH = G * H, P = p.P;
     const int u0 = pslice * U;
     const int q0 = p.n0 + qg * p.rpg;
@@ -95,11 +99,12 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
             }
     }
     // plain (L2-resident) publish stores when the whole set shares an XCD (rnn_split_kernel.h: xcd_set_colocated)
-    __shared__ unsigned xcd_flag;
-    bool plain = false;
+    __shared__ unsigned long long xcd_flag;
+    unsigned long long local = 0ull;    // bit c: consumer slice c shares this workgroup's XCD
     if (p.xcd) {
         unsigned* tab = p.xchg + (int64_t)4 * p.N * p.P * p.P * U;   // behind the ring, poisoned by the same memset
-        plain = xcd_set_colocated(tab, (int)(blockIdx.x & 7), pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag) && !(p.flags & 524288);
+        local = xcd_peer_mask(tab, xset, pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag);
+        if (p.flags & 524288) local = 0ull;
     }
     // zero both A tiles once: pad rows / pad gate columns stay zero for the whole launch
     for (int i = tid; i < 2 * 16 * RS_LDA; i += THREADS) {
@@ -352,8 +357,7 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                     o.z = (__float_as_uint(acc[2]) & ~3u) | tag;
                     o.w = (__float_as_uint(acc[3]) & ~3u) | tag;
                     const unsigned boff = (unsigned)((((rblk + c) * P + pslice) * U + half * 16 + u4) * 4);
-                    if (plain && (p.flags & 1048576)) __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 1);   // (A/B: sc0)
-                    else if (plain) __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 0);       // the line stays in this XCD's L2
+                    if ((local >> c) & 1ull) __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 0);   // the line stays in this XCD's L2
                     else __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 16);            // sc1: agent-scope write-through
                 }
             }
@@ -419,7 +423,7 @@ int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
         p.Q = cdiv(rows, rpg);
         // 8 (direction, row group) sets of at most 32 workgroups: XCD-aware grid (debug bit 262144: the plain 3-D grid,
         // 524288: XCD-aware grid but write-through publish stores)
-        p.xcd = (p.Q * 2 == 8 && p.P <= 32 && !(p.flags & 262144)) ? 1 : 0;
+        p.xcd = (p.flags & 262144) ? 0 : (p.Q * 2 == 8 && p.P <= 32) ? 1 : (p.Q * 2 == 4 && p.P <= 64 && p.P % 2 == 0) ? 2 : 0;
         const int rc = (U == 32) ? launch_rs<MODE, 32>(p, s) : launch_rs<MODE, 16>(p, s);
         if (rc != 0) return -1;
         AAS_LAUNCH_CHECK(name);

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
     auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xq, 0, (int)((int64_t)2 * T * N * KC * 128), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     constexpr unsigned POISON = 0xFFFFFFFFu;
-    __shared__ unsigned xcd_flag;
+    __shared__ unsigned long long xcd_flag;
     bool plain = false;   // plain (L2-resident) publish stores once the set is verified to share an XCD
     if (p.xcd) {
         unsigned* tab = xq + (int64_t)2 * T * N * KC * 32;

@@ -51,7 +51,9 @@ __device__ __forceinline__ void st_sc0_u32(unsigned* p, unsigned v) {
 // takes the plain-store path only if all agree; otherwise - or if the table read times out - the launch runs exactly as before.
 constexpr int XCD_TAB_BYTES = 8 * 64 * 4;
 
-__device__ __forceinline__ bool xcd_set_colocated(unsigned* tab, int set, int pslice, int P, unsigned* err, int tag, unsigned* lds_word) {
+// -> bit c set: slice c of this workgroup's set runs on the same XCD as this workgroup (0: unknown - table read timed out)
+__device__ __forceinline__ unsigned long long xcd_peer_mask(unsigned* tab, int set, int pslice, int P, unsigned* err, int tag,
+                                                            unsigned long long* lds_word) {
     const int tid = threadIdx.x;
     if (tid < 64) {
         unsigned xcc;
@@ -73,13 +75,18 @@ __device__ __forceinline__ bool xcd_set_colocated(unsigned* tab, int set, int ps
                 break;
             }
         }
-        ok = ok && !__any(v != xcc);
-        if (tid == 0) *lds_word = ok ? 1u : 0u;
+        const unsigned long long m = __ballot(tid < P && v == xcc);
+        if (tid == 0) *lds_word = ok ? m : 0ull;
     }
     __syncthreads();
-    const bool r = *lds_word != 0u;
+    const unsigned long long r = *lds_word;
     __syncthreads();
     return r;
+}
+
+__device__ __forceinline__ bool xcd_set_colocated(unsigned* tab, int set, int pslice, int P, unsigned* err, int tag, unsigned long long* lds_word) {
+    const unsigned long long all = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
+    return xcd_peer_mask(tab, set, pslice, P, err, tag, lds_word) == all;
 }
 
 // MODE, MT = 16-row batch tiles per workgroup, KS = 32-wide k chunks per wave
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 
     unsigned long long ph[5] = {0, 0, 0, 0, 0};
     const bool stamp = (p.flags & 64) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-    __shared__ unsigned xcd_flag;
+    __shared__ unsigned long long xcd_flag;
     bool plain = false;   // plain (L2-resident) publish stores once the set is verified to share an XCD (xcd_set_colocated)
     if (FWD && p.xcd) {
         unsigned* tab = p.xchg + xrows * KC * 32;          // behind the exchange rows, poisoned by the same memset

@@ -38,6 +38,8 @@ int aas_device_cus(void);
  *   BPTT instead of the reduce-scatter kernel, 512 16-unit slices, 8192 poll before streaming in the reduce-scatter
  *   BPTT, 1024 128x128 tiles instead of 256x256 and 2048 128x256 instead of 128x128 in aas_gemm_planes, 4096 plain
  *   3-D grid instead of the XCD-aware tile order in aas_gemm_planes, 16384 the general (any S) CTC kernel even when S <= 64,
+ *   262144 the plain 3-D grid in the persistent recurrent launches instead of the XCD-aware one (exchange sets per XCD class,
+ *     L2-resident publish stores once a set is verified co-located), 524288 XCD-aware grid but write-through publish stores,
  *   65536 / 131072 four waves per workgroup (one per SIMD) instead of eight in aas_gemm_planes_tn / the 128x128 aas_gemm_planes,
  *   32768 the 1000-unit GRU BPTT kernel with one (not two) k-steps of lo weight fragments in LDS (the older, spilling variant). */
 int aas_set_debug_flags(int flags);

@@ -55,5 +55,31 @@ def main():
         L.aas_set_rnn_cu_limit(128)
 
 
+def gru():
+    L = _lib.lib()
+    L.aas_set_rnn_cu_limit(128)
+    T, N, H, G, dev = 85, 30, 1000, 3, "cuda"
+    torch.manual_seed(2)
+    x = torch.randn(T, N, H, device=dev) * 0.5
+    w = [torch.randn(G * H, H, device=dev) / H ** 0.5 for _ in range(4)]
+    hout, gact, _ = ops._birnn_fwd("gru", x, *w)
+    dy = torch.randn(T, N, H, device=dev)
+    sync, xc = ops._sync_buf(x.device), ops._xchg_buf(x.device, T, N, H, G)
+    s, p = _lib.stream(), _lib.ptr
+    outs = {}
+    for fl in (262144, 524288, 0):
+        L.aas_set_debug_flags(fl)
+        dgx, dgh = torch.zeros(T, N, 2, G * H, device=dev), torch.zeros(T, N, 2, G * H, device=dev)
+        b = lambda: L.aas_gru_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(hout), p(gact), p(dgx), p(dgh), p(sync), p(xc))
+        t = rnn_bench.timeit(b, n=10)
+        torch.cuda.synchronize()
+        outs[fl] = (dgx.clone(), dgh.clone())
+        print("gru N=%d flags=%7d  bwd %.3f ms (%.2f us/step)  timeout=%s  max|diff vs 3-D grid| %.3e" %
+              (N, fl, t, 1e3 * t / T, ops.rnn_timeout_flag(),
+               max((outs[fl][0] - outs[262144][0]).abs().max().item(), (outs[fl][1] - outs[262144][1]).abs().max().item())), flush=True)
+    L.aas_set_debug_flags(0)
+
+
 if __name__ == "__main__":
+    gru()
     main()
