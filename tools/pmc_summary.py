@@ -1,6 +1,6 @@
 """Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM bytes per launch.
 
-    python tools/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> "<command that was profiled>"
+    python tools/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> "<command that was profiled>" [steps in the run]
 
 Units (MI355X_MICROARCH.md, HBM / rocprofv3 section): both counters are in KiB per dispatch; on gfx950 FETCH_SIZE reports
 half of the bytes of wide (16 B/lane) coalesced reads, so fetched bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact."""
@@ -44,13 +44,15 @@ def main():
     classes = {"lstm_bwd[N=60,H=500]": "rnn_bwd_rs_kernel<1, 32, 4> grid=65536", "lstm_bwd[N=30,H=500]": "rnn_bwd_rs_kernel<1, 32, 4> grid=65536",
                "gru_bwd[N=30,H=1000]": "rnn_bwd_rs_kernel<3, 32, 8> grid=65536", "lstm_fwd[N=60,H=500]": "rnn_fwd32_kernel<0, 2, 0> grid=65536",
                "lstm_fwd[N=30,H=500]": "rnn_split_kernel<0, 1, 4> grid=65536", "gru_fwd[N=30,H=1000]": "rnn_fwd32_kernel<2, 4, 2> grid=65536",
-               "gemm_planes_wgrad": "gemm_planes_kernel<128, 128, 2, 2, true>", "gemm_planes": "gemm_planes_kernel<256, 256, 4, 2, true>"}
+               "gemm_planes_wgrad": "gemm_planes_tn_kernel<8>", "gemm_planes": "gemm_planes_kernel<256, 256, 4, 2, true>"}
     by_class = {}
     for cname, kname in classes.items():
         hit = [v for k, v in kernels.items() if k == kname or (kname.split(" grid=")[0] == k.split(" grid=")[0] and cname.startswith(("lstm", "gru")) and len([x for x in kernels if x.split(" grid=")[0] == k.split(" grid=")[0]]) == 1)]
         if hit:
             by_class[cname] = dict(hit[0], kernel=kname)
-    json.dump({"by_class": by_class, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `%s`" % cmd,
+    total = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in kernels.values())
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    json.dump({"total_hbm_bytes": total, "steps_in_run": steps, "hbm_bytes_per_step": (total / steps) if steps else None, "by_class": by_class, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `%s`" % cmd,
                "units": "KiB per dispatch; fetched bytes = 2 x FETCH_SIZE x 1024 (gfx950 wide-read correction), written bytes = WRITE_SIZE x 1024",
                "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
