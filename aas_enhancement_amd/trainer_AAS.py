@@ -372,13 +372,9 @@ class Trainer(object):
             # two chains of half-chip persistent launches run side by side: the weight-gradient GEMMs never take more than the
             # other half of the CUs, so a recurrent launch always finds its CUs (AAS_WGRAD_WGS overrides)
             lanes = self._lanes_ok(tuple(cl_inputs.shape) == tuple(inputs.shape))
-            if not os.environ.get("AAS_WGRAD_WGS"):
-                # (batched-D schedule only: with the two-lane schedule's three chains a cap costs more than it saves, 19.5 vs 18.6 ms)
-                ops.set_wgrad_cap(ops.device_cus() // 2 if (self._overlap_asr() and not lanes) else 0)
-                if getattr(self, "_g_first_lid", None) is None:   # E's first layer is back-propagated last: nothing left to protect
-                    self._g_first_lid = next((m._aas_layer_id for m in self.G.modules() if getattr(m, "_aas_layer_id", None) is not None), 0)
-                ops.UNCAPPED_LIDS.clear()
-                ops.UNCAPPED_LIDS.add(self._g_first_lid)
+            # (ops.set_wgrad_cap / AAS_WGRAD_WGS: a grid cap on the weight-gradient GEMMs, so that they never hold more than half
+            #  of the CUs while a recurrent launch waits to become resident, bought 0.4 ms before the XCD-aware recurrent launches;
+            #  since then it is worth +-0.05 ms with a frozen A and costs 1.5 ms with a trainable one: off by default)
             if lanes:
                 enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC = self._two_lane_core(inputs, cl_inputs, scales, ctc_meta, asr_steps)
             else:
@@ -390,8 +386,6 @@ class Trainer(object):
                 self._reducer.wait()
         finally:
             ops.WGRAD_HOOK[0] = None
-            if not os.environ.get("AAS_WGRAD_WGS"):
-                ops.set_wgrad_cap(0)
         optimizer_g.step_dev()
         if not getattr(self, "_early_adam", False):
             optimizer_d.step_dev()

@@ -54,8 +54,8 @@ int aas_set_rnn_launch_tag(int tag);
 int aas_rnn_last_fwd_h_pitch(void);
 /* Cap on the grid of the aas_gemm_planes_tn launches queued after the call (0 = none, the default: one workgroup per tile):
  * with a cap each workgroup walks several tiles, so the weight-gradient products never hold more than `workgroups` CUs while
- * a persistent recurrent launch waits to become resident.  The AAS step sets half of the CUs while its two chains of half-chip
- * launches run (18.9 -> 18.5 ms / step at config 2); steps with a single chain leave it off (a cap only slows them down). */
+ * a persistent recurrent launch waits to become resident (an A/B switch: worth 0.4 ms / step at config 2 before the XCD-aware
+ * recurrent launches, nothing since; trainers leave it off). */
 int aas_set_wgrad_wg_cap(int workgroups);
 /* Matrix-product operand precision: 0 = exact fp32-input MFMA; 1 (default) = split-bf16: each fp32 operand is
  * carried as bf16 hi + bf16 lo and the product as hi*hi + lo*hi + hi*lo with fp32 accumulation (~1e-5 relative,
