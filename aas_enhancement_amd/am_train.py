@@ -52,7 +52,7 @@ class AMTrainer(object):
         meta = self.criterion.prepare(targets, sizes, target_sizes, inputs.device)
         if self.dp.active:   # global batch size as a device scalar (no host sync before the step is queued)
             if getattr(self, "_aux", None) is None:
-                self._aux = torch.cuda.Stream()
+                self._aux = ops.refresh_stream(inputs.device)   # the one utility stream (few hardware queues)
             counts = DeviceCounts(self.dp, [N], inputs.device, self._aux)
         ops.sync_wgrad()
         self.flat.zero_grad()

@@ -34,7 +34,10 @@ class DataLoader():
             from .lmfb import LMFB
             self._lmfb = LMFB(n_mels=n_mels).to(self.device)
         self._ds, self._sp, self._it, self._ahead = {}, {}, {}, {}
-        self._copy_stream = torch.cuda.Stream(device=self.device) if (self.device is not None and self.device.type == "cuda") else None
+        self._copy_stream = None
+        if self.device is not None and self.device.type == "cuda":
+            from . import ops
+            self._copy_stream = ops.refresh_stream(self.device)   # the process's one utility stream: streams share four hardware queues
         for key, manifest, sampled in (("cl/train", tr_cl_manifest, True), ("ny/train", tr_ny_manifest, True),
                                        ("ny/trsub", trsub_manifest, False), ("ny/val", val_manifest, False),
                                        ("ny/val2", val2_manifest, False)):
