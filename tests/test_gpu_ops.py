@@ -574,3 +574,47 @@ def test_batchnorm_split_entry_points_and_adam_tick(ops):
     kt, o6 = torch.full((1,), 0.9995, device="cuda", dtype=torch.float64), torch.zeros(6, device="cuda", dtype=torch.float64)
     ops.began_step(torch.tensor(3.0).cuda(), torch.tensor(8.0).cuda(), torch.tensor(5.0).cuda(), kt, o6, 0.5, 0.001, 30.0)
     assert float(kt) == pytest.approx(min(1.0, 0.9995 + 0.001 * (0.5 * 8.0 - 3.0))) and o6.tolist() == pytest.approx([3.0, 8.0, 5.0, float(kt), 150.0, 30.0])
+
+
+@pytest.mark.parametrize("kind,T,N,H", [("lstm", 60, 30, 500), ("lstm", 60, 60, 500), ("gru", 40, 30, 1000), ("lstm", 25, 30, 64)])
+def test_xcd_aware_recurrent_launches_are_bit_identical(ops, kind, T, N, H):
+    """The XCD-aware persistent launches (exchange sets dealt to XCD classes; L2-resident publish stores once the XCC-id
+    handshake has verified that a set - or a producer / consumer pair - shares an XCD) against the plain 3-D grid with
+    write-through stores (debug bit 262144) and the XCD-aware grid with write-through stores (524288): same bits, no timeout.
+    Half-chip grids as in the step (that is where 8 / 4 exchange sets occur); the small layer exercises the ineligible path."""
+    from aas_enhancement_amd import _lib
+    L = _lib.lib()
+    G = 4 if kind == "lstm" else 3
+    dev = "cuda"
+    L.aas_set_rnn_cu_limit(ops.device_cus() // 2)
+    try:
+        x = R(T, N, H, seed=3, scale=0.5).to(dev)
+        w = [(R(G * H, H, seed=4 + i) / H ** 0.5).to(dev) for i in range(4)]
+        pre = R(T, N, 2, G * H, seed=9).to(dev)
+        dy = R(T, N, H, seed=10).to(dev)
+        sync, xc = ops._sync_buf(x.device), ops._xchg_buf(x.device, T, N, H, G)
+        s, p = _lib.stream(), _lib.ptr
+        res = {}
+        for fl in (262144, 524288, 0):
+            L.aas_set_debug_flags(fl)
+            hout = torch.zeros(2, T, N, H, device=dev)
+            gact = torch.zeros(2, T, N, H, 4, device=dev)
+            cst = torch.zeros(2, T, N, H, device=dev)
+            dgx = torch.zeros(T, N, 2, G * H, device=dev)
+            dgh = torch.zeros(T, N, 2, G * H, device=dev)
+            if kind == "lstm":
+                ops.check(L.aas_lstm_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(cst), p(sync), p(xc)), "fwd")
+                ops.check(L.aas_lstm_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(gact), p(cst), p(dgx), p(sync), p(xc)), "bwd")
+            else:
+                ops.check(L.aas_gru_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(sync), p(xc)), "fwd")
+                ops.check(L.aas_gru_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(hout), p(gact), p(dgx), p(dgh), p(sync), p(xc)), "bwd")
+            torch.cuda.synchronize()
+            assert not ops.rnn_timeout_flag()
+            res[fl] = [t.clone() for t in (hout, gact, cst, dgx, dgh)]
+        for fl in (524288, 0):
+            for a, b in zip(res[fl], res[262144]):
+                assert torch.equal(a, b), (kind, fl)
+        assert torch.isfinite(res[0][3]).all() and res[0][3].abs().max() > 0
+    finally:
+        L.aas_set_debug_flags(0)
+        L.aas_set_rnn_cu_limit(0)
