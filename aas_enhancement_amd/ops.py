@@ -123,13 +123,8 @@ def set_rnn_cu_limit(cus):
     check(lib().aas_set_rnn_cu_limit(int(cus)), "aas_set_rnn_cu_limit")
 
 
-_wgrad_cap = [0]
-UNCAPPED_LIDS = set()    # layer ids whose weight-gradient GEMMs ignore the cap (a step's LAST layer: no recurrent launch follows it)
-
-
 def set_wgrad_cap(workgroups):
     """Grid cap of the row-major weight-gradient GEMMs queued from now on (0 = none); include/aas_hip.h: aas_set_wgrad_wg_cap."""
-    _wgrad_cap[0] = int(workgroups)
     lib().aas_set_wgrad_wg_cap(int(workgroups))
 
 
@@ -873,12 +868,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
                           C0=out[1].data_ptr(), C1=0, msplit=GH, ldc=H, ta=1, tb=0),
                      dict(base, A=a_h, B=hx.data_ptr() + R * hpitch, ldb=hpitch, bcols=hpitch // 4, acol0=GH, M=GH, N=H,
                           K=(T - 1) * ns, C0=out[3].data_ptr(), C1=0, msplit=GH, ldc=H, ta=0, tb=1)]
-            uncapped = _wgrad_cap[0] > 0 and lid in UNCAPPED_LIDS
-            if uncapped:
-                lib().aas_set_wgrad_wg_cap(0)
             gemm_planes_tn(probs, ns, N, dev, accumulate=True)
-            if uncapped:
-                lib().aas_set_wgrad_wg_cap(_wgrad_cap[0])
         cur = torch.cuda.current_stream()
         for t_ in (dgp, dghp, xp.buf, hx):
             t_.record_stream(cur)

@@ -599,20 +599,7 @@ class Trainer(object):
             self._kt_dev.fill_(float(self.kt))   # another path advanced the host copy since
         self._kt_dev_live = True
         self._host_ahead = True
-        if os.environ.get("AAS_MAIN_PRIO", "0") == "1":
-            # the whole step on a highest-priority stream of the trainer's own (the caller's stream has default priority, the
-            # same as the weight-gradient stream): joined with the caller's stream at both ends
-            if getattr(self, "_main_stream", None) is None:
-                self._main_stream = ops.chain_stream()
-            caller = torch.cuda.current_stream()
-            self._main_stream.wait_stream(caller)
-            with torch.cuda.stream(self._main_stream):
-                enhanced, prob = self._device_core(inputs, cl_inputs, nv_ny, nv_cl, meta, it=iter)
-            caller.wait_stream(self._main_stream)
-            for t_ in (enhanced, prob, inputs, cl_inputs):
-                t_.record_stream(self._main_stream)
-        else:
-            enhanced, prob = self._device_core(inputs, cl_inputs, nv_ny, nv_cl, meta, it=iter)
+        enhanced, prob = self._device_core(inputs, cl_inputs, nv_ny, nv_cl, meta, it=iter)
         self._host_ahead = False
         return dict(enhanced=enhanced, prob=prob, scalars=self._g_out)
 
