@@ -44,28 +44,34 @@ struct PTN {
     int accumulate, flags, per, tiles, maxwg;
 };
 
+template <int PITCH>
 __device__ __forceinline__ bf16x8 tr_frag(const char* a) {
-    // rows 8g .. 8g+3 then 8g+4 .. 8g+7 (2048 B = 4 LDS rows further on): lane i of the group gets column i
+    // rows 8g .. 8g+3 then 8g+4 .. 8g+7 (4 LDS rows further on): lane i of the group gets column i
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 2048));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 4 * PITCH));
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
 
 __device__ __forceinline__ int fsw(int k) { return (2 * (k & 3)) ^ (8 * ((k >> 3) & 1)); }
 
-// 128 x 128 x 32 tile, NW waves as (NW/2) x 2: wave tile (256/NW) x 64 rows x columns, i.e. MI x 4 MFMA tiles with MI = 16/NW;
-// two LDS slots of (A, B) x 32 rows x 512 B.  NW = 8 (two waves per SIMD from ONE workgroup) is the default: a layer's products
-// are only ~256 tiles, one per CU, and with a single wave per SIMD nothing covers that wave's LDS / barrier waits.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void gemm_planes_tn_kernel(PTN p) {
-    constexpr int TILE_B = 32 * 512, STAGE_B = 2 * TILE_B;
-    constexpr int MI = 16 / NW;          // 16-row m tiles per wave
-    constexpr int JS = 16 / NW;          // staging loads per operand, wave and k-step (2 LDS rows each)
+// BMC x BNC x 32 tile (columns of A / columns of B), WM x WN waves, wave tile (BMC/WM) x (BNC/WN) as MI x NJ MFMA tiles; two LDS
+// slots of (A, B) x 32 rows.  128 x 128 with 4 x 2 waves (two waves per SIMD from ONE workgroup: with a single wave per SIMD
+// nothing covers that wave's LDS / barrier waits, 0.30 -> 0.20 ms); 256 x 256 with 4 x 2 waves as an opt-in (debug bit
+// 8388608): the kernel is bound by what a CU can stage per k-step (32 KB at 128 x 128, ~53 GB/s per CU), and a 256 x 256 tile
+// stages 64 KB for four times the flops - but a layer then has only 64 long-lived workgroups (see the launch code).
+template <int BMC, int BNC, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_planes_tn_kernel(PTN p) {
+    constexpr int NW = WM * WN;
+    constexpr int A_P = BMC * 4, B_P = BNC * 4;              // LDS bytes per k row (hi | lo of every column)
+    constexpr int TILE_A = 32 * A_P, TILE_Bb = 32 * B_P, STAGE_B = TILE_A + TILE_Bb;
+    constexpr int MI = BMC / WM / 16, NJ = BNC / WN / 16;
+    constexpr int JA = TILE_A / 1024 / NW, JB = TILE_Bb / 1024 / NW;   // 1-KB staging loads per wave and k-step
+    static_assert(TILE_A % (1024 * NW) == 0 && TILE_Bb % (1024 * NW) == 0, "tiles must split into whole wave loads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     // XCD x (workgroups with blockIdx % 8 == x) takes the contiguous run of tiles [x*per, (x+1)*per); with a capped grid a
     // workgroup walks its XCD's run in strides of gridDim/8
     for (int slot = blockIdx.x >> 3; slot < p.per; slot += gridDim.x >> 3) {
@@ -76,84 +82,128 @@ __global__ __launch_bounds__(64 * NW) void gemm_planes_tn_kernel(PTN p) {
     while (pr + 1 < p.nprob && qt >= p.tile0[pr + 1]) ++pr;
     const int qq = qt - p.tile0[pr];
     const int gx = p.gx[pr];
-    const int m0 = (qq / gx) * 128, n0t = (qq % gx) * 128;
+    const int m0 = (qq / gx) * BMC, n0t = (qq % gx) * BNC;
     const int K = p.K[pr], Ns = p.Ns, Nb = p.Nb;
     const char* Ab = p.A[pr];
     const char* Bb = p.B[pr];
     const int64_t lda = p.lda[pr], ldb = p.ldb[pr];
     const int arow0 = p.ta[pr] * Nb + p.n0[pr], brow0 = p.tb[pr] * Nb + p.n0[pr];
 
-    // ---- staging roles: load j of this wave fills LDS rows 2*(JS*wave + j) + (lane >> 5), chunk slot lane & 31.  Each lane walks
-    // its rows down the operands with running 64-bit pointers: per k-step a row index advances by 32 positions of the class,
-    // i.e. by 32 + (time-step wraps) * (Nb - Ns) plane rows - one multiply-add per pointer and step.
-    const int pc = lane & 31;
-    const char* zsrc = p.zero + pc * 16;
-    const char *pa[JS], *pb[JS];
-    unsigned sa[JS], sb_[JS];     // row pitch in bytes, 0 for a column chunk outside the operand (pointer parked on the zero block)
-    int nn[JS];
+    // ---- staging roles: load j of this wave fills 1 KB of a tile: LDS row kr, 16-byte chunk slot pc.  The rows walk down the
+    // operands: per k-step a row index advances by 32 positions of the class, i.e. by 32 + (time-step wraps) * (Nb - Ns) plane
+    // rows.  With 1-KB LDS rows (256-column tiles) a load covers ONE row: the row state is wave-uniform (scalar registers) and
+    // a lane keeps just its column offset; with 512-byte rows (128 columns) the two halves of a wave are on different rows and
+    // every lane walks its own 64-bit pointers.
+    const char* zsrc = p.zero + (lane & 31) * 16;
     const int gap = Nb - Ns;
+    u32x4 ra_[JA], rb_[JB];
+    // per-lane state (512-byte rows)
+    const char *pa[JA], *pb[JB];
+    unsigned sa[JA], sb_[JB];     // row pitch in bytes, 0 for a column chunk outside the operand (pointer parked on the zero block)
+    int na[JA], nb_[JB];
+    // wave-uniform state (1-KB rows): plane row index and position inside the time step per load, column byte offset per lane
+    int64_t rowa[JA], rowb[JB];
+    int offa[JA], offb[JB];
 #pragma unroll
-    for (int j = 0; j < JS; ++j) {
-        const int kr = 2 * (JS * wave + j) + (lane >> 5);
+    for (int j = 0; j < JA; ++j) {
+        const int byte = (wave * JA + j) * 1024 + lane * 16;
+        const int kr = A_P == 1024 ? wave * JA + j : byte / A_P, pc = (byte % A_P) / 16;   // (1-KB rows: wave-uniform row)
         const int c = pc ^ fsw(kr);                        // logical chunk: piece (16 columns), hi / lo, 8-column half
         const int piece = c >> 2, hl = (c >> 1) & 1, half = c & 1;
         const int ca = p.acol0[pr] + m0 + 16 * piece + 8 * half;
-        const int cb = n0t + 16 * piece + 8 * half;
         const bool va = (m0 + 16 * piece + 8 * half < p.M[pr]) && (ca + 8 <= p.acols[pr]);
-        const bool vb = (cb < p.N[pr]) && (cb + 8 <= p.bcols[pr]);
+        const int cbyte = (ca >> 5) * 128 + hl * 64 + (ca & 31) * 2;
         const int t0 = kr / Ns;
-        nn[j] = kr - t0 * Ns;
-        const int64_t r0 = (int64_t)t0 * Nb + nn[j];
-        pa[j] = va ? Ab + (r0 + arow0) * lda + ((ca >> 5) * 128 + hl * 64 + (ca & 31) * 2) : zsrc;
-        pb[j] = vb ? Bb + (r0 + brow0) * ldb + ((cb >> 5) * 128 + hl * 64 + (cb & 31) * 2) : zsrc;
-        sa[j] = va ? (unsigned)lda : 0u;
-        sb_[j] = vb ? (unsigned)ldb : 0u;
+        na[j] = kr - t0 * Ns;
+        if constexpr (A_P == 1024) {
+            rowa[j] = (int64_t)t0 * Nb + na[j] + arow0;
+            offa[j] = va ? cbyte : -1;
+        } else {
+            pa[j] = va ? Ab + ((int64_t)t0 * Nb + na[j] + arow0) * lda + cbyte : zsrc;
+            sa[j] = va ? (unsigned)lda : 0u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+        const int byte = (wave * JB + j) * 1024 + lane * 16;
+        const int kr = B_P == 1024 ? wave * JB + j : byte / B_P, pc = (byte % B_P) / 16;
+        const int c = pc ^ fsw(kr);
+        const int piece = c >> 2, hl = (c >> 1) & 1, half = c & 1;
+        const int cb = n0t + 16 * piece + 8 * half;
+        const bool vb = (cb < p.N[pr]) && (cb + 8 <= p.bcols[pr]);
+        const int cbyte = (cb >> 5) * 128 + hl * 64 + (cb & 31) * 2;
+        const int t0 = kr / Ns;
+        nb_[j] = kr - t0 * Ns;
+        if constexpr (B_P == 1024) {
+            rowb[j] = (int64_t)t0 * Nb + nb_[j] + brow0;
+            offb[j] = vb ? cbyte : -1;
+        } else {
+            pb[j] = vb ? Bb + ((int64_t)t0 * Nb + nb_[j] + brow0) * ldb + cbyte : zsrc;
+            sb_[j] = vb ? (unsigned)ldb : 0u;
+        }
     }
     // Register staging (global_load_dwordx4 -> ds_write_b128), one k-step ahead: the tile of step i+1 is written into the
     // other LDS slot right after the barrier of step i, and the loads of step i+2 are issued before the MFMAs of step i, so a
     // load has a whole k-step to land.  (LDS-DMA as in gemm_planes.hip was measured equal; behind a pending global_load_lds
     // the compiler also puts vmcnt(0) in front of the first transposing LDS read.)
-    u32x4 ra_[JS], rb_[JS];
     auto load = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < JS; ++j) {
-            const int kr = 2 * (JS * wave + j) + (lane >> 5);
+        for (int j = 0; j < JA; ++j) {
+            const int kr = A_P == 1024 ? wave * JA + j : ((wave * JA + j) * 1024 + lane * 16) / A_P;
             const bool rok = (k0 + kr) < K && !(p.flags & 64);
-            ra_[j] = *reinterpret_cast<const u32x4*>(rok ? pa[j] : zsrc);
-            rb_[j] = *reinterpret_cast<const u32x4*>(rok ? pb[j] : zsrc);
-            nn[j] += 32;                                   // the next k-step of this lane's row
             unsigned adv = 32;
-            while (nn[j] >= Ns) { nn[j] -= Ns; adv += gap; }
-            pa[j] += (uint64_t)adv * sa[j];
-            pb[j] += (uint64_t)adv * sb_[j];
+            na[j] += 32;                                   // the next k-step of this row
+            while (na[j] >= Ns) { na[j] -= Ns; adv += gap; }
+            if constexpr (A_P == 1024) {
+                const char* rp = Ab + rowa[j] * lda;       // wave-uniform
+                ra_[j] = *reinterpret_cast<const u32x4*>((rok && offa[j] >= 0) ? rp + offa[j] : zsrc);
+                rowa[j] += adv;
+            } else {
+                ra_[j] = *reinterpret_cast<const u32x4*>(rok ? pa[j] : zsrc);
+                pa[j] += (uint64_t)adv * sa[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int kr = B_P == 1024 ? wave * JB + j : ((wave * JB + j) * 1024 + lane * 16) / B_P;
+            const bool rok = (k0 + kr) < K && !(p.flags & 64);
+            unsigned adv = 32;
+            nb_[j] += 32;
+            while (nb_[j] >= Ns) { nb_[j] -= Ns; adv += gap; }
+            if constexpr (B_P == 1024) {
+                const char* rp = Bb + rowb[j] * ldb;
+                rb_[j] = *reinterpret_cast<const u32x4*>((rok && offb[j] >= 0) ? rp + offb[j] : zsrc);
+                rowb[j] += adv;
+            } else {
+                rb_[j] = *reinterpret_cast<const u32x4*>(rok ? pb[j] : zsrc);
+                pb[j] += (uint64_t)adv * sb_[j];
+            }
         }
     };
     auto put = [&](int st) {
-        char* base = smem + st * STAGE_B + wave * (JS * 1024) + lane * 16;
+        char* base = smem + st * STAGE_B + lane * 16;
 #pragma unroll
-        for (int j = 0; j < JS; ++j) {
-            *reinterpret_cast<u32x4*>(base + j * 1024) = ra_[j];
-            *reinterpret_cast<u32x4*>(base + TILE_B + j * 1024) = rb_[j];
-        }
+        for (int j = 0; j < JA; ++j) *reinterpret_cast<u32x4*>(base + (wave * JA + j) * 1024) = ra_[j];
+#pragma unroll
+        for (int j = 0; j < JB; ++j) *reinterpret_cast<u32x4*>(base + TILE_A + (wave * JB + j) * 1024) = rb_[j];
     };
 
-    f32x4 acc[MI][4];
+    f32x4 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- fragment addresses: group g = lane >> 4 reads LDS rows 8g .. 8g+7; lane 4q'+p' supplies row 8g + q', bytes 8p' ----
     const int i16 = lane & 15, g = lane >> 4, qp = i16 >> 2, pp = i16 & 3;
     const int fq = (2 * qp) ^ (8 * (g & 1));
-    const int rbase = (8 * g + qp) * 512 + 8 * (pp & 1);
-    int fa[MI][2], fb[4][2];
+    int fa[MI][2], fb[NJ][2];
 #pragma unroll
     for (int hl = 0; hl < 2; ++hl) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i][hl] = rbase + ((((wm * MI + i) * 4 + 2 * hl) ^ fq) + (pp >> 1)) * 16;
+        for (int i = 0; i < MI; ++i) fa[i][hl] = (8 * g + qp) * A_P + 8 * (pp & 1) + ((((wm * MI + i) * 4 + 2 * hl) ^ fq) + (pp >> 1)) * 16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j][hl] = TILE_B + rbase + ((((wn * 4 + j) * 4 + 2 * hl) ^ fq) + (pp >> 1)) * 16;
+        for (int j = 0; j < NJ; ++j) fb[j][hl] = TILE_A + (8 * g + qp) * B_P + 8 * (pp & 1) + ((((wn * NJ + j) * 4 + 2 * hl) ^ fq) + (pp >> 1)) * 16;
     }
 
     const int nk = (K + 31) / 32;
@@ -168,13 +218,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_planes_tn_kernel(PTN p) {
             bf16x8 ah[MI], al[MI];
 #pragma unroll
             for (int ii = 0; ii < MI; ++ii) {
-                ah[ii] = tr_frag(sb + fa[ii][0]);
-                al[ii] = tr_frag(sb + fa[ii][1]);
+                ah[ii] = tr_frag<A_P>(sb + fa[ii][0]);
+                al[ii] = tr_frag<A_P>(sb + fa[ii][1]);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16x8 bh = tr_frag(sb + fb[j][0]);
-                const bf16x8 bl = tr_frag(sb + fb[j][1]);
+            for (int j = 0; j < NJ; ++j) {
+                const bf16x8 bh = tr_frag<B_P>(sb + fb[j][0]);
+                const bf16x8 bl = tr_frag<B_P>(sb + fb[j][1]);
 #pragma unroll
                 for (int ii = 0; ii < MI; ++ii) {   // operands swapped: a lane ends up with 4 consecutive columns of one C row
                     acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[ii], acc[ii][j], 0, 0, 0);
@@ -197,8 +247,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_planes_tn_kernel(PTN p) {
         if (m >= M) continue;
         float* crow = (m < ms) ? p.C0[pr] + (int64_t)m * ldc : p.C1[pr] + (int64_t)(m - ms) * ldc;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0t + (wn * 4 + j) * 16 + g * 4;
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0t + (wn * NJ + j) * 16 + g * 4;
             if (n >= N) continue;
             const f32x4 v = acc[i][j] * alpha;
             float* cp = crow + n;
@@ -222,6 +272,31 @@ __global__ __launch_bounds__(64 * NW) void gemm_planes_tn_kernel(PTN p) {
     }   // tiles of this workgroup
 }
 
+template <int BMC, int BNC, int WM, int WN>
+int launch_tn(PTN& p, const int* h_M, const int* h_N, int count, hipStream_t s) {
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        p.gx[i] = cdiv(h_N[i], BNC);
+        p.tile0[i] = tiles;
+        tiles += p.gx[i] * cdiv(h_M[i], BMC);
+    }
+    p.tile0[count] = tiles;
+    p.tiles = tiles;
+    p.per = (tiles + 7) / 8;
+    constexpr int LDS = 2 * 32 * (BMC + BNC) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_tn_kernel<BMC, BNC, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return -1;
+        attr_done = true;
+    }
+    int grid = 8 * p.per;
+    const int cap = aas_wgrad_wg_cap();     // > 0: at most this many workgroups (a multiple of 8), each walking several tiles
+    if (cap > 0 && grid > cap) grid = cap < 8 ? 8 : cap / 8 * 8;
+    hipLaunchKernelGGL((gemm_planes_tn_kernel<BMC, BNC, WM, WN>), dim3(grid), dim3(64 * WM * WN), LDS, s, p);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int aas_gemm_planes_tn(aasStream_t stream, int count, const void* const* h_A, const void* const* h_B, float* const* h_C0,
@@ -236,7 +311,7 @@ extern "C" int aas_gemm_planes_tn(aasStream_t stream, int count, const void* con
     AAS_CHECK(Ns >= 1 && Nb >= Ns, "aas_gemm_planes_tn: bad row map Ns=%d Nb=%d", Ns, Nb);
     PTN p = {};
     p.nprob = count;
-    int tiles = 0;
+    int wide = 1;
     for (int i = 0; i < count; ++i) {
         AAS_CHECK(h_A[i] && h_B[i] && h_C0[i], "aas_gemm_planes_tn: null operand %d", i);
         AAS_CHECK(h_M[i] >= 1 && h_N[i] >= 1 && h_K[i] >= 0 && h_msplit[i] >= 0 && (h_msplit[i] >= h_M[i] || h_C1[i]),
@@ -250,30 +325,20 @@ extern "C" int aas_gemm_planes_tn(aasStream_t stream, int count, const void* con
         p.M[i] = h_M[i]; p.N[i] = h_N[i]; p.K[i] = h_K[i]; p.msplit[i] = h_msplit[i]; p.acol0[i] = h_acol0[i];
         p.n0[i] = h_n0[i]; p.ta[i] = h_ta[i]; p.tb[i] = h_tb[i];
         p.lda[i] = h_lda[i]; p.acols[i] = h_acols[i]; p.ldb[i] = h_ldb[i]; p.bcols[i] = h_bcols[i]; p.ldc[i] = h_ldc[i];
-        p.gx[i] = cdiv(h_N[i], 128);
-        p.tile0[i] = tiles;
-        tiles += p.gx[i] * cdiv(h_M[i], 128);
+        if (h_N[i] < 192 || h_M[i] < 512) wide = 0;          // narrow results keep 128 x 128 tiles
     }
-    p.tile0[count] = tiles;
     p.Ns = Ns; p.Nb = Nb;
     p.zero = (const char*)zero512;
     p.accumulate = accumulate;
     p.flags = aas_debug_flags_value();
-    p.tiles = tiles;
-    p.per = (tiles + 7) / 8;
-    constexpr int LDS = 2 * 2 * 32 * 512;
-    static bool attr_done = false;
-    if (!attr_done) {
-        AAS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_tn_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess &&
-                      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_tn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess,
-                  "aas_gemm_planes_tn: could not raise the dynamic LDS limit");
-        attr_done = true;
-    }
-    int grid = 8 * p.per;
-    const int cap = aas_wgrad_wg_cap();     // > 0: at most this many workgroups (a multiple of 8), each walking several tiles
-    if (cap > 0 && grid > cap) grid = cap < 8 ? 8 : cap / 8 * 8;
-    if (p.flags & 65536) hipLaunchKernelGGL(gemm_planes_tn_kernel<4>, dim3(grid), dim3(256), LDS, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gemm_planes_tn_kernel<8>, dim3(grid), dim3(512), LDS, (hipStream_t)stream, p);
+    // debug bits: 65536 = 128 x 128 tiles with four waves (one per SIMD); 8388608 = 256 x 256 tiles for wide results: 45 % less
+    // CU time per product (64 KB staged per k-step for four times the flops) but a quarter of the workgroups, each living
+    // 0.5 ms - config 2 with a frozen A 16.33 vs 16.40 ms, with a trainable A 19.6 vs 17.7, AM step 7.28 vs 7.15: off
+    int rc;
+    if (p.flags & 65536) rc = launch_tn<128, 128, 2, 2>(p, h_M, h_N, count, (hipStream_t)stream);
+    else if (wide && (p.flags & 8388608)) rc = launch_tn<256, 256, 4, 2>(p, h_M, h_N, count, (hipStream_t)stream);
+    else rc = launch_tn<128, 128, 4, 2>(p, h_M, h_N, count, (hipStream_t)stream);
+    AAS_CHECK(rc == 0, "aas_gemm_planes_tn: could not raise the dynamic LDS limit");
     AAS_LAUNCH_CHECK("aas_gemm_planes_tn");
     return 0;
 }

@@ -19,6 +19,17 @@ def ops():
     return o
 
 
+@pytest.fixture(autouse=True)
+def _reset_debug_flags():
+    """Tests that set A/B bits (aas_set_debug_flags) leave the library as they found it, pass or fail."""
+    yield
+    try:
+        from aas_enhancement_amd import _lib
+        _lib.lib().aas_set_debug_flags(0)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def R(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale)
@@ -315,6 +326,8 @@ def test_gemm_planes_tn_vs_fp64(ops, T, Nb, GH, I, H):
     the middle of a 32-column block, utterance classes with their own device-scalar alpha, K not a multiple of 32, poisoned
     (NaN) rows outside the reduction, accumulate on / off."""
     dev = "cuda"
+    if GH >= 2000:      # the wide case also through the opt-in 256 x 256 tiles (second half of the test body runs on them)
+        ops.lib().aas_set_debug_flags(8388608)      # (reset by the autouse fixture below, also when an assertion fails)
     R_ = T * Nb
     dg = R(R_, 2 * GH, seed=11).to(dev)
     x = R(R_, I, seed=12).to(dev)
@@ -358,6 +371,7 @@ def test_gemm_planes_tn_vs_fp64(ops, T, Nb, GH, I, H):
                              bcols=px.Kp, acol0=0, M=2 * GH, N=I, K=R_, C0=o2.data_ptr(), C1=0, msplit=2 * GH, ldc=I, ta=0, tb=0)],
                        Nb, Nb, torch.device(dev), accumulate=False)
     assert rel_err(o2, dg.double().t() @ x.double()) < 2e-5
+    ops.lib().aas_set_debug_flags(0)
 
 
 def test_split_planes_transposed(ops):
