@@ -205,6 +205,7 @@ def wgrad_stream(dev):
 # flush_deferred_wgrad(): the products are HBM-heavy and, queued beside a latency-bound BPTT chain that is on the step's
 # critical path, they slow its cross-CU exchange (D's BPTT launches at N=60: 0.96 ms alone, up to 1.9 ms beside them).
 DEFER_WGRAD = [False]
+DEFER_LIDS = set()       # layer ids (model.py: _aas_layer_id) whose products are held back even when DEFER_WGRAD is off
 _deferred = []
 
 
@@ -916,7 +917,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         for t_ in (dgx, dgh, dgp, dghp, x, hout) + ((keep["xp"].buf if "xp" in keep else None, keep.get("hx")) if keep else ()):
             if t_ is not None:
                 t_.record_stream(side)
-        if DEFER_WGRAD[0]:
+        if DEFER_WGRAD[0] or lid in DEFER_LIDS:
             _deferred.append(run)      # (the closure keeps the layer's operands alive until it runs)
         else:
             run()

@@ -440,11 +440,22 @@ class Trainer(object):
             # the discriminator's weight-gradient products are held back while the two BPTT chains run (they slow the chains'
             # cross-CU exchange) and released into E's backward phase, where half of the chip has little else to do
             ops.DEFER_WGRAD[0] = os.environ.get("AAS_DEFER_WGRAD", "0") == "1"   # (measured: no gain, 19.0 vs 19.2 ms - kept as a switch)
+            # The weight-gradient products of the layers that are back-propagated FIRST (D's - and a trainable A's - top layers)
+            # are held back until E's backward: beside the two BPTT chains every CU is taken and the products only slow the chains
+            # down, beside E's backward half of the chip is free.  Not all of them: E's backward phase has room for about two D
+            # layers on top of E's own (16.7 -> 16.1 ms with two, 16.2 with three, 16.5 with one).
+            ops.DEFER_LIDS.clear()
+            for net, env, dflt in ((self.D, "AAS_DEFER_D_LAYERS", 2), (self.ASR, "AAS_DEFER_A_LAYERS", 0)):
+                ndef = int(os.environ.get(env, str(dflt)))
+                if ndef > 0:
+                    lids = [m._aas_layer_id for m in net.modules() if getattr(m, "_aas_layer_id", None) is not None]
+                    ops.DEFER_LIDS.update(lids[-ndef:])
             try:
                 l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, None, ctc_meta, None, None, None,
                                                                                 scales=scales)
             finally:
                 ops.DEFER_WGRAD[0] = False
+                ops.DEFER_LIDS.clear()
         else:
             if overlap:
                 acoustic = self._acoustic_branch(enhanced, None, None, None, None, ctc_meta, scale=scales[2])
