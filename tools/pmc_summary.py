@@ -41,10 +41,10 @@ def main():
         kernels[name] = {"FETCH_SIZE_KiB_avg": fa, "WRITE_SIZE_KiB_avg": wa, "dispatches": max(len(f), len(w)),
                          "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
     # launch classes of bench.py's roofline object (ops.Profiler names) -> kernel instances (persistent grids: P x Q x 2 x threads)
-    classes = {"lstm_bwd[N=60,H=500]": "rnn_bwd_rs_kernel<1, 32, 4> grid=65536", "lstm_bwd[N=30,H=500]": "rnn_bwd_rs_kernel<1, 32, 4> grid=65536",
-               "gru_bwd[N=30,H=1000]": "rnn_bwd_rs_kernel<3, 32, 8> grid=65536", "lstm_fwd[N=60,H=500]": "rnn_fwd32_kernel<0, 2, 0> grid=65536",
+    classes = {"lstm_bwd[N=60,H=500]": "rnn_bwd_rs_kernel<1, 32, 4, -1> grid=65536", "lstm_bwd[N=30,H=500]": "rnn_bwd_rs_kernel<1, 32, 4, -1> grid=65536",
+               "gru_bwd[N=30,H=1000]": "rnn_bwd_rs_kernel<3, 32, 8, -1> grid=65536", "lstm_fwd[N=60,H=500]": "rnn_fwd32_kernel<0, 2, 0> grid=65536",
                "lstm_fwd[N=30,H=500]": "rnn_split_kernel<0, 1, 4> grid=65536", "gru_fwd[N=30,H=1000]": "rnn_fwd32_kernel<2, 4, 2> grid=65536",
-               "gemm_planes_wgrad": "gemm_planes_tn_kernel<8>", "gemm_planes": "gemm_planes_kernel<256, 256, 4, 2, true>"}
+               "gemm_planes_wgrad": "gemm_planes_tn_kernel<128, 128, 4, 2>", "gemm_planes": "gemm_planes_kernel<256, 256, 4, 2, true>"}
     by_class = {}
     for cname, kname in classes.items():
         hit = [v for k, v in kernels.items() if k == kname or (kname.split(" grid=")[0] == k.split(" grid=")[0] and cname.startswith(("lstm", "gru")) and len([x for x in kernels if x.split(" grid=")[0] == k.split(" grid=")[0]]) == 1)]
