@@ -333,10 +333,12 @@ extern "C" int aas_gemm_planes_tn(aasStream_t stream, int count, const void* con
     p.flags = aas_debug_flags_value();
     // debug bits: 65536 = 128 x 128 tiles with four waves (one per SIMD); 8388608 = 256 x 256 tiles for wide results: 45 % less
     // CU time per product (64 KB staged per k-step for four times the flops) but a quarter of the workgroups, each living
-    // 0.5 ms - config 2 with a frozen A 16.33 vs 16.40 ms, with a trainable A 19.6 vs 17.7, AM step 7.28 vs 7.15: off
+    // 0.5 ms - config 2 with a frozen A 16.33 vs 16.40 ms, with a trainable A 19.6 vs 17.7, AM step 7.28 vs 7.15: off.
+    // 33554432 = 256 x 128 tiles (a layer = 128 workgroups): frozen A 15.65 vs 15.73, trainable A 18.0 vs 17.5, AM 7.4 vs 7.0: off
     int rc;
     if (p.flags & 65536) rc = launch_tn<128, 128, 2, 2>(p, h_M, h_N, count, (hipStream_t)stream);
     else if (wide && (p.flags & 8388608)) rc = launch_tn<256, 256, 4, 2>(p, h_M, h_N, count, (hipStream_t)stream);
+    else if (wide && (p.flags & 33554432)) rc = launch_tn<256, 128, 4, 2>(p, h_M, h_N, count, (hipStream_t)stream);
     else rc = launch_tn<128, 128, 4, 2>(p, h_M, h_N, count, (hipStream_t)stream);
     AAS_CHECK(rc == 0, "aas_gemm_planes_tn: could not raise the dynamic LDS limit");
     AAS_LAUNCH_CHECK("aas_gemm_planes_tn");
