@@ -56,8 +56,9 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     // p.xcd == 2: 4 sets of (up to 64) workgroups, each spread over the XCD classes s and s + 4 (the 1000-unit GRU: a set is
     // 32 workgroups, a launch beside another chain gets 16 CUs per XCD): set b % 4, slice 2*(b / 8) + (b % 8) / 4.  A partial
     // block then stays in L2 exactly when its ONE consumer sits on the producer's XCD (per-consumer mask from the XCC table).
-    const int xset = p.xcd == 2 ? (int)(blockIdx.x & 3) : (int)(blockIdx.x & 7);
-    const int pslice = p.xcd == 2 ? (int)(2 * (blockIdx.x >> 3) + ((blockIdx.x & 7) >> 2)) : p.xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int xidx = (int)(blockIdx.x >> 3);        // p.xcd == 1: XCD class b % 8 hosts the sets class + 8 j, P workgroups each
+    const int xset = p.xcd == 2 ? (int)(blockIdx.x & 3) : (int)(blockIdx.x & 7) + 8 * (xidx / p.P);
+    const int pslice = p.xcd == 2 ? (int)(2 * (blockIdx.x >> 3) + ((blockIdx.x & 7) >> 2)) : p.xcd ? xidx % p.P : (int)blockIdx.x;
     const int qg = p.xcd ? (xset >> 1) : (int)blockIdx.y;
     const int d = p.xcd ? (xset & 1) : (int)blockIdx.z;
     const int T = p.T, N = p.N, H = p.H, GH = G * H, P = p.P;
@@ -423,7 +424,7 @@ int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
         p.Q = cdiv(rows, rpg);
         // 8 (direction, row group) sets of at most 32 workgroups: XCD-aware grid (debug bit 262144: the plain 3-D grid,
         // 524288: XCD-aware grid but write-through publish stores)
-        p.xcd = (p.flags & 262144) ? 0 : (p.Q * 2 == 8 && p.P <= 32) ? 1 : (p.Q * 2 == 4 && p.P <= 64 && p.P % 2 == 0) ? 2 : 0;
+        p.xcd = (p.flags & 262144) ? 0 : ((p.Q * 2) % 8 == 0 && p.P * (p.Q * 2 / 8) <= 32) ? 1 : (p.Q * 2 == 4 && p.P <= 64 && p.P % 2 == 0) ? 2 : 0;
         const int rc = (U == 32) ? launch_rs<MODE, 32>(p, s) : launch_rs<MODE, 16>(p, s);
         if (rc != 0) return -1;
         AAS_LAUNCH_CHECK(name);

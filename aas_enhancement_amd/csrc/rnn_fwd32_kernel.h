@@ -24,9 +24,11 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
     __shared__ u32x4 bl_lds[LKS ? LKS * NT : 1][LKS ? 512 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pslice = p.xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;        // XCD-aware launch: see rnn_split_kernel.h
-    const int qg = p.xcd ? (int)((blockIdx.x & 7) >> 1) : (int)blockIdx.y;
-    const int d = p.xcd ? (int)(blockIdx.x & 1) : (int)blockIdx.z;
+    const int xidx = (int)(blockIdx.x >> 3);                                     // XCD-aware launch: see rnn_split_kernel.h
+    const int xset = (int)(blockIdx.x & 7) + 8 * (xidx / p.P);
+    const int pslice = p.xcd ? xidx % p.P : (int)blockIdx.x;
+    const int qg = p.xcd ? (xset >> 1) : (int)blockIdx.y;
+    const int d = p.xcd ? (xset & 1) : (int)blockIdx.z;
     const int T = p.T, N = p.N, H = p.H, GH = G * H;
     const int Hp = p.P * U;                              // padded unit pitch of the exchange rows
     const int u0 = pslice * U;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
     bool plain = false;   // plain (L2-resident) publish stores once the set is verified to share an XCD
     if (p.xcd) {
         unsigned* tab = xq + (int64_t)2 * T * N * KC * 32;
-        plain = xcd_set_colocated(tab, (int)(blockIdx.x & 7), pslice, p.P, err, p.tag, &xcd_flag) && !(p.flags & 524288);
+        plain = xcd_set_colocated(tab, xset, pslice, p.P, err, p.tag, &xcd_flag) && !(p.flags & 524288);
     }
 
     // gate-math role: one (row, unit) per thread
@@ -304,7 +306,7 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
         // XCD-aware grid + L2-resident publish stores: only with <= 8 rows per group - in the all-gather every workgroup of a set
         // reads the WHOLE exchanged block, and 16 readers on one L2 lose against 16 readers spread over eight at 16 rows per
         // group (N=60: 3.65 -> 4.13 us / step; N=30 at 8 rows per group: 3.06 -> 2.74)
-        p.xcd = (p.Q * 2 == 8 && p.P <= 32 && rpg <= 8 && !(p.flags & 262144)) ? 1 : 0;
+        p.xcd = ((p.Q * 2) % 8 == 0 && p.P * (p.Q * 2 / 8) <= 32 && rpg <= 8 && !(p.flags & 262144)) ? 1 : 0;
         dim3 grid(p.P, p.Q, 2), block(512);
         if (p.xcd) grid = dim3(p.P * p.Q * 2);
         if constexpr (LSTM) {

@@ -49,7 +49,7 @@ __device__ __forceinline__ void st_sc0_u32(unsigned* p, unsigned v) {
 // LSTM BPTT 3.09 -> 2.65 us / step at N=30 and 4.74 -> 3.49 at N=60, bit-identical results.  Placement is not a contract, so
 // every workgroup publishes its XCC id (write-through) in a table behind the exchange data, reads its set's P entries back and
 // takes the plain-store path only if all agree; otherwise - or if the table read times out - the launch runs exactly as before.
-constexpr int XCD_TAB_BYTES = 8 * 64 * 4;
+constexpr int XCD_TAB_BYTES = 32 * 64 * 4;   // up to 32 sets x 64 slices
 
 // -> bit c set: slice c of this workgroup's set runs on the same XCD as this workgroup (0: unknown - table read timed out)
 __device__ __forceinline__ unsigned long long xcd_peer_mask(unsigned* tab, int set, int pslice, int P, unsigned* err, int tag,
@@ -104,10 +104,13 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     __shared__ float red2[DB ? 2 : 1][4][ROWS][LDR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware launch (p.xcd; forward modes, 8 sets): workgroup b -> set b % 8 = (row group, direction), slice b / 8
-    const int pslice = p.xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int qg = p.xcd ? (int)((blockIdx.x & 7) >> 1) : (int)blockIdx.y;
-    const int d = p.xcd ? (int)(blockIdx.x & 1) : (int)blockIdx.z;
+    // XCD-aware launch (p.xcd; forward modes, 8 m sets): workgroup b -> XCD class b % 8, which hosts the m sets
+    // class + 8 j (j < m) of P workgroups each: set = (row group, direction), slice = (b / 8) % P
+    const int xidx = (int)(blockIdx.x >> 3);
+    const int xset = (int)(blockIdx.x & 7) + 8 * (xidx / p.P);
+    const int pslice = p.xcd ? xidx % p.P : (int)blockIdx.x;
+    const int qg = p.xcd ? (xset >> 1) : (int)blockIdx.y;
+    const int d = p.xcd ? (xset & 1) : (int)blockIdx.z;
     const int T = p.T, N = p.N, H = p.H, GH = G * H;
     const int Hp = p.P * U;                             // padded unit pitch of the exchange arrays
     const int u0 = pslice * U;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     bool plain = false;   // plain (L2-resident) publish stores once the set is verified to share an XCD (xcd_set_colocated)
     if (FWD && p.xcd) {
         unsigned* tab = p.xchg + xrows * KC * 32;          // behind the exchange rows, poisoned by the same memset
-        plain = xcd_set_colocated(tab, (int)(blockIdx.x & 7), pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag) && !(p.flags & 524288);
+        plain = xcd_set_colocated(tab, xset, pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag) && !(p.flags & 524288);
     }
     for (int s = 0; s < T; ++s) {
         unsigned long long st0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull, st1 = st0, st2 = st0, st3 = st0;
@@ -524,7 +527,7 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
         p.Q = cdiv(rows, rpg);
         // poison the exchange arrays (hi | lo): a word is valid data once it is no longer 0xFFFFFFFF (+ the XCC table)
         AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes + XCD_TAB_BYTES, s));
-        p.xcd = (FWD && p.Q * 2 == 8 && p.P <= 32 && rpg <= 8 && !(p.flags & 262144)) ? 1 : 0;   // (see rnn_fwd32_kernel.h)
+        p.xcd = (FWD && (p.Q * 2) % 8 == 0 && p.P * (p.Q * 2 / 8) <= 32 && rpg <= 8 && !(p.flags & 262144)) ? 1 : 0;   // (see rnn_fwd32_kernel.h)
         int rc = (mt == 1) ? launch_split_mt<MODE, 1>(p, ks_need, s) : launch_split_mt<MODE, 2>(p, ks_need, s);
         if (rc != 0) return -1;
         AAS_LAUNCH_CHECK(name);

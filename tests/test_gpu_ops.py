@@ -590,17 +590,19 @@ def test_batchnorm_split_entry_points_and_adam_tick(ops):
     assert float(kt) == pytest.approx(min(1.0, 0.9995 + 0.001 * (0.5 * 8.0 - 3.0))) and o6.tolist() == pytest.approx([3.0, 8.0, 5.0, float(kt), 150.0, 30.0])
 
 
+@pytest.mark.parametrize("half_chip", [True, False])
 @pytest.mark.parametrize("kind,T,N,H", [("lstm", 60, 30, 500), ("lstm", 60, 60, 500), ("gru", 40, 30, 1000), ("lstm", 25, 30, 64)])
-def test_xcd_aware_recurrent_launches_are_bit_identical(ops, kind, T, N, H):
+def test_xcd_aware_recurrent_launches_are_bit_identical(ops, kind, T, N, H, half_chip):
     """The XCD-aware persistent launches (exchange sets dealt to XCD classes; L2-resident publish stores once the XCC-id
     handshake has verified that a set - or a producer / consumer pair - shares an XCD) against the plain 3-D grid with
     write-through stores (debug bit 262144) and the XCD-aware grid with write-through stores (524288): same bits, no timeout.
-    Half-chip grids as in the step (that is where 8 / 4 exchange sets occur); the small layer exercises the ineligible path."""
+    Half-chip grids as in the AAS step (8 / 4 exchange sets) and whole-chip grids (16 sets: two per XCD class); the small layer
+    exercises the ineligible path."""
     from aas_enhancement_amd import _lib
     L = _lib.lib()
     G = 4 if kind == "lstm" else 3
     dev = "cuda"
-    L.aas_set_rnn_cu_limit(ops.device_cus() // 2)
+    L.aas_set_rnn_cu_limit(ops.device_cus() // 2 if half_chip else 0)   # (whole chip: two exchange sets per XCD class)
     try:
         x = R(T, N, H, seed=3, scale=0.5).to(dev)
         w = [(R(G * H, H, seed=4 + i) / H ** 0.5).to(dev) for i in range(4)]
