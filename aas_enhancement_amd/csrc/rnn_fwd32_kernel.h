@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
     bool plain = false;   // plain (L2-resident) publish stores once the set is verified to share an XCD
     if (p.xcd) {
         unsigned* tab = xq + (int64_t)2 * T * N * KC * 32;
-        plain = xcd_set_colocated(tab, xset, pslice, p.P, err, p.tag, &xcd_flag) && !(p.flags & 524288);
+        plain = xcd_set_colocated(tab, xset, pslice, p.P, err, p.tag, &xcd_flag) && !(p.flags & 524288) && p.xcd == 1;
     }
 
     // gate-math role: one (row, unit) per thread
@@ -306,7 +306,9 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
         // XCD-aware grid + L2-resident publish stores: only with <= 8 rows per group - in the all-gather every workgroup of a set
         // reads the WHOLE exchanged block, and 16 readers on one L2 lose against 16 readers spread over eight at 16 rows per
         // group (N=60: 3.65 -> 4.13 us / step; N=30 at 8 rows per group: 3.06 -> 2.74)
-        p.xcd = ((p.Q * 2) % 8 == 0 && p.P * (p.Q * 2 / 8) <= 32 && rpg <= 8 && !(p.flags & 262144)) ? 1 : 0;
+        // (more rows per group: the XCD-aware grid alone, write-through stores - same speed as the plain grid, but a set's block
+        //  crosses the fabric once instead of once per XCD; debug bit 67108864: plain grid there)
+        p.xcd = ((p.Q * 2) % 8 == 0 && p.P * (p.Q * 2 / 8) <= 32 && !(p.flags & 262144)) ? (rpg <= 8 ? 1 : ((p.flags & 67108864) ? 0 : 3)) : 0;
         dim3 grid(p.P, p.Q, 2), block(512);
         if (p.xcd) grid = dim3(p.P * p.Q * 2);
         if constexpr (LSTM) {
