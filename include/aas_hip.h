@@ -40,6 +40,7 @@ int aas_device_cus(void);
  *   3-D grid instead of the XCD-aware tile order in aas_gemm_planes, 16384 the general (any S) CTC kernel even when S <= 64,
  *   262144 the plain 3-D grid in the persistent recurrent launches instead of the XCD-aware one (exchange sets per XCD class,
  *     L2-resident publish stores once a set is verified co-located), 524288 XCD-aware grid but write-through publish stores,
+ *     67108864 plain grid for the forward launches with more than 8 rows per group (default: XCD-aware grid, write-through),
  *   8388608 / 33554432 256x256 / 256x128 tiles for the wide products of aas_gemm_planes_tn (default 128x128),
  *   65536 / 131072 four waves per workgroup (one per SIMD) instead of eight in aas_gemm_planes_tn / the 128x128 aas_gemm_planes,
  *   32768 the 1000-unit GRU BPTT kernel with one (not two) k-steps of lo weight fragments in LDS (the older, spilling variant). */
