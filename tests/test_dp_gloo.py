@@ -55,7 +55,8 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # loopback only: no hostname / interface discovery
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
     try:
         from aas_enhancement_amd.dist import DPContext, FlatBuffers
         dp = DPContext.from_env()
@@ -132,7 +133,8 @@ def _bucket_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # loopback only: no hostname / interface discovery
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
     try:
         from aas_enhancement_amd.dist import BucketReducer, DPContext, FlatBuffers
         dp = DPContext.from_env()
@@ -178,6 +180,7 @@ def test_bucket_reducer_covers_every_element_exactly_once():
 
 def _main_worker(rank, world, port, tmp, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # loopback only: no hostname / interface discovery
     torch.set_num_threads(1)
     import types
     from aas_enhancement_amd import main as M

@@ -51,7 +51,8 @@ def _worker(rank, world, port, q, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["RANK"] = str(rank); os.environ["WORLD_SIZE"] = str(world)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # loopback only: no hostname / interface discovery
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
     try:
         torch.cuda.set_device(0)
         from aas_enhancement_amd.dist import DPContext
@@ -140,7 +141,8 @@ def _am_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["RANK"] = str(rank); os.environ["WORLD_SIZE"] = str(world)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # loopback only: no hostname / interface discovery
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
     try:
         torch.cuda.set_device(0)
         from aas_enhancement_amd.am_train import AMTrainer
