@@ -144,23 +144,6 @@ _SKIP_WGRAD = bool(int(__import__('os').environ.get('AAS_SKIP_WGRAD', '0')))
 _wgrad_streams = {}
 
 
-def _cu_masked_stream(dev, ncus):
-    """A HIP stream whose kernels may only run on the first `ncus` bits of the queue's CU mask (hipExtStreamCreateWithCUMask;
-    the driver deals the mask bits round-robin over the XCDs, so N bits = N/8 CUs of every XCD)."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    words = (device_cus() + 31) // 32
-    mask = (ctypes.c_uint32 * words)()
-    for i in range(min(ncus, 32 * words)):
-        mask[i // 32] |= 1 << (i % 32)
-    h = ctypes.c_void_p()
-    with torch.cuda.device(dev):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
-    if rc != 0:
-        raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
-    return torch.cuda.ExternalStream(h.value, device=dev)
-
-
 _chain_streams = {}
 
 
@@ -185,8 +168,6 @@ def chain_stream(dev=None):
 
 def wgrad_stream(dev):
     s = _wgrad_streams.get(dev)
-    if s is None and int(os.environ.get("AAS_WGRAD_CUS", "0")) > 0:
-        s = _wgrad_streams[dev] = _cu_masked_stream(dev, int(os.environ["AAS_WGRAD_CUS"]))
     if s is None:
         # lowest priority: when a persistent recurrent launch and queued weight-gradient blocks compete for CUs, the
         # recurrent grid (which must become fully resident) is dispatched first
