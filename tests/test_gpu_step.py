@@ -340,6 +340,49 @@ def test_am_trainer_class_golden(gpu):
         assert rel_err(v.double(), z["am.final." + k]) < 2e-3, k
 
 
+def test_am_async_steps_equal_synchronous_steps_and_goldens(gpu):
+    """AMTrainer.train_step_async (no host read-back: device step counter, loss through a pinned ring, read one step late) on
+    the F5 AM vectors - same losses, logits and final weights as the reference; interleaved with synchronous steps the Adam
+    counters stay in step."""
+    from aas_enhancement_amd import prng
+    from aas_enhancement_amd.am_train import AMTrainer
+    from aas_enhancement_amd.model import DeepSpeech
+    z = load("f5_fsegan_am.npz")
+    A = DeepSpeech(nn.GRU, LABELS, 12, 3, True, 11, 2, 8, 2, nFreq=8)
+    load_sd(A, {k: torch.from_numpy(v) for k, v in prng.fill_state_dict(A.state_dict(), 8001, conv_std=0.1).items()}, strict=False)
+    tr = AMTrainer(A.cuda(), lr=1e-3)
+    recs = []
+    for it in range(2):
+        b = make_batch(3, 8, [60, 50, 38], 8100 + it, [4, 3, 2], 8200 + it)
+        recs.append(tr.train_step_async((torch.from_numpy(b["inputs"]), torch.from_numpy(b["targets"]), torch.from_numpy(b["pct"]),
+                                         torch.from_numpy(b["target_sizes"]))))
+    for it, r in enumerate(recs):      # read late: nothing of the update depended on the host seeing the loss
+        loss, is_inf = tr.read_loss(r["handle"])
+        assert not is_inf and loss == pytest.approx(float(z["am.it%d.loss" % it]), rel=REL_LOSS)
+        assert rel_err(r["logits"], z["am.it%d.logits" % it]) < REL_OUT
+    for k, v in A.state_dict().items():
+        if k in NOISE_PARAMS:
+            continue
+        assert rel_err(v.double(), z["am.final." + k]) < 2e-3, k
+    # alternate the two forms on a second model: equal to synchronous steps only
+    outs = []
+    for mode in ("sync", "mixed"):
+        A2 = DeepSpeech(nn.GRU, LABELS, 12, 3, True, 11, 2, 8, 2, nFreq=8)
+        load_sd(A2, {k: torch.from_numpy(v) for k, v in prng.fill_state_dict(A2.state_dict(), 8001, conv_std=0.1).items()}, strict=False)
+        t2 = AMTrainer(A2.cuda(), lr=1e-3)
+        for it in range(4):
+            b = make_batch(3, 8, [60, 50, 38], 8100 + it, [4, 3, 2], 8200 + it)
+            data = (torch.from_numpy(b["inputs"]), torch.from_numpy(b["targets"]), torch.from_numpy(b["pct"]), torch.from_numpy(b["target_sizes"]))
+            if mode == "mixed" and it % 2 == 1:
+                t2.read_loss(t2.train_step_async(data)["handle"])
+            else:
+                t2.train_step(data)
+        outs.append({k: v.detach().clone() for k, v in A2.state_dict().items()})
+    for k in outs[0]:
+        if k not in NOISE_PARAMS:
+            assert rel_err(outs[1][k].double(), outs[0][k].double()) < 1e-4, k      # (bias corrections: device fp32 vs host fp64)
+
+
 def test_round_trip_properties_full_size(gpu):
     """Size-independent properties at BASELINE config-2 sizes: (i) linearity of backward in the upstream
     gradient, (ii) fused and as-executed schedules agree, (iii) the step is deterministic run to run
