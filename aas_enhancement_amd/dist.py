@@ -16,14 +16,39 @@ import torch
 import torch.distributed as dist
 
 
+_HOST_GROUPS = {}   # default-group backend -> a gloo group of all ranks for host-side control traffic (created collectively, once)
+
+
+def _host_group():
+    """A gloo group beside an `nccl` default group: host-side integers (the padded length of a sharded batch) and barriers
+    that may outlast RCCL's watchdog (rank 0 validating for an hour) travel over it, without a device synchronisation and
+    without a pending RCCL collective.  With a gloo default group (CPU tests) the default group itself is used."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    be = dist.get_backend()
+    if be == "gloo":
+        return None
+    if be not in _HOST_GROUPS:
+        import datetime
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        _HOST_GROUPS[be] = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=24))
+    return _HOST_GROUPS[be]
+
+
 class DPContext(object):
     def __init__(self, world=1, rank=0, group=None):
         self.world, self.rank, self.group = int(world), int(rank), group
+        self._host = None
 
     @classmethod
     def from_env(cls):
+        """Collective when a process group exists (the first call creates the host-side gloo group): every rank must call it
+        at the same point - the trainers do, in their constructors / make_optimizers()."""
         if dist.is_available() and dist.is_initialized():
-            return cls(dist.get_world_size(), dist.get_rank())
+            c = cls(dist.get_world_size(), dist.get_rank())
+            if c.world > 1:
+                c._host = _host_group()
+            return c
         return cls(1, 0)
 
     @property
@@ -37,9 +62,30 @@ class DPContext(object):
             return like.device
         return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
 
+    def _host_ready(self):
+        return self._host is not None or dist.get_backend(self.group) == "gloo"
+
     def barrier(self):
-        if self.active:
+        """Host-side barrier.  Over the gloo side group when the data path is RCCL: it has no device work, so it neither
+        trips RCCL's watchdog (default 10 minutes) while rank 0 validates nor orders itself against queued collectives."""
+        if not self.active:
+            return
+        if self._host_ready():
+            dist.barrier(group=self._host if self._host is not None else self.group)
+        else:
             dist.barrier(group=self.group)
+
+    def host_max(self, value):
+        """MAX over ranks of one host integer (the padded length of a sharded batch) without touching the device."""
+        if not self.active:
+            return int(value)
+        if self._host_ready():
+            t = torch.tensor([int(value)], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._host if self._host is not None else self.group)
+            return int(t[0])
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self._dev())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
 
     def global_counts(self, values):
         """SUM over ranks of a short list of integers (N, nElement ...) -> list[int]."""
@@ -80,10 +126,16 @@ class DPContext(object):
         return list(range(self.rank, n, self.world))
 
     def shard_collated(self, data_list):
-        """Shard a `_collate_fn` tuple (inputs, targets, pct, target_sizes, mask) by stride."""
+        """Shard an already collated GLOBAL `_collate_fn` tuple (inputs, targets, pct, target_sizes, mask) by stride - for callers
+        that hold a whole batch (tests, synthetic benchmarks).  The loaders shard BEFORE loading instead
+        (loader_functions.FeatSampler(rank, world) + data_loader.DataLoader(dp=...)): a rank then never opens another rank's files.
+        The number of valid frames comes from the host-side `input_percentages` (no device read-back)."""
         if not self.active:
             return data_list
         inputs, targets, pct, tsz, mask = data_list
+        if inputs.size(0) < self.world:
+            raise ValueError("data parallel: a global batch of %d utterances cannot be sharded over %d ranks (every rank needs at "
+                             "least one row; FeatSampler(world=...) drops such bins identically on every rank)" % (inputs.size(0), self.world))
         rows = self.shard_rows(inputs.size(0))
         idx = torch.tensor(rows, dtype=torch.long)
         offs = [0]
@@ -91,7 +143,13 @@ class DPContext(object):
             offs.append(offs[-1] + int(s))
         tg = torch.cat([targets[offs[r]:offs[r + 1]] for r in rows]) if targets is not None and len(rows) else targets
         m = mask.index_select(0, idx.to(mask.device))
-        m.n_valid = int(m.numel()) - int(m.sum().item())
+        if pct is not None and not pct.is_cuda:
+            # T_i = pct_i * T_max exactly as _collate_fn formed it (lengths / T_max in fp64, rounded to fp32)
+            m.n_valid = int(torch.round(pct.index_select(0, idx).double() * inputs.size(2)).sum().item())
+        elif not mask.is_cuda:
+            m.n_valid = int(m.numel()) - int(m.sum().item())
+        else:
+            m.n_valid = int(m.numel()) - int(m.sum().item())     # (device mask and no host lengths: one read-back)
         return (inputs.index_select(0, idx.to(inputs.device)), tg, pct.index_select(0, idx), tsz.index_select(0, idx), m)
 
 
@@ -101,11 +159,11 @@ class DeviceCounts(object):
     waits for that stream's event.  (global_counts() returns python ints instead and therefore blocks the host until the
     device has caught up - fine for a logging path, not at the top of a training step.)"""
 
-    def __init__(self, dp, values, device, aux_stream, pinned=None):
+    def __init__(self, dp, values, device, aux_stream):
         host = torch.tensor([float(v) for v in values], dtype=torch.float64)
-        if pinned is not None:
-            pinned[:host.numel()].copy_(host)
-            host = pinned[:host.numel()]
+        if not os.environ.get("AAS_NO_PIN"):
+            host = host.pin_memory()     # a fresh pinned buffer per call (a few bytes): the copy below never blocks the host and no
+                                         # later call can overwrite it before it has run
         main = torch.cuda.current_stream()
         aux_stream.wait_stream(main)
         with torch.cuda.stream(aux_stream):

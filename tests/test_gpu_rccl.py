@@ -1,0 +1,195 @@
+"""GPU (-m gpu): the data-parallel code path on RCCL itself.  The test box has ONE GPU and RCCL refuses two ranks on a
+device, so a child process forms a one-rank `nccl` group (AAS_DP_FORCE=1 arms the data-parallel path on it) and runs the
+device-resident steps at CONFIG-2 SIZE - the size at which every recurrent layer's gradient slice is >= 1 Mi elements, so
+dist.BucketReducer's per-layer buckets really fire from the weight-gradient stream (the tiny models of test_gpu_dp.py only
+ever reach flush()).  Checked: the F3 goldens of the reference (iterations 0 and 1, A trainable from iteration 1), every
+element of every flat gradient buffer all-reduced EXACTLY once per step (the collectives are recorded by wrapping
+DPContext.allreduce_sum_; with one rank SUM is the identity, so only the record can show a double or a missed reduction),
+layer buckets among them, and the sticky exchange-timeout word clear (RCCL's kernels share the chip with the persistent
+grids).  bench.py's own launcher is exercised too: `--gpus 2` on this one-GPU box must fail fast with a clear message."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _record_allreduces(dp, flats):
+    """Wrap dp.allreduce_sum_: per call append (flat name, lo, hi) of the reduced range."""
+    log = []
+    inner = dp.allreduce_sum_
+
+    def wrapped(tensor, async_op=False):
+        for name, f in flats.items():
+            off = (tensor.data_ptr() - f.flat_g.data_ptr()) // 4
+            if 0 <= off < f.flat_g.numel():
+                log.append((name, int(off), int(off + tensor.numel())))
+                break
+        else:
+            log.append(("?", 0, int(tensor.numel())))
+        return inner(tensor, async_op=async_op)
+    dp.allreduce_sum_ = wrapped
+    return log
+
+
+def _coverage(log, flats, names):
+    """-> {name: (covered exactly once?, number of ranges >= 1 Mi elements that are not the whole buffer)}"""
+    out = {}
+    for name in names:
+        n = flats[name].flat_g.numel()
+        cnt = np.zeros(n, dtype=np.int32)
+        big = 0
+        for nm, lo, hi in log:
+            if nm == name:
+                cnt[lo:hi] += 1
+                big += int(hi - lo >= (1 << 20) and hi - lo < n)
+        out[name] = (bool((cnt == 1).all()), big, int(cnt.min()), int(cnt.max()))
+    return out
+
+
+def _aas_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", AAS_DP_FORCE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from aas_enhancement_amd import ops
+        from aas_enhancement_amd.trainer_AAS import Trainer
+        from tests.helpers import load
+        from tests.test_gpu_round2 import _config2_batches, _config2_models
+        from tests.test_gpu_step import cfg
+        z = load("f3_aas_config2.npz")
+        tr = Trainer(cfg(lr=float(z["lr"]), nFeat=80, rnn_size=500, allow_ASR_update_iter=0), None, models=_config2_models())
+        tr.kt = float(z["kt0"])
+        tr.make_optimizers()
+        assert tr.dp.active and tr._reducer is not None and dist.get_backend() == "nccl"
+        log = _record_allreduces(tr.dp, tr._flat)
+        res = []
+        for it in range(2):
+            del log[:]
+            ny, cl = _config2_batches(it)
+            r = tr.train_step_async(ny, cl, it)
+            sc = tr.read_scalars()
+            names = ["G", "D"] + (["A"] if it > 0 else [])
+            cov = _coverage(log, tr._flat, names)
+            enh, prob = r["enhanced"].detach().reshape(-1), r["prob"].detach().reshape(-1)
+            e_got = enh[torch.from_numpy(z["it%d.enh_idx" % it]).cuda()].cpu().numpy()
+            p_got = prob[torch.from_numpy(z["it%d.logit_idx" % it]).cuda()].cpu().numpy()
+            res.append(dict(sc=sc, cov=cov, e=e_got, p=p_got, unknown=[e for e in log if e[0] == "?"]))
+        q.put(dict(ok=True, res=res, timeout=ops.rnn_timeout_flag()))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(dict(ok=False, err=traceback.format_exc() + repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_child(target):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=target, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=900)
+    p.join(timeout=120)
+    assert out["ok"], out.get("err")
+    assert p.exitcode == 0
+    return out
+
+
+def test_aas_async_steps_on_one_rank_rccl_config2_buckets_and_goldens():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tests.helpers import load
+    z = load("f3_aas_config2.npz")
+    out = _run_child(_aas_worker)
+    assert not out["timeout"], "a persistent recurrent launch timed out beside the RCCL kernels"
+    for it, r in enumerate(out["res"]):
+        for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt", "conv_measure"):
+            assert r["sc"][k] == pytest.approx(float(z["it%d.%s" % (it, k)]), rel=1e-2), (it, k)
+        e_ref, p_ref = z["it%d.enh_samples" % it], z["it%d.logit_samples" % it]
+        assert np.abs(r["e"] - e_ref).max() < 1e-3 * np.abs(e_ref).max(), it
+        assert np.abs(r["p"] - p_ref).max() < 1e-3 * np.abs(p_ref).max(), it
+        assert not r["unknown"], r["unknown"]
+        for name, (once, big, lo, hi) in r["cov"].items():
+            assert once, "iteration %d: flat gradient buffer %s reduced between %d and %d times per element" % (it, name, lo, hi)
+            # 4 recurrent layers in E / D (one of E's is left to the flush by design), 5 in A: the per-layer buckets fired
+            assert big >= (3 if name != "A" else 4), (it, name, big)
+
+
+def _am_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", AAS_DP_FORCE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import torch.nn as nn
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from aas_enhancement_amd import ops, prng
+        from aas_enhancement_amd.am_train import AMTrainer
+        from aas_enhancement_amd.model import DeepSpeech
+        from tests.helpers import LABELS, load
+        from tests.test_gpu_round2 import _fill
+        z = load("f7_am_config5.npz")
+        N, F, T, HA, M, L = [int(z[k]) for k in ("N", "F", "T", "HA", "M", "L")]
+        A = _fill(DeepSpeech(nn.GRU, LABELS, HA, 5, True, 11, 2, M, 2, nFreq=F), int(z["weight_seed"]), 0.1).cuda()
+        tr = AMTrainer(A, lr=float(z["lr"]))
+        assert tr.dp.active and tr._reducer is not None
+        flats = {"A": tr.flat}
+        log = _record_allreduces(tr.dp, flats)
+        res = []
+        for it in range(2):
+            del log[:]
+            x = torch.from_numpy(prng.uniform(int(z["input_seed0"]) + it, (N, F, T), 0.0, 6.0))
+            tg = torch.from_numpy(prng.randint(int(z["label_seed0"]) + it, (N * L,), 1, 28).astype(np.int32))
+            r = tr.train_step_async((x, tg, torch.ones(N), torch.full((N,), L, dtype=torch.int32)))
+            loss, is_inf = tr.read_loss(r["handle"])
+            lg = r["logits"].detach().reshape(-1)
+            got = lg[torch.from_numpy(z["it%d.logit_idx" % it]).cuda()].cpu().numpy()
+            res.append(dict(loss=loss, cov=_coverage(log, flats, ["A"]), p=got))
+        q.put(dict(ok=True, res=res, timeout=ops.rnn_timeout_flag()))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(dict(ok=False, err=traceback.format_exc() + repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_am_async_steps_on_one_rank_rccl_config5_buckets_and_goldens():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tests.helpers import load
+    z = load("f7_am_config5.npz")
+    out = _run_child(_am_worker)
+    assert not out["timeout"]
+    for it, r in enumerate(out["res"]):
+        assert r["loss"] == pytest.approx(float(z["it%d.loss" % it]), rel=1e-2)
+        ref = z["it%d.logit_samples" % it]
+        assert np.abs(r["p"] - ref).max() < 1e-3 * np.abs(ref).max(), it
+        once, big, lo, hi = r["cov"]["A"]
+        assert once, (it, lo, hi)
+        assert big >= 4, (it, big)
+
+
+def test_bench_gpus_2_on_a_one_gpu_box_fails_fast_with_a_clear_message():
+    """`python bench.py --gpus N` starts its own N ranks (no launcher needed); with fewer devices than ranks it must say so
+    and exit non-zero before anything touches the GPU - not hang, not exit 0."""
+    have = torch.cuda.device_count()
+    if have >= 2:
+        pytest.skip("box has %d GPUs" % have)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert cp.returncode != 0
+    assert "only %d device" % have in cp.stderr
+    assert cp.stdout.strip() == ""
