@@ -72,6 +72,7 @@ SIGNATURES = {
     "aas_greedy_decode": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "aas_edit_distance": [c_vp, c_int, c_vp, c_int],
     "aas_adam_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_f32],
+    "aas_sgd_nesterov_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32],
     "aas_adam_dev_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_int, c_f32],
     "aas_adam_tick": [c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_vp],
     "aas_began_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double],

@@ -24,17 +24,22 @@ from .ctc import CTCLoss
 from .decoder import GreedyDecoder
 from .dist import BucketReducer, DeviceCounts, DPContext, FlatBuffers
 from .model import DeepSpeech, supported_rnns
-from .optim import FlatAdam
+from .optim import FlatAdam, FlatSGD
 from .utils import AverageMeter, _get_variable_nograd
 
 
 class AMTrainer(object):
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), dp=None, labels=None, sync_bn=False):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), dp=None, labels=None, sync_bn=False, optim="adam", momentum=0.9):
         self.model = model
         self.criterion = CTCLoss()
         ops.name_layers(model, "A")
         self.flat = FlatBuffers(model)
-        self.opt = FlatAdam(self.flat, lr=lr, betas=betas, amsgrad=False)
+        if optim == "adam":      # train.py:171-172,246-247
+            self.opt = FlatAdam(self.flat, lr=lr, betas=betas, amsgrad=False)
+        elif optim == "sgd":     # train.py:173-174,248-249: SGD(momentum, nesterov=True)
+            self.opt = FlatSGD(self.flat, lr=lr, momentum=momentum)
+        else:
+            raise ValueError("optim must be 'adam' or 'sgd', got %r" % (optim,))
         self.dp = dp or DPContext.from_env()
         self._reducer = BucketReducer(self.dp, [self.flat]) if self.dp.active else None
         # data parallel: BatchNorm statistics over the GLOBAL batch (default: local-batch statistics per rank)
@@ -175,9 +180,11 @@ class AMTrainer(object):
 
     # ---- epoch loop (:293-486) ---------------------------------------------------------------------------------
     def fit(self, train_batches, val_batches, epochs, save_path=None, best_path=None, start_epoch=0, print_every=100,
-            on_epoch_end=None, history=None):
+            on_epoch_end=None, history=None, presharded=False):
         """`train_batches(epoch)` / `val_batches()` return iterables of batch tuples.  Writes the running package to
-        `save_path` after every epoch and the best-validation-WER package to `best_path`.  Returns the history dict."""
+        `save_path` after every epoch and the best-validation-WER package to `best_path`.  Returns the history dict.
+        Data parallel: `presharded` says the batches are already this rank's shard (DataLoader(dp=...)); otherwise every rank
+        is handed the global batch and keeps its strided share."""
         hist = history or dict(loss_results=[], wer_results=[], cer_results=[])
         best_wer = min(hist["wer_results"]) if hist["wer_results"] else None
         rank0 = self.dp.rank == 0
@@ -187,7 +194,7 @@ class AMTrainer(object):
             avg_loss, n_batches, end = 0.0, 0, time.time()
             prev = None
             for i, data in enumerate(train_batches(epoch)):
-                if self.dp.active:
+                if self.dp.active and not presharded:
                     data = self.dp.shard_collated(tuple(data[:4]) + ((data[4],) if len(data) > 4 else (torch.zeros(data[0].size(0), 1, data[0].size(2), dtype=torch.uint8),)))
                 # the loss of step i is read after step i+1 has been queued: the host stays one step ahead of the device
                 cur = (self.train_step_async(data), data[0].size(0), i)
@@ -230,11 +237,11 @@ class AMTrainer(object):
         return avg_loss + loss_value, time.time()
 
     @classmethod
-    def resume(cls, path, lr=1e-4, gpu=0, dp=None):
+    def resume(cls, path, lr=1e-4, gpu=0, dp=None, labels=None, sync_bn=False, optim="adam", momentum=0.9):
         """`--continue_from` (:163-185): model + optimiser state + history from a package; -> (trainer, start_epoch, history)."""
         package = torch.load(path, map_location=lambda storage, loc: storage)
         model = DeepSpeech.load_model_package(package, gpu=gpu)
-        tr = cls(model, lr=lr, dp=dp)
+        tr = cls(model, lr=lr, dp=dp, labels=labels, sync_bn=sync_bn, optim=optim, momentum=momentum)
         if package.get("optim_dict") is not None:
             tr.opt.load_state_dict(package["optim_dict"])
         start_epoch = int(package.get("epoch", 1)) - 1
@@ -307,7 +314,10 @@ def main(argv=None):
     ap.add_argument("--DB_name", default="librispeech")
     ap.add_argument("--expnum", default=0, type=int)
     ap.add_argument("--preprocess", default="file", help="file: LMFB .pt7 tensors | code: waveforms + the LMFB HIP kernel")
-    ap.add_argument("--no_sortagrad", dest="sortagrad", action="store_false")
+    ap.add_argument("--sortagrad", default=False, type=lambda v: str(v).lower() in ("true", "1"),
+                    help="first epoch in manifest (increasing length) order, no reshuffling afterwards (train.py:109,270-272,484-486)")
+    ap.add_argument("--optim", default="adam", help="adam|sgd (sgd: momentum, nesterov; train.py:171-174)")
+    ap.add_argument("--momentum", default=0.9, type=float)
     ap.add_argument("--seed", default=123456, type=int)
     ap.add_argument("--dist_backend", default="nccl")
     ap.add_argument("--sync_bn", action="store_true", help="data parallel: all-reduce the BatchNorm statistics (global-batch BN)")
@@ -324,23 +334,29 @@ def main(argv=None):
     from .data_loader import DataLoader
     with open(a.labels_path) as f:
         labels = str("".join(json.load(f)))
+    dp = DPContext.from_env()
     dl = DataLoader(batch_size=a.batch_size, tr_ny_manifest=a.train_manifest, val_manifest=a.val_manifest, labels=labels,
-                    num_workers=a.num_workers, pin_memory=True, preprocess=a.preprocess, n_mels=a.nFreq)
+                    num_workers=a.num_workers, pin_memory=True, preprocess=a.preprocess, n_mels=a.nFreq, dp=dp)
     os.makedirs(a.save_folder, exist_ok=True)
     if a.continue_from:
-        tr, start_epoch, hist = AMTrainer.resume(a.continue_from, lr=a.lr, gpu=a.gpu)
+        tr, start_epoch, hist = AMTrainer.resume(a.continue_from, lr=a.lr, gpu=a.gpu, dp=dp, labels=labels, sync_bn=a.sync_bn, optim=a.optim,
+                                                 momentum=a.momentum)
     else:
         model = DeepSpeech(rnn_hidden_size=a.rnn_size, rnn_layers=a.rnn_layers, rnn_type=supported_rnns[a.rnn_type.lower()], labels=labels,
                            kernel_sz=a.conv_kernel, stride=a.conv_stride, map=a.conv_map, cnn_layers=a.conv_layers, nFreq=a.nFreq)
         weights_init(model)
-        tr, start_epoch, hist = AMTrainer(model.cuda(), lr=a.lr, labels=labels, sync_bn=a.sync_bn), 0, None
-    n_train = (len(dl._ds["ny/train"]) + a.batch_size - 1) // a.batch_size
+        tr, start_epoch, hist = AMTrainer(model.cuda(), lr=a.lr, dp=dp, labels=labels, sync_bn=a.sync_bn, optim=a.optim, momentum=a.momentum), 0, None
+    # batch order (train.py:270-272,484-486): sortagrad keeps the manifest (increasing length) order for the first epoch and never
+    # reshuffles; otherwise the bins are shuffled before the first epoch and after every epoch.  The loader builds its iterators
+    # lazily, so this shuffle happens before any batch has been drawn.
+    dl.reshuffle = not a.sortagrad
     if not (a.sortagrad and start_epoch == 0):
         dl._sp["ny/train"].shuffle()
+    n_train = len(dl._sp["ny/train"])
     train_batches = lambda epoch: (dl.next("ny", "train") for _ in range(n_train))
     val_batches = lambda: (dl.next("ny", "val") for _ in range(dl.num_batches("val")))
     tr.fit(train_batches, val_batches, a.epochs, save_path="%s/%s_%d.pth.tar" % (a.save_folder, a.DB_name, a.expnum), best_path=a.model_path,
-           start_epoch=start_epoch, print_every=a.print_every, history=hist)
+           start_epoch=start_epoch, print_every=a.print_every, history=hist, presharded=dp.active)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

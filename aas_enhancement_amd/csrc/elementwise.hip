@@ -141,6 +141,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// torch.optim.SGD(momentum, nesterov=True, dampening 0): buf = mu buf + g (buf starts at zero, which gives the first step's
+// "buf = g" exactly); p -= lr (g + mu buf)
+__global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                           int64_t n, float lr, float mu, float gscale) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const float gi = g[i] * gscale;
+        const float b = mu * buf[i] + gi;
+        buf[i] = b;
+        p[i] -= lr * (gi + mu * b);
+    }
+}
+
 // dx[n,t,f] = sum_kk dcol[n, (t-kk)/s, kk, f]
 __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int N,
                                                      int T, int T1, int F, int KW, int s) {
@@ -297,6 +311,15 @@ extern "C" int aas_adam_f32(aasStream_t stream, float* p, const float* g, float*
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n, beta1,
                        beta2, eps, step_size, bc2_sqrt, amsgrad, grad_scale, (const float*)nullptr);
     AAS_LAUNCH_CHECK("aas_adam_f32");
+    return 0;
+}
+
+extern "C" int aas_sgd_nesterov_f32(aasStream_t stream, float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                                    float grad_scale) {
+    AAS_CHECK(p && g && buf && n >= 0, "aas_sgd_nesterov_f32: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum, grad_scale);
+    AAS_LAUNCH_CHECK("aas_sgd_nesterov_f32");
     return 0;
 }
 

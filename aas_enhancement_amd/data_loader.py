@@ -8,6 +8,10 @@
 * `preprocess="code"` (AM_training/train.py:59 `--preprocess file|code`): manifests list 16 kHz waveform tensors
   instead of precomputed LMFB `.pt7` files; the log-Mel features are extracted on the device by the LMFB HIP kernel
   (aas_enhancement_amd/lmfb.py), per utterance length, on the copy stream - also one batch ahead.
+* `dp=DPContext` (data parallel): the TRAINING sets are sharded BEFORE loading (FeatSampler(rank, world)): a rank opens only its
+  own utterances of each global bin.  Its shard is then padded to the GLOBAL maximum length (one host integer, MAX-all-reduced
+  over the gloo side group - no device synchronisation) and `input_percentages` re-expressed against it, so the un-masked L1
+  sums and A's output lengths equal the single-process ones.  Validation sets are not sharded (rank 0 validates).
 """
 import torch
 
@@ -18,9 +22,10 @@ from .loader_functions import FeatDataset, FeatLoader, FeatLoader_paired, FeatSa
 class DataLoader():
     def __init__(self, batch_size, paired=False, tr_cl_manifest="", tr_ny_manifest="", trsub_manifest="",
                  val_manifest="", val2_manifest="", labels=None, num_workers=1, pin_memory=False, preprocess="file",
-                 device=None, n_mels=80):
+                 device=None, n_mels=80, dp=None):
         self.batch_size, self.labels, self.num_workers = batch_size, labels, num_workers
         self.paired, self.preprocess = paired, preprocess
+        self.dp = dp if (dp is not None and dp.active) else None
         if preprocess not in ("file", "code"):
             raise ValueError("preprocess must be 'file' or 'code', got %r" % (preprocess,))
         self.pin = bool(pin_memory) and torch.cuda.is_available()
@@ -44,8 +49,10 @@ class DataLoader():
             if len(manifest) > 0:
                 self._ds[key] = FeatDataset(manifest=manifest, labels=labels)
                 if sampled:
-                    self._sp[key] = FeatSampler(self._ds[key], batch_size=batch_size)
-                self._it[key] = self._make(key)
+                    self._sp[key] = FeatSampler(self._ds[key], batch_size=batch_size, **(dict(rank=self.dp.rank, world=self.dp.world) if self.dp else {}))
+        # iterators are created on first use: a caller may still reorder a sampler's bins (am_train: --sortagrad / shuffle before
+        # the first epoch) - a torch DataLoader iterator with workers prefetches its first bins the moment it exists
+        self.reshuffle = True     # reshuffle the training bins whenever a training set wraps around (data_loader.py:42-83)
 
     def _make(self, key):
         kw = dict(num_workers=self.num_workers, pin_memory=self.pin)
@@ -61,13 +68,44 @@ class DataLoader():
 
     # ---- host side: the reference's semantics (data_loader.py:42-83) ---------------------------------------------
     def _next_host(self, key):
+        if key not in self._it:
+            if key not in self._ds:
+                raise KeyError("no manifest was given for %r" % (key,))
+            self._it[key] = self._make(key)
         try:
-            return next(self._it[key])
+            batch = next(self._it[key])
         except StopIteration:
-            if key in self._sp:
+            if key in self._sp and self.reshuffle:
                 self._sp[key].shuffle()       # training sets: reshuffle the batch order, then restart
             self._it[key] = self._make(key)
-            return next(self._it[key])
+            batch = next(self._it[key])
+        if self.dp is not None and key in self._sp:
+            batch = self._pad_to_global(batch)
+        return batch
+
+    def _pad_to_global(self, batch):
+        """This rank's shard -> padded to the global batch's longest utterance (the padding the single-process collate would
+        have produced), `input_percentages` = T_i / T_global.  One host-side MAX all-reduce of one integer per batch."""
+        if self.preprocess == "code":
+            waves = batch[0]
+            s_glob = self.dp.host_max(waves.size(1))
+            if s_glob > waves.size(1):
+                pad = lambda w: torch.nn.functional.pad(w, (0, s_glob - w.size(1)))
+                batch = (pad(waves),) + tuple(batch[1:4]) + ((pad(batch[4]),) if self.paired else ())
+            return batch
+        big = [i for i, t in enumerate(batch) if torch.is_tensor(t) and t.dim() == 3]       # inputs [, outputs], mask
+        pct_i = 4 if self.paired else 2
+        t_loc = batch[big[0]].size(2)
+        t_glob = self.dp.host_max(t_loc)
+        if t_glob == t_loc:
+            return batch
+        out = list(batch)
+        lengths = torch.round(batch[pct_i].double() * t_loc)
+        for i in big:
+            t = batch[i]
+            out[i] = torch.nn.functional.pad(t, (0, t_glob - t_loc), value=1 if t.dtype == torch.uint8 else 0)   # mask: 1 = padding
+        out[pct_i] = (lengths / float(t_glob)).float()
+        return tuple(out)
 
     # ---- device side: one batch ahead on the copy stream ---------------------------------------------------------
     def _to_device(self, batch):

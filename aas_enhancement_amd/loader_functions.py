@@ -117,20 +117,41 @@ class FeatLoader_paired(DataLoader):
 
 
 class FeatSampler(Sampler):
-    """Batches of consecutive (length-sorted) manifest entries; batch order shuffled per epoch."""
+    """Batches of consecutive (length-sorted) manifest entries; batch order shuffled per epoch (loader_functions.py:118-137).
 
-    def __init__(self, data_source, batch_size=1):
+    Data parallel (`world` > 1; new in this build): the sampler still walks the GLOBAL bins, in the same order and with the
+    same random draws on every rank (same numpy seed), but hands this rank only ITS utterances of each bin - so a rank opens,
+    collates, copies and (`--preprocess code`) LMFB-extracts its own shard and nothing else.  The partition: the bin's ids in
+    descending manifest order (manifests are sorted by length, so this is the longest-first order `_collate_fn` produces),
+    rank r takes positions r, r + W, ...: lengths are balanced across ranks and the union over ranks, re-interleaved, is the
+    single-process batch.  Bins with fewer utterances than ranks (the tail bin) are dropped, identically on every rank: every
+    rank needs at least one row, and all ranks must issue the same collectives."""
+
+    def __init__(self, data_source, batch_size=1, rank=0, world=1):
         self.data_source = data_source
+        self.rank, self.world = int(rank), int(world)
         ids = list(range(0, len(data_source)))
         self.bins = [ids[i:i + batch_size] for i in range(0, len(ids), batch_size)]
+        self.log = None       # tests: a list that receives (global ids of the bin, this rank's ids) per batch
+
+    def shard(self, ids):
+        return sorted(ids, reverse=True)[self.rank::self.world]
+
+    def _usable(self, ids):
+        return self.world == 1 or len(ids) >= self.world
 
     def __iter__(self):
         for ids in self.bins:
-            np.random.shuffle(ids)
-            yield ids
+            np.random.shuffle(ids)       # (every rank draws the same permutation, whether or not it keeps the bin)
+            if not self._usable(ids):
+                continue
+            mine = ids if self.world == 1 else self.shard(ids)
+            if self.log is not None:
+                self.log.append((list(ids), list(mine)))
+            yield mine
 
     def __len__(self):
-        return len(self.bins)
+        return sum(1 for ids in self.bins if self._usable(ids))
 
     def shuffle(self):
         np.random.shuffle(self.bins)

@@ -31,9 +31,6 @@ def main(config):
     # one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE come from the launcher's environment.  Every rank reads the same
     # manifests with the same seed, so all ranks draw the same global minibatch and keep their strided shard of it.
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and config.trainer not in ("AAS", "acoustic_supervision"):
-        raise NotImplementedError("data parallel training is implemented for --trainer AAS / acoustic_supervision (and am_train); "
-                                  "%r would train the full batch on every rank" % config.trainer)
     if world > 1:
         import torch.distributed as dist
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -62,10 +59,12 @@ def main(config):
         config.tr_cl_manifest = "data/chime_tr_org.csv"
     with open(config.labels_path) as label_file:
         labels = str("".join(json.load(label_file)))
+    from .dist import DPContext
+    dp = DPContext.from_env()       # (collective when world > 1: also creates the host-side gloo group)
     data_loader = DataLoader(batch_size=config.batch_size, paired=paired, tr_cl_manifest=config.tr_cl_manifest,
                              tr_ny_manifest=config.tr_ny_manifest, trsub_manifest=config.trsub_manifest,
                              val_manifest=config.val_manifest, val2_manifest=config.val2_manifest, labels=labels,
-                             pin_memory=config.gpu >= 0, preprocess=config.preprocess)
+                             pin_memory=config.gpu >= 0, preprocess=config.preprocess, dp=dp)
     os.makedirs("logs/" + str(config.expnum), exist_ok=True)
     trainer = Trainer(config, data_loader)
     torch.manual_seed(config.random_seed)

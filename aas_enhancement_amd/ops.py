@@ -1207,3 +1207,8 @@ def began_step(l_ny, l_cl, l_ctc, d_kt, d_out6, gamma, lambda_k, n_batch):
 def adam_step(p, g, m, v, vmax, lr, beta1, beta2, eps, step, amsgrad=True, grad_scale=1.0):
     check(lib().aas_adam_f32(stream(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), float(lr), float(beta1),
                              float(beta2), float(eps), int(step), int(amsgrad), float(grad_scale)), "aas_adam_f32")
+
+
+def sgd_nesterov_step(p, g, buf, lr, momentum, grad_scale=1.0):
+    check(lib().aas_sgd_nesterov_f32(stream(), ptr(p), ptr(g), ptr(buf), p.numel(), float(lr), float(momentum), float(grad_scale)),
+          "aas_sgd_nesterov_f32")

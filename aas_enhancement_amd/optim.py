@@ -96,3 +96,43 @@ class FlatAdam(object):
                           self.eps, self._hyper, self.amsgrad, grad_scale)
         self.step_count += 1
         self.flat.version += 1
+
+
+class FlatSGD(object):
+    """torch.optim.SGD(lr, momentum, nesterov=True) over a FlatBuffers pair (AM_training/train.py:172-174,247-249, `--optim sgd`):
+    one fused HIP launch per step.  The update has no step-dependent scalar, so `step` and `step_dev` are the same launch."""
+
+    def __init__(self, flat, lr=1e-3, momentum=0.9):
+        self.flat, self.lr, self.momentum = flat, lr, momentum
+        self.step_count = 0
+        self.buf = torch.zeros_like(flat.flat_p)
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0):
+        ops.sgd_nesterov_step(self.flat.flat_p, self.flat.flat_g, self.buf, self.lr, self.momentum, grad_scale)
+        self.step_count += 1
+        self.flat.version += 1
+
+    step_dev = step
+
+    # ---- torch.optim.SGD-shaped state (the `optim_dict` of a DeepSpeech package) -------
+    def state_dict(self):
+        state = {}
+        if self.step_count > 0:
+            for i, (p, (off, n)) in enumerate(zip(self.flat.params, self.flat.slices)):
+                state[i] = {"momentum_buffer": self.buf[off:off + n].view_as(p).clone()}
+        group = dict(lr=self.lr, momentum=self.momentum, dampening=0, weight_decay=0, nesterov=True, params=list(range(len(self.flat.params))))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        for i, (off, n) in enumerate(self.flat.slices):
+            st = sd["state"].get(i)
+            if st is not None and st.get("momentum_buffer") is not None:
+                self.buf[off:off + n].copy_(st["momentum_buffer"].reshape(-1))
+                self.step_count = max(self.step_count, 1)
+        if sd.get("param_groups"):
+            self.lr = sd["param_groups"][0].get("lr", self.lr)
+            self.momentum = sd["param_groups"][0].get("momentum", self.momentum)

@@ -384,6 +384,9 @@ class Trainer(object):
             if dp.active:
                 self._reducer.flush(self._flat["G"])
                 self._reducer.wait()
+        except BaseException:
+            self._early_adam = False
+            raise
         finally:
             ops.WGRAD_HOOK[0] = None
         optimizer_g.step_dev()
@@ -477,11 +480,13 @@ class Trainer(object):
             self._reducer.flush(self._flat["D"])
             if asr_steps:
                 self._reducer.flush(self._flat["A"])
-        elif os.environ.get("AAS_EARLY_ADAM", "1") == "1" and not torch.cuda.is_current_stream_capturing():
+        elif (os.environ.get("AAS_EARLY_ADAM", "1") == "1" and not torch.cuda.is_current_stream_capturing()
+              and ops.DIRECT_WGRAD[0] and ops.LINEAR_DIRECT[0]):
             # D's (and a trainable A's) gradients are complete once the products queued on the weight-gradient stream have run:
             # their Adam steps and weight-plane refreshes go onto that stream now and overlap E's backward instead of
             # following it (every parameter gradient of D is produced on that stream; A's BatchNorm / conv / fc ones on `side`)
             wg = ops.wgrad_stream(leaf.device)
+            wg.wait_stream(torch.cuda.current_stream())   # (cheap insurance: any gradient autograd accumulated on this stream)
             if asr_steps:
                 wg.wait_stream(self._side)
             with torch.cuda.stream(wg):
@@ -869,11 +874,12 @@ class Trainer(object):
         return prob, l_CTC, leaf_a
 
     def _next_pair(self):
-        """Next (noisy, clean) training batches; data parallel: every rank draws the same global batch (same seed, same
-        sampler state) and keeps its strided shard of the length-sorted utterances (dist.DPContext.shard_collated)."""
+        """Next (noisy, clean) training batches; data parallel: the loader shards BEFORE loading (DataLoader(dp=...): every rank
+        walks the same global bins with the same seed and opens only its strided share of the length-sorted utterances)."""
         data_list = self.data_loader.next(cl_ny="ny", type="train")
         data_list_cl = self.data_loader.next(cl_ny="cl", type="train")
-        if self.dp.active:
+        if self.dp.active and getattr(self.data_loader, "dp", None) is None:
+            # a loader that is not data-parallel aware hands out the global batch: shard it here (every rank loaded all of it)
             data_list, data_list_cl = self.dp.shard_collated(data_list), self.dp.shard_collated(data_list_cl)
         return data_list, data_list_cl
 
@@ -908,9 +914,15 @@ class Trainer(object):
                 if getattr(self, "_kt_dev_live", False):
                     self.read_scalars()
                 if rank0:   # every rank holds identical parameters: rank 0 validates and writes the checkpoints
-                    self.validate_and_checkpoint(iter)
+                    # A stays in train mode during validation (as in the reference), so with --sync_bn its BatchNorm would
+                    # issue all-reduces that no other rank matches: rank-0-only validation uses local statistics
+                    armed, ops.SYNC_BN[0] = ops.SYNC_BN[0], None
+                    try:
+                        self.validate_and_checkpoint(iter)
+                    finally:
+                        ops.SYNC_BN[0] = armed
                 if self.dp.active:
-                    self.dp.barrier()
+                    self.dp.barrier()   # host-side (gloo side group): no pending RCCL work while rank 0 validates, however long
 
     # ---- validation + checkpoint lifecycle (:215-297) -----------------------------------------
     def validate_and_checkpoint(self, iter):

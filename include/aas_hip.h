@@ -290,6 +290,11 @@ int aas_edit_distance(const int* h_a, int na, const int* h_b, int nb);
 int aas_adam_f32(aasStream_t stream, float* p, const float* g, float* m, float* v, float* vmax,
                  int64_t n, float lr, float beta1, float beta2, float eps, int step, int amsgrad,
                  float grad_scale);
+/* torch.optim.SGD(momentum, nesterov=True) element-wise update on a flat buffer (AM_training/train.py:172-174,247-249, `--optim sgd`):
+ *   buf = momentum buf + g  (buf zero-initialised: the first step's "buf = g");  p -= lr (g + momentum buf).  No step-dependent
+ * scalar, so the same launch serves the host-synchronous and the device-resident step. */
+int aas_sgd_nesterov_f32(aasStream_t stream, float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
+                         float grad_scale);
 
 /* Same update with the step-dependent scalars read from device memory: d_hyper[0] = lr/(1-b1^t),
  * d_hyper[1] = sqrt(1-b2^t) - lets the whole training step be captured in a hipGraph and replayed. */

@@ -191,8 +191,8 @@ def _main_worker(rank, world, port, tmp, q):
             from aas_enhancement_amd.dist import DPContext
             self.dp = DPContext.from_env()
             seen["world"], seen["rank"] = self.dp.world, self.dp.rank
-            seen["batch"] = data_loader.next(cl_ny="ny", type="train")
-            seen["shard"] = self.dp.shard_collated(seen["batch"])
+            assert data_loader.dp is not None and data_loader.dp.world == self.dp.world     # main.py hands the loader its DP context
+            seen["batch"] = data_loader.next(cl_ny="ny", type="train")                     # already this rank's shard
 
         def train(self):
             pass
@@ -206,12 +206,13 @@ def _main_worker(rank, world, port, tmp, q):
                            "--expnum", str(40 + rank), "--gpu", "-1"])
     os.chdir(tmp)
     M.main(cfg)
-    q.put((rank, seen["world"], seen["batch"][0].numpy(), seen["shard"][0].numpy(), seen["shard"][3].tolist()))
+    q.put((rank, seen["world"], seen["batch"][0].numpy(), seen["batch"][2].numpy(), seen["batch"][3].tolist()))
 
 
 def test_main_initialises_process_group_and_shards(tmp_path):
     """`torchrun -m aas_enhancement_amd.main --trainer AAS` wiring: RANK/WORLD_SIZE from the environment -> process group ->
-    every rank draws the SAME global batch and keeps its strided shard."""
+    a data-parallel aware loader: every rank walks the SAME global bins and loads only its strided shard, padded to the global
+    longest utterance."""
     import json
     tmp = str(tmp_path)
     json.dump(list("_'abcdefghijklmnopqrstuvwxyz "), open(os.path.join(tmp, "labels.json"), "w"))
@@ -234,6 +235,15 @@ def test_main_initialises_process_group_and_shards(tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] == 2 and res[1][1] == 2
-    assert np.array_equal(res[0][2], res[1][2])                       # same global batch on both ranks
-    assert np.array_equal(res[0][3], res[0][2][0::2]) and np.array_equal(res[1][3], res[1][2][1::2])
-    assert res[0][4] != res[1][4] or len(res[0][4]) == 2
+    x0, x1 = res[0][2], res[1][2]
+    assert x0.shape == x1.shape and x0.shape[0] == 2                  # batch_size 4 over 2 ranks, same (global) padded length
+    ids0, ids1 = sorted(int(v) for v in x0[:, 0, 0]), sorted(int(v) for v in x1[:, 0, 0])   # (utterance i is filled with the value i)
+    assert not set(ids0) & set(ids1)
+    both = sorted(ids0 + ids1)
+    assert both in ([0, 1, 2, 3], [4, 5, 6, 7])                       # together: one global bin of the length-sorted manifest
+    lens = [30, 28, 27, 25, 22, 20, 19, 15]
+    t_glob = max(lens[i] for i in both)
+    assert x0.shape[2] == t_glob
+    for x, pct in ((x0, res[0][3]), (x1, res[1][3])):
+        for row, pc in zip(x, pct):
+            assert int(round(float(pc) * t_glob)) == lens[int(row[0, 0])]

@@ -1,0 +1,326 @@
+"""GPU parity tests (-m gpu) added in round 3: the device-resident FSEGAN step against the reference goldens and the
+synchronous step, SGD-with-Nesterov-momentum (AM_training/train.py:172-174) against torch.optim.SGD, data parallelism for the
+DCE / FSEGAN trainers, and `Trainer.train()` data parallel with a sharding loader and --sync_bn across a save_iter."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from tests.helpers import LABELS, load, load_sd
+from tests.test_gpu_step import cfg
+
+pytestmark = pytest.mark.gpu
+REL_OUT, REL_LOSS = 1e-3, 1e-2
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _fill(m, seed, conv_std=None):
+    from aas_enhancement_amd import prng
+    load_sd(m, {k: torch.from_numpy(v) for k, v in prng.fill_state_dict(m.state_dict(), seed, conv_std=conv_std).items()}, strict=False)
+    return m
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+# ------------------------------------------------------------------------------------------------ FSEGAN, device-resident
+def test_fsegan_async_config4_golden(gpu):
+    """F6 (config 4 at size) through train_step_async + read_scalars: scalars, kt trajectory and enhanced samples of the
+    reference-module step, two iterations (the second one sees the kt the device advanced)."""
+    from aas_enhancement_amd import ops, prng
+    from aas_enhancement_amd.model import stackedBRNN
+    from aas_enhancement_amd.trainer_FSEGAN import Trainer
+    z = load("f6_fsegan_config4.npz")
+    N, F, T, H = [int(z[k]) for k in ("N", "F", "T", "H")]
+    G, D = _fill(stackedBRNN(I=F, O=F, H=H, L=4), int(z["weight_seed_G"])), _fill(stackedBRNN(I=2 * F, O=F, H=H, L=4), int(z["weight_seed_D"]))
+    tr = Trainer(cfg(lr=float(z["lr"]), w_adversarial=float(z["w_adversarial"]), nFeat=F, rnn_size=H), None, models=(G, D))
+    tr.kt = float(z["kt0"])
+    outs = []
+    for it in range(2):       # both queued before anything is read back
+        mix = torch.from_numpy(prng.uniform(int(z["mixture_seed0"]) + it, (N, F, T), 0.0, 6.0))
+        cln = torch.from_numpy(prng.uniform(int(z["clean_seed0"]) + it, (N, F, T), 0.0, 6.0))
+        mask = torch.zeros(N, 1, T, dtype=torch.uint8)
+        r = tr.train_step_async((mix, cln, mask), it)
+        outs.append((r["enhanced"], r["scalars"].clone()))
+    sc = tr.read_scalars()
+    for it, (enh, s) in enumerate(outs):
+        got = dict(zip(("l_adv_ny_G", "l_adv_cl", "dce", "kt"), s[:4].tolist()))
+        for k, v in got.items():
+            assert v == pytest.approx(float(z["it%d.%s" % (it, k)]), rel=REL_LOSS), (it, k)
+        e = enh.detach().reshape(-1)
+        g = e[torch.from_numpy(z["it%d.enh_idx" % it]).cuda()].cpu().numpy()
+        ref = z["it%d.enh_samples" % it]
+        assert np.abs(g - ref).max() < REL_OUT * np.abs(ref).max(), it
+    assert sc["kt"] == pytest.approx(float(z["it1.kt"]), rel=REL_LOSS) and tr.kt == sc["kt"]
+    assert not ops.rnn_timeout_flag()
+
+
+def _tiny_fsegan(as_written=False):
+    from aas_enhancement_amd.model import stackedBRNN
+    from aas_enhancement_amd.trainer_FSEGAN import Trainer
+    G, D = _fill(stackedBRNN(I=8, O=8, H=16, L=2), 31), _fill(stackedBRNN(I=16, O=8, H=16, L=2), 32)
+    tr = Trainer(cfg(lr=1e-3, w_adversarial=0.3, nFeat=8, rnn_size=16, fsegan_as_written=as_written), None, models=(G, D))
+    tr.kt = 0.2
+    return tr
+
+
+def _tiny_paired(seed, n=4, T=40, lens=None):
+    from aas_enhancement_amd import prng
+    lens = lens or [T] * n
+    x = torch.from_numpy(prng.uniform(seed, (n, 8, T), 0.0, 6.0))
+    y = torch.from_numpy(prng.uniform(seed + 1, (n, 8, T), 0.0, 6.0))
+    mask = torch.zeros(n, 1, T, dtype=torch.uint8)
+    for i, L in enumerate(lens):
+        x[i, :, L:] = 0; y[i, :, L:] = 0; mask[i, 0, L:] = 1
+    return x, y, mask
+
+
+def test_fsegan_async_and_sync_steps_interchange(gpu):
+    """async, async, sync, async == sync x 4 (host / device kt and the Adam step counters stay in step), ragged lengths."""
+    ref, mix = _tiny_fsegan(), _tiny_fsegan()
+    want, got = [], []
+    for it in range(4):
+        b = _tiny_paired(700 + 2 * it, lens=[40, 33, 25, 25])
+        r = ref.train_step(b, it)
+        want.append([r[k] for k in ("l_adv_ny_G", "l_adv_cl", "dce", "kt")])
+        if it == 2:
+            r2 = mix.train_step(b, it)
+        else:
+            mix.train_step_async(b, it)
+            r2 = mix.read_scalars() if it in (1, 3) else None
+        if r2 is not None:
+            got.append((it, [r2[k] for k in ("l_adv_ny_G", "l_adv_cl", "dce", "kt")]))
+    for it, g in got:
+        assert np.allclose(g, want[it], rtol=2e-4), (it, g, want[it])
+    for k in ("G", "D"):
+        a, b_ = ref._flat[k].flat_p, mix._flat[k].flat_p
+        assert float((a - b_).abs().max()) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------ SGD + Nesterov momentum
+def test_flat_sgd_nesterov_vs_torch(gpu):
+    from aas_enhancement_amd.dist import FlatBuffers
+    from aas_enhancement_amd.optim import FlatSGD
+    torch.manual_seed(0)
+    mod = nn.ParameterList([nn.Parameter(torch.randn(37, 5)), nn.Parameter(torch.randn(11))]).cuda()
+    ref = [p.detach().clone().requires_grad_(True) for p in mod]
+    opt_ref = torch.optim.SGD(ref, lr=0.05, momentum=0.9, nesterov=True)
+    flat = FlatBuffers(mod)
+    opt = FlatSGD(flat, lr=0.05, momentum=0.9)
+    for step in range(4):
+        gs = [torch.randn_like(p) for p in ref]
+        for p, r, g in zip(mod, ref, gs):
+            p.grad.copy_(g)
+            r.grad = g.clone()
+        opt.step() if step % 2 == 0 else opt.step_dev()
+        opt_ref.step()
+        for p, r in zip(mod, ref):
+            assert float((p.detach() - r.detach()).abs().max()) < 1e-6, step
+    sd = opt.state_dict()
+    assert sd["param_groups"][0]["nesterov"] and sd["param_groups"][0]["momentum"] == 0.9
+    assert torch.allclose(sd["state"][0]["momentum_buffer"], opt_ref.state_dict()["state"][0]["momentum_buffer"], atol=1e-6)
+    opt2 = FlatSGD(flat, lr=0.01, momentum=0.5)
+    opt2.load_state_dict(sd)
+    assert opt2.lr == 0.05 and opt2.momentum == 0.9 and torch.equal(opt2.buf, opt.buf)
+
+
+def test_am_trainer_sgd_matches_oracle_step(gpu):
+    """AMTrainer(optim='sgd') (train.py:172-174: SGD(momentum, nesterov=True)) against the CPU oracle model under torch.optim.SGD."""
+    from aas_enhancement_amd import prng
+    from aas_enhancement_amd.am_train import AMTrainer
+    from aas_enhancement_amd.model import DeepSpeech
+    from oracle import ref_model as RM
+    from oracle import ref_step as RS
+    A = _fill(DeepSpeech(nn.GRU, LABELS, 12, 3, True, 11, 2, 8, 2, nFreq=8), 51, 0.1)
+    R = RM.RefDeepSpeech(nn.GRU, LABELS, 12, 3, 11, 2, 8, 2, nFreq=8)
+    load_sd(R, A.state_dict(), strict=False)
+    tr = AMTrainer(A.cuda(), lr=1e-2, optim="sgd", momentum=0.9)
+    opt = torch.optim.SGD(R.parameters(), lr=1e-2, momentum=0.9, nesterov=True)
+    N, T, L = 3, 60, 3
+    for it in range(3):
+        b = (torch.from_numpy(prng.uniform(60 + it, (N, 8, T), 0.0, 6.0)), torch.from_numpy(prng.randint(70 + it, (N * L,), 1, 28).astype(np.int32)),
+             torch.ones(N), torch.full((N,), L, dtype=torch.int32))
+        r = tr.train_step(b) if it != 1 else None
+        if it == 1:
+            h = tr.train_step_async(b)
+            r = dict(loss=tr.read_loss(h["handle"])[0])
+        ref = RS.am_step(R, opt, b)
+        assert r["loss"] == pytest.approx(float(ref["loss"]), rel=1e-3), it
+    sd_r = R.state_dict()
+    for k, v in A.state_dict().items():
+        if "running" in k or "num_batches" in k or k in ("conv.0.bias", "conv.3.bias"):
+            continue
+        assert float((v.cpu() - sd_r[k]).abs().max()) < 2e-3 * float(sd_r[k].abs().max()) + 1e-5, k
+
+
+# ------------------------------------------------------------------------------------------------ DP: DCE / FSEGAN trainers
+def _dp_env(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=180))
+    torch.cuda.set_device(0)
+    return dist
+
+
+def _paired_shard(dp, b):
+    idx = torch.tensor(dp.shard_rows(b[0].size(0)))
+    return tuple(t.index_select(0, idx) for t in b)
+
+
+def _pair_worker(rank, world, port, q, which):
+    dist = _dp_env(rank, world, port)
+    try:
+        from aas_enhancement_amd.dist import DPContext
+        out = []
+        if which == "dce":
+            from aas_enhancement_amd.model import stackedBRNN
+            from aas_enhancement_amd.trainer_DCE import Trainer
+            tr = Trainer(cfg(lr=1e-3, nFeat=8, rnn_size=16), None, models=(_fill(stackedBRNN(I=8, H=16, L=2), 31),))
+            tr.make_optimizers()
+            for it in range(2):
+                r = tr.train_step(_paired_shard(tr.dp, _tiny_paired(800 + 2 * it, lens=[40, 36, 30, 22])), it)
+                out.append([float(r["dce"])])
+            flats = [tr._flat.flat_p]
+        else:
+            tr = _tiny_fsegan()
+            tr.make_optimizers()
+            for it in range(3):
+                b = _paired_shard(tr.dp, _tiny_paired(800 + 2 * it, lens=[40, 36, 30, 22]))
+                if which == "fsegan_sync" or it == 1:
+                    r = tr.train_step(b, it)
+                else:
+                    tr.train_step_async(b, it)
+                    r = tr.read_scalars()
+                out.append([r[k] for k in ("l_adv_ny_G", "l_adv_cl", "dce", "kt")])
+            flats = [tr._flat["G"].flat_p, tr._flat["D"].flat_p]
+        assert isinstance(tr.dp, DPContext) and tr.dp.active
+        q.put((rank, np.asarray(out), [f.detach().cpu().numpy() for f in flats]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["dce", "fsegan_sync", "fsegan_async"])
+def test_dce_and_fsegan_trainers_dp_two_ranks_equal_single(gpu, which):
+    """2 ranks x 2 utterances (global nElement, SUM all-reduce of the flat gradient buffers, all-reduced kt inputs) == 1 rank x 4."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pair_worker, args=(r, 2, port, q, which)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = []
+    if which == "dce":
+        from aas_enhancement_amd.model import stackedBRNN
+        from aas_enhancement_amd.trainer_DCE import Trainer
+        tr = Trainer(cfg(lr=1e-3, nFeat=8, rnn_size=16), None, models=(_fill(stackedBRNN(I=8, H=16, L=2), 31),))
+        for it in range(2):
+            ref.append([float(tr.train_step(_tiny_paired(800 + 2 * it, lens=[40, 36, 30, 22]), it)["dce"])])
+        flats = [tr._flat.flat_p]
+    else:
+        tr = _tiny_fsegan()
+        for it in range(3):
+            r = tr.train_step(_tiny_paired(800 + 2 * it, lens=[40, 36, 30, 22]), it)
+            ref.append([r[k] for k in ("l_adv_ny_G", "l_adv_cl", "dce", "kt")])
+        flats = [tr._flat["G"].flat_p, tr._flat["D"].flat_p]
+    ref = np.asarray(ref)
+    for rank, out, pars in res:
+        assert np.allclose(out, ref, rtol=3e-4), (rank, out, ref)
+        for a, b in zip(pars, flats):
+            d_ = np.abs(a - b.detach().cpu().numpy())
+            assert float((d_ > 2e-4).mean()) < 2e-3 and float(d_.max()) < 6.1e-3, rank    # (Adam sign flips of noise-level gradients)
+    for a, b in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ Trainer.train() data parallel
+def _manifests(tmp):
+    from aas_enhancement_amd import prng
+    lens = [36, 40, 44, 47, 50, 52, 55, 60]                   # ascending (make_manifest_librispeech.py:58-59)
+    rows = []
+    for i, T in enumerate(lens):
+        torch.save(torch.from_numpy(prng.uniform(900 + i, (8, T), 0.0, 6.0)), os.path.join(tmp, "f%d.pt7" % i))
+        open(os.path.join(tmp, "t%d.txt" % i), "w").write("ab cd"[: 2 + i % 3])
+        rows.append("%s,%s" % (os.path.join(tmp, "f%d.pt7" % i), os.path.join(tmp, "t%d.txt" % i)))
+    for name in ("ny.csv", "cl.csv", "val.csv"):
+        open(os.path.join(tmp, name), "w").write("\n".join(rows if name != "val.csv" else rows[:3]) + "\n")
+    return tmp
+
+
+def _aas_models():
+    from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
+    return (_fill(stackedBRNN(I=8, H=16, L=2), 11), _fill(stackedBRNN(I=8, H=16, L=2), 12),
+            _fill(DeepSpeech(nn.GRU, LABELS, 12, 2, True, 11, 2, 8, 2, nFreq=8), 13, 0.1))
+
+
+def _train_cfg(tmp, expnum):
+    return cfg(lr=1e-3, nFeat=8, rnn_size=16, batch_size=4, allow_ASR_update_iter=0, sync_bn=True, start_iter=0, max_iter=4, log_iter=2, save_iter=2,
+               expnum=expnum, write_log=False, w_adversarial=1.0, w_acoustic=1.0)
+
+
+def _run_train(tmp, expnum, dp):
+    from aas_enhancement_amd.data_loader import DataLoader
+    from aas_enhancement_amd.trainer_AAS import Trainer
+    np.random.seed(3)
+    dl = DataLoader(batch_size=4, tr_ny_manifest=os.path.join(tmp, "ny.csv"), tr_cl_manifest=os.path.join(tmp, "cl.csv"),
+                    trsub_manifest=os.path.join(tmp, "val.csv"), val_manifest=os.path.join(tmp, "val.csv"), labels=LABELS, num_workers=0,
+                    pin_memory=True, dp=dp)
+    tr = Trainer(_train_cfg(tmp, expnum), dl, models=_aas_models())
+    tr.model_dir = os.path.join(tmp, "logs%d" % expnum)
+    tr.train()
+    torch.cuda.synchronize()
+    return tr
+
+
+def _train_worker(rank, world, port, tmp, q):
+    dist = _dp_env(rank, world, port)
+    try:
+        from aas_enhancement_amd.dist import DPContext
+        tr = _run_train(tmp, 70, DPContext.from_env())
+        q.put((rank, tr._flat["G"].flat_p.detach().cpu().numpy(), tr._flat["A"].flat_p.detach().cpu().numpy(), float(tr.kt),
+               sorted(os.listdir(tr.model_dir)) if os.path.isdir(tr.model_dir) else []))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_loop_dp_with_sharding_loader_and_syncbn_across_save_iter(gpu, tmp_path):
+    """rank 0 alone validates at a save_iter while A stays in train mode; with --sync_bn armed its BatchNorm
+    would issue all-reduces no other rank matches.  Two ranks, a loader that shards before loading, sync_bn on, two save_iters
+    inside four iterations: the run finishes, only rank 0 writes checkpoints, every rank ends with identical parameters, and
+    they equal the single-process run on the same global batches."""
+    tmp = _manifests(str(tmp_path))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, tmp, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=420) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
+    assert any(f.startswith("G_3") for f in res[0][4]) and any(f.startswith("ASR_3") for f in res[0][4])
+    from aas_enhancement_amd import ops
+    single = _run_train(tmp, 71, None)
+    assert ops.SYNC_BN[0] is None
+    for got, want in ((res[0][1], single._flat["G"].flat_p), (res[0][2], single._flat["A"].flat_p)):
+        d_ = np.abs(got - want.detach().cpu().numpy())
+        assert float((d_ > 2e-4).mean()) < 5e-3 and float(d_.max()) < 8.1e-3
+    assert res[0][3] == pytest.approx(float(single.kt), rel=1e-3, abs=1e-6)
