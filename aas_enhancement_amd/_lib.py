@@ -99,7 +99,7 @@ def lib():
             L.aas_set_wgrad_wg_cap(int(os.environ["AAS_WGRAD_WGS"]))
         if os.environ.get("AAS_DEBUG_FLAGS"):             # A/B kernel-selection bits of aas_set_debug_flags (include/aas_hip.h)
             L.aas_set_debug_flags(int(os.environ["AAS_DEBUG_FLAGS"]))
-        if os.environ.get("AAS_PRECISION") in ("0", "1"):  # 0 = exact fp32 MFMA, 1 = split-bf16 (library default)
+        if os.environ.get("AAS_PRECISION") in ("0", "1"):  # 0 = fp32 MFMA (library default), 1 = split-bf16 fast mode
             L.aas_set_precision(int(os.environ["AAS_PRECISION"]))
         _lib = L
     return _lib

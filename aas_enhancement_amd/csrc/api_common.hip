@@ -31,8 +31,8 @@ extern "C" int aas_set_debug_flags(int flags) {
     return 0;
 }
 
-// 0 = exact fp32 MFMA everywhere; 1 = split-bf16 (hi/lo, 3 MFMAs) operands in the GEMMs
-static int g_precision = 1;
+// 0 (default) = fp32-input MFMA everywhere, the reference's arithmetic; 1 = split-bf16 (hi/lo, 3 MFMAs) fast mode
+static int g_precision = 0;
 int aas_precision_value() { return g_precision; }
 extern "C" int aas_set_precision(int mode) {
     if (mode < 0 || mode > 1) {

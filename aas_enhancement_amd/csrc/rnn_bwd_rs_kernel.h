@@ -30,7 +30,7 @@ namespace {
 
 // MODE = LSTM_BWD or GRU_BWD; U = units per workgroup (16: 256 threads, 32: 512 threads - half as many slices, so
 // half the exchanged bytes chip-wide); NTW = 16-column result tiles per wave (P <= 4*NTW)
-template <int MODE, int U, int NTW, int LKSP = -1>
+template <int MODE, int U, int NTW, int LKSP = -1, bool EX = false>
 __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     using C = Cfg<MODE>;
     constexpr int G = C::G;
@@ -42,8 +42,12 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     constexpr int KPP = NTW;                              // producers per lane in the consumer-side sum (4 lanes share a row)
     constexpr int UQ = U / 4;                             // 16-byte unit quads per block
     constexpr int TPC = U / 16;                           // result tiles per consumer slice
-    __shared__ __attribute__((aligned(16))) unsigned short a_hi[2][16][RS_LDA];
-    __shared__ __attribute__((aligned(16))) unsigned short a_lo[2][16][RS_LDA];
+    // my d(gates) slice as the MFMA operand tile, double-buffered by step parity: split - bf16 hi and lo tiles; exact - one fp32
+    // tile (EX_LDA floats per row: +4 keeps the two 16-byte reads of a lane apart from its neighbours' banks)
+    constexpr int EX_LDA = KSTEPS * 32 + 4;
+    __shared__ __attribute__((aligned(16))) unsigned short a_hi[EX ? 1 : 2][EX ? 1 : 16][EX ? 8 : RS_LDA];
+    __shared__ __attribute__((aligned(16))) unsigned short a_lo[EX ? 1 : 2][EX ? 1 : 16][EX ? 8 : RS_LDA];
+    __shared__ __attribute__((aligned(16))) float a_f[EX ? 2 : 1][EX ? 16 : 1][EX ? EX_LDA : 4];
     // the 1000-unit GRU at U = 32 needs 192 VGPRs for its W fragments alone (of 256 at two waves per SIMD): the lo
     // fragments of its last k-step live in LDS instead (64 KB, re-read once per step) so that nothing spills
     constexpr int LKS = LKSP >= 0 ? LKSP : ((!LSTM && U == 32 && NTW == 8) ? AAS_GRU_BWD_LKS : 0);
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
 
     // ---- B fragments: rows {g*H + u0 + u} of W_hh (k' = g*16 + u, padded to 64) x all Hp columns --------------
     const float* W = d == 0 ? p.w_hh : p.w_hh_r;
-    bf16x8 bh[KSTEPS][NTW], bl[KSTEPS][NTW];
+    u32x4 b0[KSTEPS][NTW], b1[KSTEPS][NTW];     // (rnn_split_kernel.h: frag_make)
     {
         const int n = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -78,25 +82,18 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int col = (wave * NTW + nt) * 16 + n;       // unit whose dh this column feeds
-                unsigned hw[4], lw[4];
+                float wv[8];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    unsigned h2[2], l2[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int kk = ks * 32 + q * 8 + jj * 2 + e;
-                        const int gate = kk / U, unit = u0 + kk % U;
-                        float v = 0.f;
-                        if (gate < G && unit < H && col < H) v = W[(int64_t)(gate * H + unit) * H + col];
-                        split_bf16(v, h2[e], l2[e]);
-                    }
-                    hw[jj] = h2[0] | (h2[1] << 16);
-                    lw[jj] = l2[0] | (l2[1] << 16);
+                for (int e = 0; e < 8; ++e) {
+                    const int kk = ks * 32 + q * 8 + e;
+                    const int gate = kk / U, unit = u0 + kk % U;
+                    wv[e] = (gate < G && unit < H && col < H) ? W[(int64_t)(gate * H + unit) * H + col] : 0.f;
                 }
-                const u32x4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
-                bh[ks][nt] = __builtin_bit_cast(bf16x8, hv);
-                if (ks >= KSTEPS - LKS) bl_lds[LKS ? (ks - (KSTEPS - LKS)) * NTW + nt : 0][LKS ? tid : 0] = lv;
-                else bl[ks][nt] = __builtin_bit_cast(bf16x8, lv);
+                u32x4 w0, w1;
+                frag_make<EX>(wv, w0, w1);
+                b0[ks][nt] = w0;
+                if (ks >= KSTEPS - LKS) bl_lds[LKS ? (ks - (KSTEPS - LKS)) * NTW + nt : 0][LKS ? tid : 0] = w1;
+                else b1[ks][nt] = w1;
             }
     }
     // plain (L2-resident) publish stores when the whole set shares an XCD (rnn_split_kernel.h: xcd_set_colocated)
@@ -108,9 +105,13 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
         if (p.flags & 524288) local = 0ull;
     }
     // zero both A tiles once: pad rows / pad gate columns stay zero for the whole launch
-    for (int i = tid; i < 2 * 16 * RS_LDA; i += THREADS) {
-        (&a_hi[0][0][0])[i] = 0;
-        (&a_lo[0][0][0])[i] = 0;
+    if constexpr (EX) {
+        for (int i = tid; i < 2 * 16 * EX_LDA; i += THREADS) (&a_f[0][0][0])[i] = 0.f;
+    } else {
+        for (int i = tid; i < 2 * 16 * RS_LDA; i += THREADS) {
+            (&a_hi[0][0][0])[i] = 0;
+            (&a_lo[0][0][0])[i] = 0;
+        }
     }
     __syncthreads();
 
@@ -260,13 +261,18 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
         }
         const int par = s & 1;
         unsigned h16[4] = {0, 0, 0, 0}, l16[4] = {0, 0, 0, 0};
+        if constexpr (!EX) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) split_bf16(xv[g], h16[g], l16[g]);
-        if (rowok && s + 1 < T) {  // my d(gates) slice as the split-bf16 A tile of the partial product
+            for (int g = 0; g < G; ++g) split_bf16(xv[g], h16[g], l16[g]);
+        }
+        if (rowok && s + 1 < T) {  // my d(gates) slice as the operand tile of the partial product
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                a_hi[par][row][g * U + unit] = (unsigned short)h16[g];
-                a_lo[par][row][g * U + unit] = (unsigned short)l16[g];
+                if constexpr (EX) a_f[par][row][g * U + unit] = xv[g];
+                else {
+                    a_hi[par][row][g * U + unit] = (unsigned short)h16[g];
+                    a_lo[par][row][g * U + unit] = (unsigned short)l16[g];
+                }
             }
         }
         if (p.dgp1) {
@@ -322,11 +328,16 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
         // ---- partial dh for all units: [16 rows x 64] x [64 x Hp], published to the consumers' blocks ---
         if (s + 1 < T) {
             const int m = lane & 15, q = lane >> 4;
-            bf16x8 ah[KSTEPS], al[KSTEPS];
+            u32x4 ah[KSTEPS], al[KSTEPS];
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-                ah[ks] = *reinterpret_cast<const bf16x8*>(&a_hi[par][m][ks * 32 + q * 8]);
-                al[ks] = *reinterpret_cast<const bf16x8*>(&a_lo[par][m][ks * 32 + q * 8]);
+                if constexpr (EX) {
+                    ah[ks] = *reinterpret_cast<const u32x4*>(&a_f[par][m][ks * 32 + q * 8]);
+                    al[ks] = *reinterpret_cast<const u32x4*>(&a_f[par][m][ks * 32 + q * 8 + 4]);
+                } else {
+                    ah[ks] = *reinterpret_cast<const u32x4*>(&a_hi[par][m][ks * 32 + q * 8]);
+                    al[ks] = *reinterpret_cast<const u32x4*>(&a_lo[par][m][ks * 32 + q * 8]);
+                }
             }
             const unsigned tag = (unsigned)(s % 3);
             const int slot = s & 1;
@@ -341,22 +352,30 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                 if (!(p.flags & 2)) {
 #pragma unroll
                     for (int ks = 0; ks < KSTEPS; ++ks) {
-                        bf16x8 blv;
-                        if (ks >= KSTEPS - LKS) blv = __builtin_bit_cast(bf16x8, bl_lds[LKS ? (ks - (KSTEPS - LKS)) * NTW + nt : 0][LKS ? tid : 0]);
-                        else blv = bl[ks][nt];
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks][nt], al[ks], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blv, ah[ks], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks][nt], ah[ks], acc, 0, 0, 0);
+                        u32x4 w1;
+                        if (ks >= KSTEPS - LKS) w1 = bl_lds[LKS ? (ks - (KSTEPS - LKS)) * NTW + nt : 0][LKS ? tid : 0];
+                        else w1 = b1[ks][nt];
+                        if constexpr (EX) acc = mma_chunk<true>(acc, b0[ks][nt], w1, ah[ks], al[ks]);
+                        else {   // (the order of the three products is part of the bit-exact contract between the kernel variants)
+                            const bf16x8 whi = __builtin_bit_cast(bf16x8, b0[ks][nt]), wlo = __builtin_bit_cast(bf16x8, w1);
+                            const bf16x8 dhi = __builtin_bit_cast(bf16x8, ah[ks]), dlo = __builtin_bit_cast(bf16x8, al[ks]);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, dlo, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, dhi, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, dhi, acc, 0, 0, 0);
+                        }
                     }
                 }
                 const int tile = wave * NTW + nt;
                 const int c = tile / TPC, half = tile % TPC;   // consumer slice, 16-unit half of its block
                 if (c < P && prow < nrows && !(p.flags & 8)) {
+                    // the tag replaces the two low mantissa bits: exact mode rounds to nearest there (an unbiased 22-bit partial,
+                    // |error| <= 2 ulp, below the rounding noise of any fp32 summation order); split mode truncates as before
+                    constexpr unsigned RND = EX ? 2u : 0u;
                     u32x4 o;
-                    o.x = (__float_as_uint(acc[0]) & ~3u) | tag;
-                    o.y = (__float_as_uint(acc[1]) & ~3u) | tag;
-                    o.z = (__float_as_uint(acc[2]) & ~3u) | tag;
-                    o.w = (__float_as_uint(acc[3]) & ~3u) | tag;
+                    o.x = ((__float_as_uint(acc[0]) + RND) & ~3u) | tag;
+                    o.y = ((__float_as_uint(acc[1]) + RND) & ~3u) | tag;
+                    o.z = ((__float_as_uint(acc[2]) + RND) & ~3u) | tag;
+                    o.w = ((__float_as_uint(acc[3]) + RND) & ~3u) | tag;
                     const unsigned boff = (unsigned)((((rblk + c) * P + pslice) * U + half * 16 + u4) * 4);
                     if ((local >> c) & 1ull) __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 0);   // the line stays in this XCD's L2
                     else __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 16);            // sc1: agent-scope write-through
@@ -379,22 +398,22 @@ inline size_t rs_ring_bytes(int N, int H, int U) {
     return (size_t)4 * N * P * P * U * 4;
 }
 
-template <int MODE, int U>
+template <int MODE, int U, bool EX>
 int launch_rs(const RnnP& p, hipStream_t s) {
     dim3 grid(p.P, p.Q, 2), block(16 * U);
     if (p.xcd) grid = dim3(p.P * p.Q * 2);
-    if (p.P <= 8) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 2>), grid, block, 0, s, p);
-    else if (p.P <= 16) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 4>), grid, block, 0, s, p);
+    if (p.P <= 8) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 2, -1, EX>), grid, block, 0, s, p);
+    else if (p.P <= 16) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 4, -1, EX>), grid, block, 0, s, p);
     else if (p.P <= 32) {
-        if (MODE == GRU_BWD && U == 32 && (p.flags & 32768)) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 8, 1>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 8>), grid, block, 0, s, p);
+        if (!EX && MODE == GRU_BWD && U == 32 && (p.flags & 32768)) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 8, 1, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 8, -1, EX>), grid, block, 0, s, p);
     }
-    else if (U == 16 && p.P <= 64) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, 16, 16>), grid, block, 0, s, p);
+    else if (U == 16 && p.P <= 64) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, 16, 16, -1, EX>), grid, block, 0, s, p);
     else return -1;
     return 0;
 }
 
-template <int MODE>
+template <int MODE, bool EX = false>
 int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
     AAS_CHECK(p.T >= 1 && p.N >= 1 && p.H >= 1, "%s: bad sizes T=%d N=%d H=%d", name, p.T, p.N, p.H);
     const int cus = aas_rnn_cus();
@@ -425,23 +444,28 @@ int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
         // 8 (direction, row group) sets of at most 32 workgroups: XCD-aware grid (debug bit 262144: the plain 3-D grid,
         // 524288: XCD-aware grid but write-through publish stores)
         p.xcd = (p.flags & 262144) ? 0 : ((p.Q * 2) % 8 == 0 && p.P * (p.Q * 2 / 8) <= 32) ? 1 : (p.Q * 2 == 4 && p.P <= 64 && p.P % 2 == 0) ? 2 : 0;
-        const int rc = (U == 32) ? launch_rs<MODE, 32>(p, s) : launch_rs<MODE, 16>(p, s);
+        const int rc = (U == 32) ? launch_rs<MODE, 32, EX>(p, s) : launch_rs<MODE, 16, EX>(p, s);
         if (rc != 0) return -1;
         AAS_LAUNCH_CHECK(name);
     }
     return 0;
 }
 
-// BPTT entry: reduce-scatter kernel by default, the all-gather split kernel under debug flag 256, exact fp32 otherwise
+// BPTT entry: the reduce-scatter kernel in the library's arithmetic mode (split-bf16, or exact fp32 when the caller takes fp32
+// d(gates)); the all-gather split kernel under debug flag 256; the counter-based fp32 kernel otherwise (and under debug bit 134217728)
 template <int MODE>
 int run_bwd_any(const char* name, RnnP p, hipStream_t s) {
     if (p.xchg && aas_precision_value() != 0 && !(aas_debug_flags_value() & 256)) {
-        const int rc = run_bwd_rs<MODE>(name, p, s);
+        const int rc = run_bwd_rs<MODE, false>(name, p, s);
         if (rc >= 0) return rc;
     }
-    if (p.dgp1) {   // only the reduce-scatter kernel writes operand planes: the caller falls back to fp32 d(gates) + a split pass
+    if (p.dgp1) {   // only the split-bf16 reduce-scatter kernel writes operand planes: the caller falls back to fp32 d(gates) + a split pass
         aas_set_error("%s: plane output needs the split-bf16 reduce-scatter BPTT kernel (precision 1, exchange buffer, supported H)", name);
         return 3;
+    }
+    if (p.xchg && aas_precision_value() == 0 && !(aas_debug_flags_value() & (256 | 134217728))) {
+        const int rc = run_bwd_rs<MODE, true>(name, p, s);
+        if (rc >= 0) return rc;
     }
     return run_any<MODE>(name, p, s);
 }

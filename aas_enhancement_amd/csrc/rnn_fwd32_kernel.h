@@ -12,7 +12,7 @@
 namespace {
 
 // MODE = LSTM_FWD or GRU_FWD; KS = 32-wide k chunks per wave (Hp = 256*KS); LKS = k-steps whose lo fragments are in LDS
-template <int MODE, int KS, int LKS>
+template <int MODE, int KS, int LKS, bool EX = false>
 __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
     using C = Cfg<MODE>;
     constexpr int G = C::G, U = 32, NW = 8;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
 
     // ---- B fragments (hi / lo) of this workgroup's W_hh slice: rows {gate*H + unit}, this wave's k range ------------
     const float* W = d == 0 ? p.w_hh : p.w_hh_r;
-    bf16x8 bh[KS][NT], bl[KS][NT];
+    u32x4 b0[KS][NT], b1[KS][NT];     // (rnn_split_kernel.h: frag_make - bf16 hi / lo words, or the 8 fp32 values of the exact mode)
     {
         const int n = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -48,24 +48,17 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
             for (int nt = 0; nt < NT; ++nt) {
                 const int c = nt * 16 + n;                    // gate column c = u*G + gate: a unit's G gates are adjacent
                 const int gate = c % G, unit = u0 + c / G;
-                unsigned hw[4], lw[4];
+                float wv[8];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    unsigned h2[2], l2[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int k = kb + ks * 32 + q * 8 + jj * 2 + e;
-                        float v = 0.f;
-                        if (unit < H && k < H) v = W[(int64_t)(gate * H + unit) * H + k];
-                        split_bf16(v, h2[e], l2[e]);
-                    }
-                    hw[jj] = h2[0] | (h2[1] << 16);
-                    lw[jj] = l2[0] | (l2[1] << 16);
+                for (int e = 0; e < 8; ++e) {
+                    const int k = kb + ks * 32 + q * 8 + e;
+                    wv[e] = (unit < H && k < H) ? W[(int64_t)(gate * H + unit) * H + k] : 0.f;
                 }
-                const u32x4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
-                bh[ks][nt] = __builtin_bit_cast(bf16x8, hv);
-                if (ks >= KS - LKS) bl_lds[LKS ? (ks - (KS - LKS)) * NT + nt : 0][LKS ? tid : 0] = lv;
-                else bl[ks][nt] = __builtin_bit_cast(bf16x8, lv);
+                u32x4 w0, w1;
+                frag_make<EX>(wv, w0, w1);
+                b0[ks][nt] = w0;
+                if (ks >= KS - LKS) bl_lds[LKS ? (ks - (KS - LKS)) * NT + nt : 0][LKS ? tid : 0] = w1;
+                else b1[ks][nt] = w1;
             }
     }
 
@@ -119,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
                 const int nprod = (KS * 32) / U;
                 const int kprobe = kb + lane * U;
                 const bool probe = lane < nprod && kprobe < Hp && !(p.flags & 1);
-                const unsigned* wp = xq + (xr0 * KC + kprobe / 32) * 32 + (kprobe % 32) / 2;
+                const unsigned* wp = xq + xr0 * KC * 32 + elem_word<EX>(kprobe);
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
                 while (true) {
@@ -137,7 +130,7 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
             }
             if (stamp) st1 = __builtin_amdgcn_s_memrealtime();
             const int grm = q0 + m;
-            const unsigned roff = (grm < NB && !(p.flags & 1)) ? (unsigned)(((xr0 + m) * KC + wave * KS) * 128 + q * 16) : OOB;
+            const unsigned roff = (grm < NB && !(p.flags & 1)) ? (unsigned)(((xr0 + m) * KC + wave * KS) * 128) + frag_off0<EX>(q) : OOB;
             u32x4 ah[KS], al[KS];
             unsigned spins = 0;
             unsigned long long t0 = 0;
@@ -148,10 +141,10 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
                     const unsigned off = (kb + ks * 32 + q * 8 < Hp) ? roff + (unsigned)(ks * 128) : OOB;
                     if (fresh) {
                         ah[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 16));
-                        al[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off + 64u), 0, 16));
+                        al[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off + frag_off1<EX>()), 0, 16));
                     } else {
                         ah[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
-                        al[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off + 64u), 0, 0));
+                        al[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off + frag_off1<EX>()), 0, 0));
                     }
                 }
                 unsigned mx = 0u;
@@ -174,15 +167,12 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
             if (!(p.flags & 2)) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[ks]), a_l = __builtin_bit_cast(bf16x8, al[ks]);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        bf16x8 blv;
-                        if (ks >= KS - LKS) blv = __builtin_bit_cast(bf16x8, bl_lds[LKS ? (ks - (KS - LKS)) * NT + nt : 0][LKS ? tid : 0]);
-                        else blv = bl[ks][nt];
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, bh[ks][nt], acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, blv, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, bh[ks][nt], acc[nt], 0, 0, 0);
+                        u32x4 w1;
+                        if (ks >= KS - LKS) w1 = bl_lds[LKS ? (ks - (KS - LKS)) * NT + nt : 0][LKS ? tid : 0];
+                        else w1 = b1[ks][nt];
+                        acc[nt] = mma_chunk<EX>(acc[nt], ah[ks], al[ks], b0[ks][nt], w1);
                     }
                 }
             }
@@ -234,8 +224,16 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
                 kp[0] = rg; kp[1] = zg; kp[2] = ng; kp[3] = hn;
             }
         }
-        // publish: even-unit lanes store {own, partner} packed hi and lo words (pad units publish zeros)
-        {
+        // publish (pad units publish zeros): split - even-unit lanes store {own, partner} packed hi and lo words; exact - every lane
+        // stores its own fp32 word
+        if constexpr (EX) {
+            if (rowok && s + 1 < T && !(p.flags & 8)) {
+                const int64_t xr = ((int64_t)d * T + t) * N + gr;
+                unsigned* wq = xq + xr * KC * 32 + unit;
+                if (plain) st_sc0_u32(wq, __float_as_uint(hval));
+                else st_sc1_u32(wq, __float_as_uint(hval));
+            }
+        } else {
             unsigned h0, l0;
             split_bf16(hval, h0, l0);
             const unsigned mine = h0 | (l0 << 16);
@@ -271,7 +269,7 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
 
 // 32-unit forward launches: H >= 256 (smaller layers keep the 16-unit kernel so that enough workgroups share the work),
 // Hp = 32*P a multiple of... any; KS = ceil(Hp / 256) <= 4.  Returns -1 when the shape is not covered.
-template <int MODE>
+template <int MODE, bool EX = false>
 int run_fwd32(const char* name, RnnP p, hipStream_t s) {
     constexpr bool LSTM = (MODE == LSTM_FWD);
     p.flags = aas_debug_flags_value();
@@ -297,7 +295,7 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
     const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
     AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes + XCD_TAB_BYTES, s));
     // one launch covers the batch: afterwards the buffer holds h_t of every step but each direction's last as operand planes
-    aas_note_fwd_h_planes(p.N <= qmax * rpg ? (Hp / 32) * 128 : 0);
+    aas_note_fwd_h_planes((!EX && p.N <= qmax * rpg) ? (Hp / 32) * 128 : 0);
     for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {
         p.n0 = n0;
         const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
@@ -312,14 +310,14 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
         dim3 grid(p.P, p.Q, 2), block(512);
         if (p.xcd) grid = dim3(p.P * p.Q * 2);
         if constexpr (LSTM) {
-            if (ks == 1) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 1, 0>), grid, block, 0, s, p);
-            else if (ks == 2) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0>), grid, block, 0, s, p);
+            if (ks == 1) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 1, 0, EX>), grid, block, 0, s, p);
+            else if (ks == 2) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0, EX>), grid, block, 0, s, p);
             else return -1;   // 128 gate columns x more than 512 k do not fit the register file
         } else {
-            if (ks == 1) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 1, 0>), grid, block, 0, s, p);
-            else if (ks == 2) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0>), grid, block, 0, s, p);
-            else if (ks == 3) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 3, 1>), grid, block, 0, s, p);
-            else hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 4, 2>), grid, block, 0, s, p);
+            if (ks == 1) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 1, 0, EX>), grid, block, 0, s, p);
+            else if (ks == 2) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0, EX>), grid, block, 0, s, p);
+            else if (ks == 3) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 3, 1, EX>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 4, 2, EX>), grid, block, 0, s, p);
         }
         AAS_LAUNCH_CHECK(name);
     }
@@ -330,7 +328,10 @@ template <int MODE>
 int run_fwd_any(const char* name, RnnP p, hipStream_t s) {
     aas_note_fwd_h_planes(0);
     if (p.xchg && aas_precision_value() != 0) {
-        const int rc = run_fwd32<MODE>(name, p, s);
+        const int rc = run_fwd32<MODE, false>(name, p, s);
+        if (rc >= 0) return rc;
+    } else if (p.xchg && !(aas_debug_flags_value() & 134217728)) {   // exact fp32 on the same data-is-the-flag kernels
+        const int rc = run_fwd32<MODE, true>(name, p, s);
         if (rc >= 0) return rc;
     }
     return run_any<MODE>(name, p, s);

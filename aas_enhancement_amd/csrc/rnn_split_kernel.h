@@ -42,6 +42,50 @@ __device__ __forceinline__ void st_sc0_u32(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// ---- operand fragments of one 32-wide k chunk, in the two arithmetic modes of the persistent kernels -----------------------
+// EX = false (aas_set_precision(1)): bf16 hi / lo halves, 8 consecutive k per lane, three v_mfma_f32_16x16x32_bf16.
+// EX = true  (aas_set_precision(0)): the fp32 values themselves, 8 consecutive k per lane (k = 8q + j feeds the j-th of eight
+//            v_mfma_f32_16x16x4_f32; A and B are permuted identically, so the sum runs over all 32 k): exact fp32 products with
+//            fp32 accumulation - the reference's arithmetic.  Either way a fragment is two 16-byte words per lane.
+template <bool EX>
+__device__ __forceinline__ void frag_make(const float (&v)[8], u32x4& w0, u32x4& w1) {
+    if constexpr (EX) {
+        w0 = (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        w1 = (u32x4){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+    } else {
+        unsigned h[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split_bf16(v[e], h[e], l[e]);
+        w0 = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        w1 = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    }
+}
+
+// acc += X * Y over one 32-wide k chunk; X (x0, x1) is the MFMA's first operand (16 rows), Y (y0, y1) its second (16 columns)
+template <bool EX>
+__device__ __forceinline__ f32x4 mma_chunk(f32x4 acc, const u32x4& x0, const u32x4& x1, const u32x4& y0, const u32x4& y1) {
+    if constexpr (EX) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(x0[j]), __uint_as_float(y0[j]), acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(x1[j]), __uint_as_float(y1[j]), acc, 0, 0, 0);
+    } else {
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, x0), xl = __builtin_bit_cast(bf16x8, x1);
+        const bf16x8 yh = __builtin_bit_cast(bf16x8, y0), yl = __builtin_bit_cast(bf16x8, y1);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, yh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, yl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, yh, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// Exchange rows are KC chunks of 128 bytes per 32 elements in both modes: split = 64 B of bf16 hi | 64 B of bf16 lo, exact = 32 fp32.
+// -> byte offsets inside a chunk of the two 16-byte words of lane quarter q, and the 32-bit word that carries element k (split: the
+//    hi word of k's pair) - the word a consumer probes / a producer writes
+template <bool EX> __device__ __forceinline__ constexpr unsigned frag_off0(int q) { return EX ? (unsigned)q * 32u : (unsigned)q * 16u; }
+template <bool EX> __device__ __forceinline__ constexpr unsigned frag_off1() { return EX ? 16u : 64u; }
+template <bool EX> __device__ __forceinline__ constexpr int elem_word(int k) { return (k / 32) * 32 + (EX ? (k % 32) : (k % 32) / 2); }
+
 // ---- XCD co-location of an exchange set -----------------------------------------------------------------------------------
 // The P workgroups of one (direction, row group) set are the only ones that exchange data.  With the XCD-aware grid (8 sets,
 // workgroup b -> set b % 8, slice b / 8) they normally land on ONE XCD, and then the publish stores need not write through to
@@ -90,7 +134,7 @@ __device__ __forceinline__ bool xcd_set_colocated(unsigned* tab, int set, int ps
 }
 
 // MODE, MT = 16-row batch tiles per workgroup, KS = 32-wide k chunks per wave
-template <int MODE, int MT, int KS>
+template <int MODE, int MT, int KS, bool EX = false>
 __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     using C = Cfg<MODE>;
     constexpr int G = C::G, U = C::U, NT = C::NT;
@@ -122,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 
     // ---- B fragments (hi / lo) of this workgroup's W_hh slice ---------------------------------
     const float* W = d == 0 ? p.w_hh : p.w_hh_r;
-    bf16x8 bh[KS][NT], bl[KS][NT];
+    u32x4 b0[KS][NT], b1[KS][NT];
     {
         const int n = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -130,29 +174,21 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int c = nt * 16 + n;
-                unsigned hw[4], lw[4];
+                float wv[8];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    unsigned h2[2], l2[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int k = kb + ks * 32 + q * 8 + jj * 2 + e;
-                        float v = 0.f;
-                        if (FWD) {
-                            const int gate = c / U, unit = u0 + c % U;
-                            if (c < G * U && unit < H && k < H) v = W[(int64_t)(gate * H + unit) * H + k];
-                        } else {
-                            const int unit = u0 + c, gate = k / Hp, ku = k - gate * Hp;
-                            if (c < U && unit < H && gate < G && ku < H) v = W[(int64_t)(gate * H + ku) * H + unit];
-                        }
-                        split_bf16(v, h2[e], l2[e]);
+                for (int e = 0; e < 8; ++e) {
+                    const int k = kb + ks * 32 + q * 8 + e;
+                    float v = 0.f;
+                    if (FWD) {
+                        const int gate = c / U, unit = u0 + c % U;
+                        if (c < G * U && unit < H && k < H) v = W[(int64_t)(gate * H + unit) * H + k];
+                    } else {
+                        const int unit = u0 + c, gate = k / Hp, ku = k - gate * Hp;
+                        if (c < U && unit < H && gate < G && ku < H) v = W[(int64_t)(gate * H + ku) * H + unit];
                     }
-                    hw[jj] = h2[0] | (h2[1] << 16);
-                    lw[jj] = l2[0] | (l2[1] << 16);
+                    wv[e] = v;
                 }
-                const u32x4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
-                bh[ks][nt] = __builtin_bit_cast(bf16x8, hv);
-                bl[ks][nt] = __builtin_bit_cast(bf16x8, lv);
+                frag_make<EX>(wv, b0[ks][nt], b1[ks][nt]);
             }
     }
 
@@ -234,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             for (int mt = 0; mt < MT; ++mt) {
                 const int gr = q0 + mt * 16 + m;
                 const int64_t xr = FWD ? ((int64_t)d * T + tp) * N + gr : ((int64_t)tp * N + gr) * 2 + d;
-                roff[mt] = (gr < NB && !(p.flags & 1)) ? (unsigned)((xr * KC + wave * KS) * 128 + q * 16) : OOB;
+                roff[mt] = (gr < NB && !(p.flags & 1)) ? (unsigned)((xr * KC + wave * KS) * 128) + frag_off0<EX>(q) : OOB;
             }
             const int klane = kb + q * 8;
             constexpr int CH = KS >= 2 ? 2 : 1;
@@ -254,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     for (int mt = 0; mt < MT; ++mt) {
                         const unsigned off = (klane + ks * 32 < Kxp) ? roff[mt] + (unsigned)(ks * 128) : OOB;
                         dh[j][mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, decltype(AUX)::value));
-                        dl[j][mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off + 64u), 0, decltype(AUX)::value));
+                        dl[j][mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off + frag_off1<EX>()), 0, decltype(AUX)::value));
                     }
                 }
             };
@@ -287,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                 const int64_t xr0 = FWD ? ((int64_t)d * T + tp) * N + q0 : ((int64_t)tp * N + q0) * 2 + d;
                 const int kprobe = kb + lane * U;
                 const bool probe = lane < nprod && kprobe < Kxp && !(p.flags & 1);
-                const unsigned* wp = xq + (xr0 * KC + kprobe / 32) * 32 + (kprobe % 32) / 2;
+                const unsigned* wp = xq + xr0 * KC * 32 + elem_word<EX>(kprobe);
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
                 while (true) {
@@ -330,14 +366,9 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     for (int j = 0; j < CH; ++j)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            const bf16x8 ah = __builtin_bit_cast(bf16x8, ahb[c % (DEPTH + 1)][j][mt]);
-                            const bf16x8 al = __builtin_bit_cast(bf16x8, alb[c % (DEPTH + 1)][j][mt]);
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) {
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c * CH + j][nt], acc[mt][nt], 0, 0, 0);
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c * CH + j][nt], acc[mt][nt], 0, 0, 0);
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c * CH + j][nt], acc[mt][nt], 0, 0, 0);
-                            }
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = mma_chunk<EX>(acc[mt][nt], ahb[c % (DEPTH + 1)][j][mt], alb[c % (DEPTH + 1)][j][mt], b0[c * CH + j][nt], b1[c * CH + j][nt]);
                         }
                 }
             }
@@ -426,19 +457,27 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             const int64_t rbase_w = xr * KC * 32;  // row start in 32-bit words
 #pragma unroll
             for (int g = 0; g < GX; ++g) {
-                unsigned h0, l0;
-                split_bf16(xv[g], h0, l0);
-                const unsigned mine = h0 | (l0 << 16);
-                const unsigned other = __shfl_xor(mine, 1, 64);
-                if (rowok && !(u & 1) && s + 1 < T && !(p.flags & 8)) {  // the last step's output is not exchanged
-                    const int k = g * Hp + unit;  // element index of the even unit of the pair within the exchanged row
-                    unsigned* wq = xq + rbase_w + (k / 32) * 32 + (k % 32) / 2;
-                    if (plain) {
-                        st_sc0_u32(wq, (mine & 0xFFFFu) | (other << 16));
-                        st_sc0_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
-                    } else {
-                        st_sc1_u32(wq, (mine & 0xFFFFu) | (other << 16));
-                        st_sc1_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
+                const int k = g * Hp + unit;  // element index within the exchanged row (split: of the even unit of the pair)
+                if constexpr (EX) {           // every (row, unit) lane publishes its own fp32 word (pad units: zeros)
+                    if (rowok && s + 1 < T && !(p.flags & 8)) {
+                        unsigned* wq = xq + rbase_w + k;
+                        if (plain) st_sc0_u32(wq, __float_as_uint(xv[g]));
+                        else st_sc1_u32(wq, __float_as_uint(xv[g]));
+                    }
+                } else {
+                    unsigned h0, l0;
+                    split_bf16(xv[g], h0, l0);
+                    const unsigned mine = h0 | (l0 << 16);
+                    const unsigned other = __shfl_xor(mine, 1, 64);
+                    if (rowok && !(u & 1) && s + 1 < T && !(p.flags & 8)) {  // the last step's output is not exchanged
+                        unsigned* wq = xq + rbase_w + (k / 32) * 32 + (k % 32) / 2;
+                        if (plain) {
+                            st_sc0_u32(wq, (mine & 0xFFFFu) | (other << 16));
+                            st_sc0_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
+                        } else {
+                            st_sc1_u32(wq, (mine & 0xFFFFu) | (other << 16));
+                            st_sc1_u32(wq + 16, (mine >> 16) | (other & 0xFFFF0000u));
+                        }
                     }
                 }
             }
@@ -471,38 +510,40 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     }
 }
 
-template <int MODE, int MT, int KS>
+template <int MODE, int MT, int KS, bool EX>
 int launch_sk(const RnnP& p, hipStream_t s) {
     dim3 grid(p.P, p.Q, 2);
     if (p.xcd) grid = dim3(p.P * p.Q * 2);
-    hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX>), grid, dim3(256), 0, s, p);
     return 0;
 }
 
-template <int MODE, int MT>
+template <int MODE, int MT, bool EX>
 int launch_split_mt(const RnnP& p, int ks_need, hipStream_t s) {
     constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD);
-    if (ks_need <= 1) return launch_sk<MODE, MT, 1>(p, s);
-    if (ks_need <= 2) return launch_sk<MODE, MT, 2>(p, s);
-    if (ks_need <= 4) return launch_sk<MODE, MT, 4>(p, s);
+    if (ks_need <= 1) return launch_sk<MODE, MT, 1, EX>(p, s);
+    if (ks_need <= 2) return launch_sk<MODE, MT, 2, EX>(p, s);
+    if (ks_need <= 4) return launch_sk<MODE, MT, 4, EX>(p, s);
     if constexpr (MODE == LSTM_FWD) return -1;  // H > 512: fall back to the fp32 kernel
     else {
-        if (ks_need <= 8) return launch_sk<MODE, MT, 8>(p, s);
-        if constexpr (FWD) return -1;
+        if (ks_need <= 8) return launch_sk<MODE, MT, 8, EX>(p, s);
+        if constexpr (FWD || EX) return -1;
         else {
-            if (ks_need <= 16) return launch_sk<MODE, MT, 16>(p, s);
-            if (ks_need <= 24) return launch_sk<MODE, MT, 24>(p, s);
+            if (ks_need <= 16) return launch_sk<MODE, MT, 16, EX>(p, s);
+            if (ks_need <= 24) return launch_sk<MODE, MT, 24, EX>(p, s);
             return -1;
         }
     }
 }
 
-// Same chunking of the batch as run() in rnn_kernel.h; falls back to the fp32 kernel (returns -1)
-// when the shape is outside the instantiated split kernels.
-template <int MODE>
+// Same chunking of the batch as run() in rnn_kernel.h; falls back to the counter-based fp32 kernel (returns -1)
+// when the shape is outside the instantiated kernels.  EX: exact-fp32 products (forward modes only).
+template <int MODE, bool EX = false>
 int run_split(const char* name, RnnP p, hipStream_t s) {
     using C = Cfg<MODE>;
     constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD);
+    if constexpr (EX && !FWD) return -1;
+    else {
     AAS_CHECK(p.T >= 1 && p.N >= 1 && p.H >= 1, "%s: bad sizes T=%d N=%d H=%d", name, p.T, p.N, p.H);
     const int cus = aas_rnn_cus();
     AAS_CHECK(cus > 0, "%s: no HIP device", name);
@@ -513,32 +554,39 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
     const int Hp = p.P * C::U;
     const int kxp = FWD ? Hp : C::G * Hp;
     const int ks_need = cdiv(kxp, 128);
-    const int64_t xbytes = (int64_t)2 * p.T * p.N * ((kxp + 31) / 32) * 128;  // rows x chunks x (64 B hi + 64 B lo)
+    const int64_t xbytes = (int64_t)2 * p.T * p.N * ((kxp + 31) / 32) * 128;  // rows x chunks x 128 B (64 B hi + 64 B lo, or 32 fp32)
     if (xbytes >= 0x7fffffffLL) return -1;
     int mt, rpg;
     pick_groups(p.P, p.N, cus, mt, rpg);
     p.rpg = rpg;
     const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
-    if (FWD) aas_note_fwd_h_planes(p.N <= qmax * rpg ? ((kxp + 31) / 32) * 128 : 0);   // (chunked launches re-poison the buffer)
+    if (FWD) aas_note_fwd_h_planes((!EX && p.N <= qmax * rpg) ? ((kxp + 31) / 32) * 128 : 0);   // (chunked launches re-poison the buffer)
     for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {
         p.n0 = n0;
         const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
         p.n1 = n0 + rows;
         p.Q = cdiv(rows, rpg);
-        // poison the exchange arrays (hi | lo): a word is valid data once it is no longer 0xFFFFFFFF (+ the XCC table)
+        // poison the exchange arrays: a word is valid data once it is no longer 0xFFFFFFFF (+ the XCC table)
         AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes + XCD_TAB_BYTES, s));
         p.xcd = (FWD && (p.Q * 2) % 8 == 0 && p.P * (p.Q * 2 / 8) <= 32 && rpg <= 8 && !(p.flags & 262144)) ? 1 : 0;   // (see rnn_fwd32_kernel.h)
-        int rc = (mt == 1) ? launch_split_mt<MODE, 1>(p, ks_need, s) : launch_split_mt<MODE, 2>(p, ks_need, s);
+        int rc = (mt == 1) ? launch_split_mt<MODE, 1, EX>(p, ks_need, s) : launch_split_mt<MODE, 2, EX>(p, ks_need, s);
         if (rc != 0) return -1;
         AAS_LAUNCH_CHECK(name);
     }
     return 0;
+    }
 }
 
+// The data-is-the-flag kernels in the arithmetic the library is set to (aas_set_precision): split-bf16, or exact fp32 (forward
+// modes; shapes they do not cover, and the all-gather BPTT, run on the counter-based fp32 kernel of rnn_kernel.h).
+// Debug bit 134217728: always the counter-based kernel in exact mode (the previous round's fp32 path, for A/B runs).
 template <int MODE>
 int run_any(const char* name, RnnP p, hipStream_t s) {
     if (p.xchg && aas_precision_value() != 0) {
-        const int rc = run_split<MODE>(name, p, s);
+        const int rc = run_split<MODE, false>(name, p, s);
+        if (rc >= 0) return rc;
+    } else if (p.xchg && !(aas_debug_flags_value() & 134217728)) {
+        const int rc = run_split<MODE, true>(name, p, s);
         if (rc >= 0) return rc;
     }
     aas_note_fwd_h_planes(0);

@@ -40,6 +40,8 @@ def main(config):
         if not dist.is_initialized():
             kw = dict(device_id=torch.device("cuda", local_rank)) if config.dist_backend == "nccl" else {}
             dist.init_process_group(config.dist_backend, **kw)
+    from . import ops
+    ops.set_precision(1 if getattr(config, "precision", "fp32") == "bf16x3" else 0)
     import numpy as np
     np.random.seed(config.random_seed)      # FeatSampler shuffles with numpy: identical batch order on every rank
     if config.gpu >= 0:

@@ -105,11 +105,13 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-_precision = [int(__import__('os').environ.get('AAS_PRECISION', '1'))]
+_precision = [int(__import__('os').environ.get('AAS_PRECISION', '0'))]
 
 
 def set_precision(mode):
-    """0 = exact fp32-input MFMA; 1 (library default) = split-bf16 operands (hi/lo, 3 MFMAs, ~1e-5 relative)."""
+    """0 (library default) = fp32 operands on fp32-input MFMA, the reference's arithmetic; 1 = split-bf16 fast mode (operands as
+    bf16 hi/lo, 3 MFMAs per product, ~2^-17 per product: narrower than fp32, inside the parity budget).  `--precision` of main.py /
+    am_train.py and the AAS_PRECISION environment variable select it for a whole run."""
     check(lib().aas_set_precision(int(mode)), "aas_set_precision")
     _precision[0] = int(mode)
 

@@ -59,9 +59,12 @@ int aas_rnn_last_fwd_h_pitch(void);
  * a persistent recurrent launch waits to become resident (an A/B switch: worth 0.4 ms / step at config 2 before the XCD-aware
  * recurrent launches, nothing since; trainers leave it off). */
 int aas_set_wgrad_wg_cap(int workgroups);
-/* Matrix-product operand precision: 0 = exact fp32-input MFMA; 1 (default) = split-bf16: each fp32 operand is
- * carried as bf16 hi + bf16 lo and the product as hi*hi + lo*hi + hi*lo with fp32 accumulation (~1e-5 relative,
- * fp32-class; 3 bf16 MFMAs instead of 16 fp32-MFMA issue slots). */
+/* Matrix-product operand precision of every GEMM and recurrent product queued after the call:
+ *   0 (default) = fp32: fp32 operands on fp32-input MFMA with fp32 accumulation - the arithmetic of the reference's cuDNN /
+ *                 cuBLAS fp32 path (trainer_AAS.py:69-73 moves the models to the GPU as fp32);
+ *   1           = split-bf16 fast mode: each fp32 operand is carried as bf16 hi + bf16 lo and the product as
+ *                 hi*hi + lo*hi + hi*lo with fp32 accumulation (16+ mantissa bits per operand, ~2^-17 per product: NARROWER than
+ *                 fp32, inside the 1e-3 / 1e-2 parity budget; 3 bf16 MFMAs instead of 16 fp32-MFMA issue slots). */
 int aas_set_precision(int mode);
 /* cap on the CUs one persistent recurrent launch occupies (0 = whole device): lets two independent chains of recurrent
  * launches (trainer_AAS.py:153-172: discriminator pass and acoustic pass) run side by side on two streams */
@@ -168,18 +171,19 @@ int aas_sqsum_f32(aasStream_t stream, const float* x, int64_t n, double* acc);
  *   gact  [2,T,N,H,4]  post-nonlinearity gates i,f,g,o per unit (saved for backward); cst [2,T,N,H] cell states
  *   sync  >= aas_rnn_sync_bytes() bytes of zero-initialisable device scratch (zeroed by the call)
  * Persistent kernel: one workgroup per (unit slice, batch group, direction); W_hh slices stay in registers for all T
- * steps.  `sync` holds the arrival counters of the exact-fp32 kernels (re-zeroed per launch) and, at word 1024, a
- * sticky timeout flag that every bounded spin of every kernel can raise.  With aas_set_precision(1) and an exchange
- * buffer, the forward launches all-gather h_t through poison-tagged 128-byte hi|lo lines (16- or 32-unit slices per
- * workgroup, chosen from the CU budget) and the backward launches run BPTT as a per-step reduce-scatter of K-split
- * partial dh through a tagged two-slot ring (csrc/rnn_bwd_rs_kernel.h); aas_set_rnn_cu_limit() bounds the grid of
- * the launches queued after it.
+ * steps.  `sync` holds the arrival counters of the counter-based fallback kernels (re-zeroed per launch) and, at word 1024, a
+ * sticky timeout flag that every bounded spin of every kernel can raise.  With an exchange buffer, the forward launches
+ * all-gather h_t through poison-tagged 128-byte lines (32 fp32 values, or bf16 hi|lo halves under aas_set_precision(1); 16- or
+ * 32-unit slices per workgroup, chosen from the CU budget) and the backward launches run BPTT as a per-step reduce-scatter of
+ * K-split partial dh through a tagged two-slot ring (csrc/rnn_bwd_rs_kernel.h), in BOTH precisions: fp32-input MFMA on the
+ * exchanged fp32 values, or three bf16 MFMA products on their hi / lo halves; aas_set_rnn_cu_limit() bounds the grid of the
+ * launches queued after it.
  */
 size_t aas_rnn_sync_bytes(void);
-/* bytes of the split-bf16 exchange scratch `xchg` (gates = 4 LSTM / 3 GRU; one buffer per stream that runs recurrent
- * launches); pass xchg = NULL to force the exact-fp32 kernels.  With aas_set_precision(1) and xchg != NULL the
- * exchanged values are bf16 hi/lo pairs (forward) or tagged fp32 partial sums (BPTT) and the recurrent products run
- * as hi*hi + lo*hi + hi*lo on bf16 MFMA (fp32 accumulate). */
+/* bytes of the exchange scratch `xchg` (gates = 4 LSTM / 3 GRU; one buffer per stream that runs recurrent launches); pass
+ * xchg = NULL to force the counter-based fp32 kernels of round 1 (csrc/rnn_kernel.h).  With xchg != NULL the exchanged values
+ * are fp32 words or bf16 hi/lo pairs (forward) and tagged fp32 partial sums (BPTT; the 2-bit step tag replaces the two low
+ * mantissa bits of a partial, rounded to nearest in the fp32 mode). */
 size_t aas_rnn_xchg_bytes(int T, int N, int H, int gates);
 int aas_lstm_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh,
                  const float* w_hh_rev, float* hout, float* gact, float* cst, void* sync, void* xchg);

@@ -324,3 +324,54 @@ def test_train_loop_dp_with_sharding_loader_and_syncbn_across_save_iter(gpu, tmp
         d_ = np.abs(got - want.detach().cpu().numpy())
         assert float((d_ > 2e-4).mean()) < 5e-3 and float(d_.max()) < 8.1e-3
     assert res[0][3] == pytest.approx(float(single.kt), rel=1e-3, abs=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ exact-fp32 recurrent kernels
+@pytest.mark.parametrize("half_chip", [True, False])
+@pytest.mark.parametrize("kind,T,N,H", [("lstm", 60, 30, 500), ("lstm", 60, 60, 500), ("gru", 40, 30, 1000), ("lstm", 25, 30, 64), ("gru", 9, 5, 24)])
+def test_exact_fp32_flag_kernels_vs_counter_kernels_and_xcd_variants(gpu, kind, T, N, H, half_chip):
+    """aas_set_precision(0) runs the data-is-the-flag kernels (all-gather forward, reduce-scatter BPTT) with fp32-input MFMA on fp32
+    exchange words.  Against the counter-based fp32 kernels of round 1 (debug bit 134217728: same products, another summation
+    order) they agree to fp32 rounding; their XCD-aware launch variants (262144 plain grid, 524288 write-through stores) are bit
+    identical; no timeout.  Config-2 layer shapes on half-chip and whole-chip grids, plus shapes only the fallback covers."""
+    from aas_enhancement_amd import _lib, ops
+    L = _lib.lib()
+    G = 4 if kind == "lstm" else 3
+    dev = "cuda"
+    g = torch.Generator().manual_seed(5)
+    R = lambda *shape, scale=1.0: (torch.randn(*shape, generator=g) * scale).to(dev)
+    ops.set_precision(0)
+    L.aas_set_rnn_cu_limit(ops.device_cus() // 2 if half_chip else 0)
+    try:
+        w = [R(G * H, H, scale=1.0 / H ** 0.5) for _ in range(4)]
+        pre = R(T, N, 2, G * H)
+        dy = R(T, N, H)
+        sync, xc = ops._sync_buf(torch.device(dev, 0)), ops._xchg_buf(torch.device(dev, 0), T, N, H, G)
+        s, p = _lib.stream(), _lib.ptr
+        res = {}
+        for fl in (134217728, 262144, 524288, 0):
+            L.aas_set_debug_flags(fl)
+            hout = torch.zeros(2, T, N, H, device=dev)
+            gact = torch.zeros(2, T, N, H, 4, device=dev)
+            cst = torch.zeros(2, T, N, H, device=dev)
+            dgx = torch.zeros(T, N, 2, G * H, device=dev)
+            dgh = torch.zeros(T, N, 2, G * H, device=dev)
+            if kind == "lstm":
+                ops.check(L.aas_lstm_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(cst), p(sync), p(xc)), "fwd")
+                ops.check(L.aas_lstm_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(gact), p(cst), p(dgx), p(sync), p(xc)), "bwd")
+            else:
+                ops.check(L.aas_gru_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(sync), p(xc)), "fwd")
+                ops.check(L.aas_gru_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(hout), p(gact), p(dgx), p(dgh), p(sync), p(xc)), "bwd")
+            torch.cuda.synchronize()
+            assert not ops.rnn_timeout_flag()
+            res[fl] = [t.clone() for t in (hout, gact, cst, dgx, dgh)]
+        for fl in (524288, 0):
+            for a, b in zip(res[fl], res[262144]):
+                assert torch.equal(a, b), (kind, fl)
+        for a, b in zip(res[0], res[134217728]):     # summation order differs (K split over waves / producers): fp32 rounding only
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, kind
+        assert torch.isfinite(res[0][3]).all() and res[0][3].abs().max() > 0
+    finally:
+        L.aas_set_debug_flags(0)
+        L.aas_set_rnn_cu_limit(0)
+        ops.set_precision(int(os.environ.get("AAS_PRECISION", "0")))
