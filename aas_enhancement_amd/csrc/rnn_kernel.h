@@ -27,7 +27,9 @@ constexpr int SYNC_BYTES = (SYNC_WORDS + 64) * 4;
 constexpr int STAMP_WORD = 1040;   // 8 x u64 phase totals of workgroup (0,0,0) wave 0 when debug flag 64 is set
 constexpr int CNT_STRIDE = 16;  // one 64-B line per counter
 
-enum Mode { LSTM_FWD = 0, LSTM_BWD = 1, GRU_FWD = 2, GRU_BWD = 3 };
+// RNN_* = the vanilla tanh recurrence h_t = tanh(W_ih x_t + W_hh h_{t-1}) (nn.RNN, the `rnn` entry of supported_rnns, model.py:12-17):
+// one "gate"; it runs on the counter-based kernel below in both precisions (no BASELINE configuration uses it)
+enum Mode { LSTM_FWD = 0, LSTM_BWD = 1, GRU_FWD = 2, GRU_BWD = 3, RNN_FWD = 4, RNN_BWD = 5 };
 
 struct RnnP {
     int T, N, H;
@@ -83,6 +85,8 @@ template <> struct Cfg<LSTM_FWD> { static constexpr int G = 4, U = 16, NT = 4; }
 template <> struct Cfg<GRU_FWD>  { static constexpr int G = 3, U = 16, NT = 3; };
 template <> struct Cfg<LSTM_BWD> { static constexpr int G = 4, U = 16, NT = 1; };
 template <> struct Cfg<GRU_BWD>  { static constexpr int G = 3, U = 16, NT = 1; };
+template <> struct Cfg<RNN_FWD>  { static constexpr int G = 1, U = 16, NT = 1; };
+template <> struct Cfg<RNN_BWD>  { static constexpr int G = 1, U = 16, NT = 1; };
 
 constexpr int red_ld(int NT, int U) {
     // row stride of the LDS reduction buffer: (ld mod 32) == 8 (U=8) or 16 (U=16) keeps the
@@ -99,8 +103,9 @@ template <int MODE, int MT, int KS, bool VEC>
 __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
     using C = Cfg<MODE>;
     constexpr int G = C::G, U = C::U, NT = C::NT;
-    constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD);
+    constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD || MODE == RNN_FWD);
     constexpr bool LSTM = (MODE == LSTM_FWD || MODE == LSTM_BWD);
+    constexpr bool GRU = (MODE == GRU_FWD || MODE == GRU_BWD);
     constexpr int LDR = red_ld(NT, U);
     constexpr int ROWS = MT * 16;
     constexpr int EPT = (ROWS * U + 255) / 256;  // (row, unit) elements per thread
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
                     if (LSTM) {
                         sav[i][4] = p.cst[((int64_t)d * T * N + tn) * H + unit];
                         sav[i][5] = hasq ? p.cst[qn] : 0.f;
-                    } else {
+                    } else if (GRU) {
                         sav[i][5] = hasq ? p.hout[qn] : 0.f;
                     }
                 }
@@ -328,6 +333,14 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
                 carry[i] = h;
                 st_sc1(p.hout + ((int64_t)d * T * N + tn) * H + unit, h);
                                 *reinterpret_cast<f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4) = (f32x4){rg, zg, ng, hn};
+            } else if (MODE == RNN_FWD) {
+                const float h = tanhf_(pin[i][0] + rs[0]);
+                st_sc1(p.hout + ((int64_t)d * T * N + tn) * H + unit, h);
+                *reinterpret_cast<f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4) = (f32x4){h, 0.f, 0.f, 0.f};
+            } else if (MODE == RNN_BWD) {
+                const float dh = pin[i][0] + rs[0];
+                const float h = sav[i][0];
+                st_sc1(p.dg1 + (tn * 2 + d) * GH + unit, dh * (1.f - h * h));
             } else if (MODE == LSTM_BWD) {
                 const float dh = pin[i][0] + rs[0];
                 const float ig = sav[i][0], fg = sav[i][1], gg = sav[i][2], og = sav[i][3];
@@ -372,7 +385,7 @@ int launch_k(const RnnP& p, hipStream_t s) {
 
 template <int MODE, int MT>
 int launch_mt(const RnnP& p, int ks_need, bool vec, hipStream_t s) {
-    constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD);
+    constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD || MODE == RNN_FWD);
     if (!vec) return ks_need <= 1 ? launch_k<MODE, MT, 1, false>(p, s) : -1;
     if (ks_need <= 1) return launch_k<MODE, MT, 1, true>(p, s);
     if (ks_need <= 2) return launch_k<MODE, MT, 2, true>(p, s);
@@ -381,7 +394,7 @@ int launch_mt(const RnnP& p, int ks_need, bool vec, hipStream_t s) {
     if constexpr (MODE == LSTM_FWD) return -1;  // H > 512 not instantiated for the LSTM forward slice width
     else {
         if (ks_need <= 16) return launch_k<MODE, MT, 16, true>(p, s);
-        if constexpr (FWD) return -1;
+        if constexpr (FWD || MODE == RNN_BWD) return -1;
         else {
             if (ks_need <= 32) return launch_k<MODE, MT, 32, true>(p, s);
             if (ks_need <= 48) return launch_k<MODE, MT, 48, true>(p, s);
@@ -403,7 +416,7 @@ inline void pick_groups(int P, int N, int cus, int& mt, int& rpg) {
 template <int MODE>
 int run(const char* name, RnnP p, hipStream_t s) {
     using C = Cfg<MODE>;
-    constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD);
+    constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD || MODE == RNN_FWD);
     AAS_CHECK(p.T >= 1 && p.N >= 1 && p.H >= 1, "%s: bad sizes T=%d N=%d H=%d", name, p.T, p.N, p.H);
     const int cus = aas_rnn_cus();
     AAS_CHECK(cus > 0, "%s: no HIP device", name);

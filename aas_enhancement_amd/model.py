@@ -27,8 +27,8 @@ def _rnn_kind(rnn_type):
         kind = rnn_type.lower()
     else:
         kind = supported_rnns_inv.get(rnn_type, getattr(rnn_type, "__name__", str(rnn_type)).lower())
-    if kind not in ("lstm", "gru"):
-        raise NotImplementedError("rnn_type %r: only bias-free bidirectional LSTM and GRU have HIP kernels" % (rnn_type,))
+    if kind not in ("lstm", "gru", "rnn"):
+        raise NotImplementedError("rnn_type %r: supported_rnns are lstm | gru | rnn (bias-free, bidirectional)" % (rnn_type,))
     return kind
 
 
@@ -49,7 +49,7 @@ class _RNNWeights(nn.Module):
 
     def __init__(self, input_size, hidden_size, kind):
         super().__init__()
-        g = 4 if kind == "lstm" else 3
+        g = {"lstm": 4, "gru": 3, "rnn": 1}[kind]
         self.kind, self.input_size, self.hidden_size = kind, input_size, hidden_size
         self.weight_ih_l0 = nn.Parameter(torch.empty(g * hidden_size, input_size))
         self.weight_hh_l0 = nn.Parameter(torch.empty(g * hidden_size, hidden_size))

@@ -659,6 +659,7 @@ def _wih_t_planes(w_ih, w_ih_r, GH, I):
     return wt
 
 
+_GATES = {"lstm": 4, "gru": 3, "rnn": 1}
 TN_WGRAD = [os.environ.get("AAS_TN_WGRAD", "1") == "1"]   # weight-gradient products from row-major planes (aas_gemm_planes_tn)
 
 
@@ -666,7 +667,7 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None):
     """x [T,N,I] -> (hout[2,T,N,H], gact, cst).  keep: a dict that receives what the layer's weight-gradient products can
     reuse: 'xp' = the input's operand planes, 'hx' / 'hpitch' = the forward launch's exchange buffer (h_t as planes)."""
     T, N, I = x.shape
-    G = 4 if kind == "lstm" else 3
+    G = _GATES[kind]
     H = w_hh.shape[1]
     dev = x.device
     pre = torch.empty((T, N, 2, G * H), device=dev, dtype=torch.float32)
@@ -693,12 +694,18 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None):
     hout = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
     gact = torch.empty((2, T, N, 4 * H), device=dev, dtype=torch.float32)
     sync = _sync_buf(dev)
+    if kind == "rnn":
+        keep = None
     if keep is not None and _precision[0] == 1:   # a buffer of the layer's own: it is read again by the backward pass
         xchg = torch.empty(int(lib().aas_rnn_xchg_bytes(T, N, H, G)), dtype=torch.uint8, device=dev)
     else:
         xchg = _xchg_buf(dev, T, N, H, G)
     rflops = 2.0 * 2 * T * N * H * G * H  # both directions, T steps of [N,H]x[H,G*H]
     lib().aas_set_rnn_launch_tag(2 * lid if lid else 1)
+    if kind == "rnn":
+        with _timed("rnn", "rnn_fwd[N=%d,H=%d]" % (N, H), rflops, T):
+            check(lib().aas_rnn_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync)), "aas_rnn_fwd")
+        return hout, gact, None
     if kind == "lstm":
         cst = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
         with _timed("rnn", "lstm_fwd[N=%d,H=%d]" % (N, H), rflops, T):
@@ -719,7 +726,7 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None):
 def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residual, need_dx=True, need_dw=True, rs=None,
                direct=None, lid=0, keep=None):
     T, N, I = x.shape
-    G = 4 if kind == "lstm" else 3
+    G = _GATES[kind]
     H = w_hh.shape[1]
     GH = G * H
     dev = x.device
@@ -727,7 +734,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     sync = _sync_buf(dev)
     xchg = _xchg_buf(dev, T, N, H, G)
     R = T * N
-    use_planes = (_precision[0] == 1 and PLANES_BWD[0] and R >= 1024 and H >= 64 and I >= 64 and GH % 8 == 0
+    use_planes = (_precision[0] == 1 and kind != "rnn" and PLANES_BWD[0] and R >= 1024 and H >= 64 and I >= 64 and GH % 8 == 0
                   and w_ih_r.data_ptr() != w_ih.data_ptr() and (w_ih_r.data_ptr() - w_ih.data_ptr()) % 4 == 0)
     rflops = 2.0 * 2 * T * N * H * GH
     lib().aas_set_rnn_launch_tag(2 * lid + 1 if lid else 1)
@@ -754,7 +761,11 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
             check(rc, "aas_%s_bwd_planes" % kind)
     if dgp is None:
         dgx = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
-        if kind == "lstm":
+        if kind == "rnn":
+            with _timed("rnn", "rnn_bwd[N=%d,H=%d]" % (N, H), rflops, T):
+                check(lib().aas_rnn_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(dgx), ptr(sync)), "aas_rnn_bwd")
+            dgh = dgx
+        elif kind == "lstm":
             with _timed("rnn", "lstm_bwd[N=%d,H=%d]" % (N, H), rflops, T):
                 check(lib().aas_lstm_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), ptr(dgx),
                                          ptr(sync), ptr(xchg)), "aas_lstm_bwd")

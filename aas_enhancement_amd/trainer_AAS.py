@@ -448,7 +448,9 @@ class Trainer(object):
             # down, beside E's backward half of the chip is free.  Not all of them: E's backward phase has room for about two D
             # layers on top of E's own (16.7 -> 16.1 ms with two, 16.2 with three, 16.5 with one).
             ops.DEFER_LIDS.clear()
-            for net, env, dflt in ((self.D, "AAS_DEFER_D_LAYERS", 2), (self.ASR, "AAS_DEFER_A_LAYERS", 0)):
+            # (fp32 mode: the fp32 weight-gradient GEMMs keep their stream busy for the whole backward phase - 13 ms of launches
+            #  per step - so holding any of them back only lengthens the tail behind E's last BPTT launch: 32.3 vs 31.7 ms)
+            for net, env, dflt in ((self.D, "AAS_DEFER_D_LAYERS", 2 if ops.get_precision() == 1 else 0), (self.ASR, "AAS_DEFER_A_LAYERS", 0)):
                 ndef = int(os.environ.get(env, str(dflt)))
                 if ndef > 0:
                     lids = [m._aas_layer_id for m in net.modules() if getattr(m, "_aas_layer_id", None) is not None]

@@ -202,6 +202,16 @@ int aas_lstm_bwd_planes(aasStream_t stream, int T, int N, int H, const float* dy
 int aas_gru_bwd_planes(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
                        const float* hout, const float* gact, void* dgx_planes, void* dgh_planes, int Kp, void* sync, void* xchg);
 
+/* nn.RNN(nonlinearity='tanh', bias=False, bidirectional=True) - the `rnn` entry of supported_rnns (model.py:12-17), selectable with
+ * --rnn_type rnn (config.py:44):  h_t = tanh(pre_t + W_hh h_{t-1}).
+ *   pre [T,N,2,H] (input projections of both directions), w_hh / w_hh_rev [H,H], hout [2,T,N,H]; gact [2,T,N,H,4] scratch that the
+ *   backward pass reads back (slot 0 = h_t).  aas_rnn_bwd: dy [T,N,H] = gradient wrt (h_fwd + h_bwd); dpre [T,N,2,H] receives
+ *   d(loss)/d(pre).  fp32-input MFMA in both precision modes (counter-based persistent kernel). */
+int aas_rnn_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh, const float* w_hh_rev, float* hout,
+                float* gact, void* sync);
+int aas_rnn_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev, const float* gact,
+                float* dpre, void* sync);
+
 /* Bidirectional bias-free GRU (cuDNN RNN under model.py:73-74,83), gate order r,z,n:
  *   pre [T,N,2,3H]; w_hh, w_hh_rev [3H,H]; hout [2,T,N,H];
  *   gact [2,T,N,H,4] saves r, z, n and hn = (W_hn h_{t-1}) per unit for backward. */

@@ -58,9 +58,9 @@ def _coverage(log, flats, names):
     return out
 
 
-def _aas_worker(port, q):
+def _aas_worker(port, q, precision="1"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", AAS_DP_FORCE="1",
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", AAS_PRECISION=precision)
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -96,10 +96,10 @@ def _aas_worker(port, q):
         dist.destroy_process_group()
 
 
-def _run_child(target):
+def _run_child(target, *extra):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=target, args=(_free_port(), q))
+    p = ctx.Process(target=target, args=(_free_port(), q) + extra)
     p.start()
     out = q.get(timeout=900)
     p.join(timeout=120)
@@ -108,12 +108,13 @@ def _run_child(target):
     return out
 
 
-def test_aas_async_steps_on_one_rank_rccl_config2_buckets_and_goldens():
+@pytest.mark.parametrize("precision", ["0", "1"], ids=["fp32", "splitbf16"])
+def test_aas_async_steps_on_one_rank_rccl_config2_buckets_and_goldens(precision):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from tests.helpers import load
     z = load("f3_aas_config2.npz")
-    out = _run_child(_aas_worker)
+    out = _run_child(_aas_worker, precision)
     assert not out["timeout"], "a persistent recurrent launch timed out beside the RCCL kernels"
     for it, r in enumerate(out["res"]):
         for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt", "conv_measure"):

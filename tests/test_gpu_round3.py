@@ -375,3 +375,76 @@ def test_exact_fp32_flag_kernels_vs_counter_kernels_and_xcd_variants(gpu, kind, 
         L.aas_set_debug_flags(0)
         L.aas_set_rnn_cu_limit(0)
         ops.set_precision(int(os.environ.get("AAS_PRECISION", "0")))
+
+
+# ------------------------------------------------------------------------------------------------ vanilla `rnn` kind
+@pytest.fixture(params=[1, 0], ids=["splitbf16", "fp32"])
+def precision(request, gpu):
+    from aas_enhancement_amd import ops
+    ops.set_precision(request.param)
+    yield request.param
+    ops.set_precision(int(os.environ.get("AAS_PRECISION", "0")))
+
+
+@pytest.mark.parametrize("tag", ["s", "m", "l"])
+def test_brnn_vanilla_rnn_golden(gpu, precision, tag):
+    """F9: the reference's BRNN with nn.RNN (supported_rnns['rnn'], model.py:12-17,88-105): forward, input gradient and all four
+    weight gradients; `l` is the enhancer's layer shape (T=60, N=30, H=500) checked on samples and norms."""
+    from aas_enhancement_amd import ops, prng
+    from aas_enhancement_amd.model import BRNN
+    from tests.helpers import rel_err, sub
+    z = load("f9_rnn_kind.npz")
+    p = "brnn_rnn_%s." % tag
+    ft, gt = (1e-5, 1e-4) if precision == 0 else (1e-4, 5e-4)
+    if tag != "l":
+        H = z[p + "x"].shape[2]
+        m = BRNN(H, H, nn.RNN, bidirectional=True)
+        load_sd(m, sub(z, p + "w."))
+        m.cuda()
+        x = torch.from_numpy(z[p + "x"]).cuda().requires_grad_(True)
+        y = m(x)
+        y.backward(torch.from_numpy(z[p + "gy"]).cuda())
+        assert rel_err(y, z[p + "y"]) < ft and rel_err(x.grad, z[p + "gx"]) < gt
+        for k, v in m.named_parameters():
+            assert rel_err(v.grad, z[p + "gw." + k]) < gt, k
+    else:
+        T, N, H = [int(v) for v in z[p + "dims"]]
+        s_w, s_x, s_g = [int(v) for v in z[p + "seeds"]]
+        m = _fill(BRNN(H, H, nn.RNN, bidirectional=True), s_w).cuda()
+        x = torch.from_numpy(prng.normal(s_x, (T, N, H), 0.0, 0.5)).cuda().requires_grad_(True)
+        y = m(x)
+        y.backward(torch.from_numpy(prng.normal(s_g, (T, N, H))).cuda())
+        idx = torch.from_numpy(z[p + "idx"]).cuda()
+        for got, key, tol in ((y.detach(), "y", ft), (x.grad, "gx", gt)):
+            ref = z[p + key + "_samples"]
+            assert np.abs(got.reshape(-1)[idx].cpu().numpy() - ref).max() < 4 * tol * np.abs(ref).max(), key
+            assert float(got.double().norm()) == pytest.approx(float(z[p + key + "_norm"]), rel=4 * tol), key
+        for k, v in m.named_parameters():
+            assert float(v.grad.double().norm()) == pytest.approx(float(z[p + "gw_norm." + k]), rel=4 * gt), k
+            ref = z[p + "gw_samples." + k]
+            got = v.grad.reshape(-1)[idx % v.numel()].cpu().numpy()
+            assert np.abs(got - ref).max() < 4 * gt * np.abs(ref).max() + 1e-7, k
+    assert not ops.rnn_timeout_flag()
+
+
+def test_stacked_brnn_vanilla_rnn_golden_and_dce_step(gpu, precision):
+    """stackedBRNN(rnn_type=nn.RNN) (model.py:203-231) forward / backward against the reference module, then a DCE step with
+    `--rnn_type rnn` through the trainer (flat buffers, side-stream weight gradients)."""
+    from aas_enhancement_amd.model import stackedBRNN, supported_rnns
+    from aas_enhancement_amd.trainer_DCE import Trainer
+    from tests.helpers import rel_err, sub
+    z = load("f9_rnn_kind.npz")
+    p = "stacked_rnn."
+    G = stackedBRNN(I=6, O=6, H=10, L=4, rnn_type=nn.RNN)
+    load_sd(G, sub(z, p + "sd."))
+    G.cuda()
+    x = torch.from_numpy(z[p + "x"]).cuda().requires_grad_(True)
+    y = G(x)
+    y.backward(torch.from_numpy(z[p + "gy"]).cuda())
+    ft, gt = (2e-5, 2e-4) if precision == 0 else (2e-4, 1e-3)
+    assert rel_err(y, z[p + "y"]) < ft and rel_err(x.grad, z[p + "gx"]) < gt
+    for k, v in G.named_parameters():
+        assert rel_err(v.grad, z[p + "gw." + k]) < gt, k
+    tr = Trainer(cfg(lr=1e-3, nFeat=8, rnn_size=16, rnn_type="rnn", rnn_layers=2), None, models=(_fill(stackedBRNN(I=8, H=16, L=2, rnn_type=supported_rnns["rnn"]), 77),))
+    losses = [float(tr.train_step(_tiny_paired(880, lens=[40, 36, 30, 22]), it)["dce"]) for it in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]

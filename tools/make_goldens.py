@@ -573,15 +573,60 @@ def f8_host_side():
     print("F8 keys", len(out), [s[0] for s in strings])
 
 
+def f9_rnn_kind():
+    """F9: the vanilla `rnn` kind of supported_rnns (model.py:12-17): the reference's BRNN with nn.RNN (tanh, bias-free,
+    directions summed; model.py:88-105) at three sizes - the last at the enhancer's layer shape - and a whole
+    stackedBRNN(rnn_type=nn.RNN) forward / backward (model.py:203-231)."""
+    out = {}
+    torch.manual_seed(0)
+    for tag, (T, N, H) in dict(s=(7, 2, 5), m=(23, 5, 24), l=(60, 30, 500)).items():
+        m = REF.BRNN(H, H, rnn_type=nn.RNN, bidirectional=True)
+        load_weights(m, 700 + T)
+        x = t(prng.normal(711 + T, (T, N, H), 0.0, 0.5)).requires_grad_(True)
+        y = m(x)
+        gy = t(prng.normal(712 + T, (T, N, H)))
+        y.backward(gy)
+        p = "brnn_rnn_%s." % tag
+        if tag == "l":     # at size: samples and norms only
+            idx = prng.randint(713, (256,), 0, T * N * H - 1).astype(np.int64)
+            out[p + "dims"] = np.asarray([T, N, H])
+            out[p + "seeds"] = np.asarray([700 + T, 711 + T, 712 + T])
+            out[p + "idx"] = idx
+            out[p + "y_samples"], out[p + "gx_samples"] = y.detach().reshape(-1)[idx].numpy(), x.grad.reshape(-1)[idx].numpy()
+            out[p + "y_norm"], out[p + "gx_norm"] = float(y.detach().double().norm()), float(x.grad.double().norm())
+            for k, v in m.named_parameters():
+                out[p + "gw_norm." + k] = float(v.grad.double().norm())
+                out[p + "gw_samples." + k] = v.grad.reshape(-1)[idx % v.numel()].numpy()
+        else:
+            out[p + "x"], out[p + "y"], out[p + "gy"], out[p + "gx"] = x.detach().numpy(), y.detach().numpy(), gy.numpy(), x.grad.numpy()
+            for k, v in m.named_parameters():
+                out[p + "w." + k] = v.detach().numpy()
+                out[p + "gw." + k] = v.grad.numpy()
+    G = REF.stackedBRNN(I=6, O=6, H=10, L=4, rnn_type=nn.RNN)
+    load_weights(G, 750)
+    x = t(prng.uniform(751, (3, 6, 17), 0.0, 6.0)).requires_grad_(True)
+    y = G(x)
+    gy = t(prng.normal(752, tuple(y.shape)))
+    y.backward(gy)
+    p = "stacked_rnn."
+    out[p + "x"], out[p + "y"], out[p + "gy"], out[p + "gx"] = x.detach().numpy(), y.detach().numpy(), gy.numpy(), x.grad.numpy()
+    for k, v in G.state_dict().items():
+        out[p + "sd." + k] = v.numpy().copy()
+    for k, v in G.named_parameters():
+        out[p + "gw." + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "f9_rnn_kind.npz"), **out)
+    print("F9 keys", len(out))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip F3 (config 2, minutes of CPU)")
-    ap.add_argument("--only", default="", help="comma list of fixtures to (re)generate: f1,f2,f3,f4,f5,f6,f7,f8")
+    ap.add_argument("--only", default="", help="comma list of fixtures to (re)generate: f1,f2,f3,f4,f5,f6,f7,f8,f9")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     if a.only:
         table = dict(f1=f1_tiny, f2=f2_dce, f3=f3_config2, f4=f4_ops, f5=f5_fsegan_am, f6=f6_fsegan_config4,
-                     f7=f7_am_config5, f8=f8_host_side)
+                     f7=f7_am_config5, f8=f8_host_side, f9=f9_rnn_kind)
         for k in a.only.split(","):
             table[k]()
         sys.exit(0)
@@ -590,6 +635,7 @@ if __name__ == "__main__":
     f5_fsegan_am()
     f2_dce()
     f8_host_side()
+    f9_rnn_kind()
     if not a.skip_big:
         f3_config2()
         f6_fsegan_config4()

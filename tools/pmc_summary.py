@@ -29,7 +29,31 @@ def collect(d, counter):
     return per
 
 
+# launch classes of bench.py's roofline object (ops.Profiler names) -> kernel-name prefixes of either arithmetic mode
+# (persistent grids: P x Q x 2 x threads; the same kernel at two batch sizes has the same grid here, so one entry serves both)
+CLASS_PATTERNS = {
+    "lstm_bwd[N=60,H=500]": "rnn_bwd_rs_kernel<1, ", "lstm_bwd[N=30,H=500]": "rnn_bwd_rs_kernel<1, ", "gru_bwd[N=30,H=1000]": "rnn_bwd_rs_kernel<3, ",
+    "lstm_fwd[N=60,H=500]": "rnn_fwd32_kernel<0, ", "lstm_fwd[N=30,H=500]": "rnn_split_kernel<0, ", "gru_fwd[N=30,H=1000]": "rnn_fwd32_kernel<2, ",
+    "gemm_planes_wgrad": "gemm_planes_tn_kernel<", "gemm_planes": "gemm_planes_kernel<256, 256",
+    "gemm_tn": "gemm_f32_kernel<false, false", "gemm_nn": "gemm_f32_kernel<true, false", "gemm_nt": "gemm_f32_kernel<true, true"}
+
+
+def classes_of(kernels):
+    by_class = {}
+    for cname, pat in CLASS_PATTERNS.items():
+        hit = [(k, v) for k, v in kernels.items() if k.startswith(pat)]
+        if hit:
+            k, v = max(hit, key=lambda kv: kv[1]["dispatches"])
+            by_class[cname] = dict(v, kernel=k)
+    return by_class
+
+
 def main():
+    if sys.argv[1] == "--rebuild":      # recompute by_class of an existing summary (kernel names changed, same raw numbers)
+        j = json.load(open(sys.argv[2]))
+        j["by_class"] = classes_of(j["kernels"])
+        json.dump(j, open(sys.argv[2], "w"), indent=1)
+        return
     fdir, wdir, out, cmd = sys.argv[1:5]
     fe, wr = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
     kernels = {}
@@ -40,16 +64,7 @@ def main():
         wa = sum(w) / len(w) if w else 0.0
         kernels[name] = {"FETCH_SIZE_KiB_avg": fa, "WRITE_SIZE_KiB_avg": wa, "dispatches": max(len(f), len(w)),
                          "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
-    # launch classes of bench.py's roofline object (ops.Profiler names) -> kernel instances (persistent grids: P x Q x 2 x threads)
-    classes = {"lstm_bwd[N=60,H=500]": "rnn_bwd_rs_kernel<1, 32, 4, -1> grid=65536", "lstm_bwd[N=30,H=500]": "rnn_bwd_rs_kernel<1, 32, 4, -1> grid=65536",
-               "gru_bwd[N=30,H=1000]": "rnn_bwd_rs_kernel<3, 32, 8, -1> grid=65536", "lstm_fwd[N=60,H=500]": "rnn_fwd32_kernel<0, 2, 0> grid=65536",
-               "lstm_fwd[N=30,H=500]": "rnn_split_kernel<0, 1, 4> grid=65536", "gru_fwd[N=30,H=1000]": "rnn_fwd32_kernel<2, 4, 2> grid=65536",
-               "gemm_planes_wgrad": "gemm_planes_tn_kernel<128, 128, 4, 2>", "gemm_planes": "gemm_planes_kernel<256, 256, 4, 2, true>"}
-    by_class = {}
-    for cname, kname in classes.items():
-        hit = [v for k, v in kernels.items() if k == kname or (kname.split(" grid=")[0] == k.split(" grid=")[0] and cname.startswith(("lstm", "gru")) and len([x for x in kernels if x.split(" grid=")[0] == k.split(" grid=")[0]]) == 1)]
-        if hit:
-            by_class[cname] = dict(hit[0], kernel=kname)
+    by_class = classes_of(kernels)
     total = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in kernels.values())
     steps = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     json.dump({"total_hbm_bytes": total, "steps_in_run": steps, "hbm_bytes_per_step": (total / steps) if steps else None, "by_class": by_class, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `%s`" % cmd,
