@@ -460,7 +460,7 @@ extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, c
     const bool split_prec = aas_precision_value() != 0;
     // TN (weight gradients: tiny MxN, deep K) wants >= 2 blocks per CU to hide the k-step latency; its atomic
     // epilogue traffic (splitk x MxN x 4 B at ~1.3 TB/s) stays far below the time saved
-    const int target = (split_prec && mode == AAS_GEMM_TN) ? 512 : 256;
+    const int target = ((split_prec || (p.flags & 268435456)) && mode == AAS_GEMM_TN) ? 512 : 256;
     if (batch == 1 && blocks < (target * 3) / 4 && K >= 1024) {
         int want = (target + blocks - 1) / blocks;
         int maxs = K / 256;
