@@ -28,6 +28,7 @@ SIGNATURES = {
     "aas_set_rnn_cu_limit": [c_int],
     "aas_gemm_f32": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                      c_int, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_i64],
+    "aas_gemm_tn_rowscaled_f32": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_int],
     "aas_gemm_planes": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                         c_int, c_i64, c_i64, c_i64],
     "aas_gemm_planes_multi": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64],

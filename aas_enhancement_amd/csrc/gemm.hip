@@ -26,6 +26,8 @@ struct GemmP {
     int64_t kouterB;
     int splitk;
     int flags;  // ablation bits (aas_set_debug_flags): 16 skip MFMA, 32 skip LDS staging, 64 skip global loads
+    const float* kscale;  // TN, fp32 kernel: reduction row r of A is scaled by kscale[r % knb] while it is staged (per-utterance
+    int knb;              // weights of a weight-gradient product: no separate scaling pass over d(gates)); null = none
 };
 
 __device__ __forceinline__ int64_t krow_addr(int r, int kdiv, int64_t kouter, int64_t ld) {
@@ -70,7 +72,8 @@ __device__ __forceinline__ void store_kcontig(float (*S)[LDT], int tid, const f3
 // row-contiguous operand ([K, cols], cols contiguous): tile [16 k][128 cols]
 template <bool VEC>
 __device__ __forceinline__ void load_rcontig(const float* __restrict__ base, int64_t ld, int kdiv, int64_t kouter,
-                                             int c0, int cmax, int k0, int kend, int tid, f32x4 (&r)[2]) {
+                                             int c0, int cmax, int k0, int kend, int tid, f32x4 (&r)[2],
+                                             const float* __restrict__ kscale = nullptr, int knb = 1) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int idx = tid + i * 256;
@@ -86,6 +89,10 @@ __device__ __forceinline__ void load_rcontig(const float* __restrict__ base, int
                 if (gc + 1 < cmax) v.y = p[1];
                 if (gc + 2 < cmax) v.z = p[2];
                 if (gc + 3 < cmax) v.w = p[3];
+            }
+            if (kscale) {
+                const float sc = kscale[gk % knb];
+                v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
             }
         }
         r[i] = v;
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     f32x4 ra[2], rb[2];
     auto gload = [&](int k0) {
         if (A_KC) load_kcontig<VECA>(A, p.lda, m0, p.M, k0, kend, tid, ra);
-        else load_rcontig<VECA>(A, p.lda, p.kdivA, p.kouterA, m0, p.M, k0, kend, tid, ra);
+        else load_rcontig<VECA>(A, p.lda, p.kdivA, p.kouterA, m0, p.M, k0, kend, tid, ra, p.kscale, p.knb);
         if (B_KC) load_kcontig<VECB>(B, p.ldb, n0, p.N, k0, kend, tid, rb);
         else load_rcontig<VECB>(B, p.ldb, p.kdivB, p.kouterB, n0, p.N, k0, kend, tid, rb);
     };
@@ -436,11 +443,11 @@ void launch(const GemmP& p, bool va, bool vb, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, const float* A, int64_t lda,
-                            const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
-                            const float* addend, int64_t ldd, int accumulate, int batch, int64_t strideA,
-                            int64_t strideB, int64_t strideC, int kdivA, int64_t kouterA, int kdivB,
-                            int64_t kouterB) {
+static int gemm_f32_impl(aasStream_t stream, int mode, int M, int N, int K, const float* A, int64_t lda,
+                         const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                         const float* addend, int64_t ldd, int accumulate, int batch, int64_t strideA,
+                         int64_t strideB, int64_t strideC, int kdivA, int64_t kouterA, int kdivB,
+                         int64_t kouterB, const float* kscale, int knb) {
     AAS_CHECK(mode >= 0 && mode <= 2, "aas_gemm_f32: bad mode %d", mode);
     AAS_CHECK(M >= 0 && N >= 0 && K >= 0 && batch >= 1, "aas_gemm_f32: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
     AAS_CHECK(A && B && C, "aas_gemm_f32: null operand");
@@ -454,6 +461,7 @@ extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, c
     p.kdivA = kdivA; p.kouterA = kouterA; p.kdivB = kdivB; p.kouterB = kouterB;
     p.splitk = 1;
     p.flags = aas_debug_flags_value();
+    p.kscale = kscale; p.knb = knb > 0 ? knb : 1;
     dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
     // split-K (atomic epilogue) when the MxN grid cannot fill the 256 CUs and K is deep
     int blocks = grid.x * grid.y;
@@ -501,4 +509,21 @@ extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, c
     AAS_CHECK(rc == 0, "aas_gemm_f32: could not raise the dynamic LDS limit for the split-bf16 kernel");
     AAS_LAUNCH_CHECK("aas_gemm_f32");
     return 0;
+}
+
+extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, const float* A, int64_t lda,
+                            const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                            const float* addend, int64_t ldd, int accumulate, int batch, int64_t strideA,
+                            int64_t strideB, int64_t strideC, int kdivA, int64_t kouterA, int kdivB,
+                            int64_t kouterB) {
+    return gemm_f32_impl(stream, mode, M, N, K, A, lda, B, ldb, C, ldc, bias, addend, ldd, accumulate, batch, strideA, strideB, strideC,
+                         kdivA, kouterA, kdivB, kouterB, nullptr, 0);
+}
+
+extern "C" int aas_gemm_tn_rowscaled_f32(aasStream_t stream, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                         float* C, int64_t ldc, int accumulate, const float* d_kscale, int knb) {
+    AAS_CHECK(d_kscale && knb > 0, "aas_gemm_tn_rowscaled_f32: scale vector missing");
+    AAS_CHECK(aas_precision_value() == 0, "aas_gemm_tn_rowscaled_f32: fp32 mode only (the split-bf16 path scales through its own operands)");
+    return gemm_f32_impl(stream, AAS_GEMM_TN, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, accumulate, 1, 0, 0, 0, 0, 0, 0, 0,
+                         d_kscale, knb);
 }

@@ -660,6 +660,11 @@ def _wih_t_planes(w_ih, w_ih_r, GH, I):
 
 
 _GATES = {"lstm": 4, "gru": 3, "rnn": 1}
+# fp32 mode: per-utterance weights folded into the weight-gradient GEMM (aas_gemm_tn_rowscaled_f32) instead of a scaling pass over
+# d(gates).  Measured on one box (tools/ab.sh): 32.5-32.6 ms / step with the fold against 31.8 without - the products then start right
+# behind the BPTT launch and take CUs from the input-gradient GEMM on the critical path, and the per-row weight lengthens the TN
+# kernel's prefetch - so it is off by default.
+_TN_FOLD = os.environ.get("AAS_TN_FOLD", "0") == "1"
 TN_WGRAD = [os.environ.get("AAS_TN_WGRAD", "1") == "1"]   # weight-gradient products from row-major planes (aas_gemm_planes_tn)
 
 
@@ -876,18 +881,26 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
             if wgrads_tn(out):
                 return
             return wgrads_planes(out)
+        tn = lambda *a_, **k_: gemm(TN, *a_, **k_)
         if rs is not None:  # per-utterance weights on the parameter gradients only (dx used the unscaled d(gates))
-            scale_rows(dgx, rs, N, out=dgx)
-            if dgh is not dgx:
-                scale_rows(dgh, rs, N, out=dgh)
-        gemm(TN, GH, I, R, dgx, 2 * GH, x2, I, out[0], I, accumulate=acc)
-        gemm(TN, GH, I, R, dgx, 2 * GH, x2, I, out[2], I, a_off=GH, accumulate=acc)
+            if _precision[0] == 0 and _TN_FOLD and all(o.is_contiguous() for o in out):
+                # fp32 mode: the weight rides on the reduction rows while the GEMM stages them (no pass over d(gates))
+                def tn(M_, N_, K_, A_, lda_, B_, ldb_, C_, ldc_, a_off=0, b_off=0, accumulate=False):
+                    with _timed("gemm", "gemm_tn", 2.0 * M_ * N_ * K_):
+                        check(lib().aas_gemm_tn_rowscaled_f32(stream(), M_, N_, K_, A_.data_ptr() + 4 * a_off, lda_, B_.data_ptr() + 4 * b_off, ldb_,
+                                                              C_.data_ptr(), ldc_, int(accumulate), ptr(rs), N), "aas_gemm_tn_rowscaled_f32")
+            else:
+                scale_rows(dgx, rs, N, out=dgx)
+                if dgh is not dgx:
+                    scale_rows(dgh, rs, N, out=dgh)
+        tn(GH, I, R, dgx, 2 * GH, x2, I, out[0], I, accumulate=acc)
+        tn(GH, I, R, dgx, 2 * GH, x2, I, out[2], I, a_off=GH, accumulate=acc)
         if T > 1:
             Rm = (T - 1) * N
-            # forward direction: sum_{t>=1} dg[t,:,0,:]^T h_f[t-1]
-            gemm(TN, GH, H, Rm, dgh, 2 * GH, hout, H, out[1], H, a_off=N * 2 * GH, accumulate=acc)
+            # forward direction: sum_{t>=1} dg[t,:,0,:]^T h_f[t-1]   (a_off is a whole number of time steps: row r still belongs to utterance r % N)
+            tn(GH, H, Rm, dgh, 2 * GH, hout, H, out[1], H, a_off=N * 2 * GH, accumulate=acc)
             # reverse direction: sum_{t<=T-2} dg[t,:,1,:]^T h_r[t+1]
-            gemm(TN, GH, H, Rm, dgh, 2 * GH, hout, H, out[3], H, a_off=GH, b_off=T * N * H + N * H, accumulate=acc)
+            tn(GH, H, Rm, dgh, 2 * GH, hout, H, out[3], H, a_off=GH, b_off=T * N * H + N * H, accumulate=acc)
         elif not acc:
             out[1].zero_()
             out[3].zero_()
@@ -897,7 +910,11 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         side = wgrad_stream(dev)
         # (plane path only: the fp32 path scales d(gates) IN PLACE for the per-utterance weights, which must not overlap the
         #  input-gradient GEMM that reads them)
-        ev = ev_bptt if (use_planes and T > 1 and os.environ.get("AAS_WGRAD_EARLY", "1") == "1") else torch.cuda.Event()
+        # fp32 mode: with the weights folded into the GEMM (or none to apply) nothing mutates d(gates) either, so the products may
+        # start right behind the BPTT launch there too
+        fold_ok = _precision[0] == 0 and _TN_FOLD and all(o.is_contiguous() for o in direct)
+        no_mutation = use_planes or rs is None or fold_ok
+        ev = ev_bptt if (no_mutation and T > 1 and os.environ.get("AAS_WGRAD_EARLY", "1") == "1") else torch.cuda.Event()
         if ev is not ev_bptt:
             ev.record(main)
         hook = WGRAD_HOOK[0]

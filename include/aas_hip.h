@@ -90,6 +90,11 @@ int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K,
                  const float* bias, const float* addend, int64_t ldd, int accumulate,
                  int batch, int64_t strideA, int64_t strideB, int64_t strideC,
                  int kdivA, int64_t kouterA, int kdivB, int64_t kouterB);
+/* C[M,N] (+)= sum_r kscale[r % knb] * A[r,M]^T B[r,N]   (fp32 mode): the TN product of aas_gemm_f32 with a per-reduction-row weight
+ * applied while A is staged - the D-step weight gradients of a batched [enhanced; clean] discriminator pass carry the BEGAN factor
+ * (-kt) on the enhanced utterances only (trainer_AAS.py:152-160); r = (t, n) time-major, knb = utterances per time step. */
+int aas_gemm_tn_rowscaled_f32(aasStream_t stream, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                              float* C, int64_t ldc, int accumulate, const float* d_kscale, int knb);
 
 /* Split-bf16 GEMM on pre-split operand planes (same products as aas_gemm_f32 under aas_set_precision(1), with the
  * fp32 -> (hi, lo) bf16 split hoisted out of the k-loop into one HBM-bound pass per operand):

@@ -448,3 +448,29 @@ def test_stacked_brnn_vanilla_rnn_golden_and_dce_step(gpu, precision):
     tr = Trainer(cfg(lr=1e-3, nFeat=8, rnn_size=16, rnn_type="rnn", rnn_layers=2), None, models=(_fill(stackedBRNN(I=8, H=16, L=2, rnn_type=supported_rnns["rnn"]), 77),))
     losses = [float(tr.train_step(_tiny_paired(880, lens=[40, 36, 30, 22]), it)["dce"]) for it in range(6)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_gemm_tn_rowscaled_fp32(gpu):
+    """aas_gemm_tn_rowscaled_f32: C (+)= sum_r s[r % nb] A[r]^T B[r] - the fp32 weight-gradient product with the per-utterance BEGAN
+    weights applied while the reduction rows are staged (no scaling pass over d(gates)); strided A, row offsets, accumulate."""
+    from aas_enhancement_amd import _lib, ops
+    L = _lib.lib()
+    ops.set_precision(0)
+    try:
+        g = torch.Generator().manual_seed(9)
+        T, nb, M, N = 37, 12, 200, 96
+        K = T * nb
+        A = torch.randn(K, 2 * M, generator=g).cuda()          # lda = 2M: the product takes the second column half
+        B = torch.randn(K, N, generator=g).cuda()
+        sc = torch.randn(nb, generator=g).cuda()
+        C0 = torch.randn(M, N, generator=g).cuda()
+        C = C0.clone()
+        ops.check(L.aas_gemm_tn_rowscaled_f32(_lib.stream(), M, N, K - nb, A.data_ptr() + 4 * (nb * 2 * M + M), 2 * M, B.data_ptr(), N,
+                                              C.data_ptr(), N, 1, sc.data_ptr(), nb), "tn_rowscaled")
+        w = sc.double().repeat(T - 1)[:, None]
+        ref = C0.double() + ((A[nb:, M:].double() * w).t() @ B[:K - nb].double())
+        assert float((C.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+        ops.set_precision(1)
+        assert L.aas_gemm_tn_rowscaled_f32(_lib.stream(), M, N, K, A.data_ptr(), 2 * M, B.data_ptr(), N, C.data_ptr(), N, 0, sc.data_ptr(), nb) != 0
+    finally:
+        ops.set_precision(int(os.environ.get("AAS_PRECISION", "0")))
