@@ -36,6 +36,9 @@ SIGNATURES = {
     "aas_set_wgrad_wg_cap": [c_int],
     "aas_gemm_planes_tn": [c_vp, c_int] + [c_vp] * 18 + [c_int, c_int, c_vp, c_int],
     "aas_split_planes": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_int],
+    "aas_split_planes3": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp],
+    "aas_add3_planes3_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp],
+    "aas_split_planes_t3": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
     "aas_split_planes_t": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
     "aas_split_planes_t2": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
     "aas_transpose_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64],
@@ -102,7 +105,7 @@ def lib():
             L.aas_set_wgrad_wg_cap(int(os.environ["AAS_WGRAD_WGS"]))
         if os.environ.get("AAS_DEBUG_FLAGS"):             # A/B kernel-selection bits of aas_set_debug_flags (include/aas_hip.h)
             L.aas_set_debug_flags(int(os.environ["AAS_DEBUG_FLAGS"]))
-        if os.environ.get("AAS_PRECISION") in ("0", "1"):  # 0 = fp32 MFMA (library default), 1 = split-bf16 fast mode
+        if os.environ.get("AAS_PRECISION") in ("0", "1", "2"):  # 0 = fp32 MFMA (library default), 1 = split-bf16 fast mode
             L.aas_set_precision(int(os.environ["AAS_PRECISION"]))
         _lib = L
     return _lib

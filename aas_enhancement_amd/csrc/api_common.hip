@@ -35,8 +35,8 @@ extern "C" int aas_set_debug_flags(int flags) {
 static int g_precision = 0;
 int aas_precision_value() { return g_precision; }
 extern "C" int aas_set_precision(int mode) {
-    if (mode < 0 || mode > 1) {
-        aas_set_error("aas_set_precision: mode must be 0 (fp32) or 1 (split-bf16)");
+    if (mode < 0 || mode > 2) {
+        aas_set_error("aas_set_precision: mode must be 0 (fp32), 1 (split-bf16) or 2 (fp32-equivalent: fp32 recurrent products, six-product plane GEMMs)");
         return 1;
     }
     g_precision = mode;

@@ -465,7 +465,7 @@ static int gemm_f32_impl(aasStream_t stream, int mode, int M, int N, int K, cons
     dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
     // split-K (atomic epilogue) when the MxN grid cannot fill the 256 CUs and K is deep
     int blocks = grid.x * grid.y;
-    const bool split_prec = aas_precision_value() != 0;
+    const bool split_prec = aas_precision_value() == 1;
     // TN (weight gradients: tiny MxN, deep K) wants >= 2 blocks per CU to hide the k-step latency; its atomic
     // epilogue traffic (splitk x MxN x 4 B at ~1.3 TB/s) stays far below the time saved
     const int target = ((split_prec || (p.flags & 268435456)) && mode == AAS_GEMM_TN) ? 512 : 256;
@@ -487,7 +487,7 @@ static int gemm_f32_impl(aasStream_t stream, int mode, int M, int N, int K, cons
         }
     }
     bool va, vb;
-    const bool split = aas_precision_value() != 0;
+    const bool split = aas_precision_value() == 1;
     int rc = 0;
     if (mode == AAS_GEMM_TN) {
         va = al16(A) && lda % 4 == 0 && M % 4 == 0 && (kdivA == 0 || kouterA % 4 == 0);
@@ -523,7 +523,7 @@ extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, c
 extern "C" int aas_gemm_tn_rowscaled_f32(aasStream_t stream, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                                          float* C, int64_t ldc, int accumulate, const float* d_kscale, int knb) {
     AAS_CHECK(d_kscale && knb > 0, "aas_gemm_tn_rowscaled_f32: scale vector missing");
-    AAS_CHECK(aas_precision_value() == 0, "aas_gemm_tn_rowscaled_f32: fp32 mode only (the split-bf16 path scales through its own operands)");
+    AAS_CHECK(aas_precision_value() != 1, "aas_gemm_tn_rowscaled_f32: fp32 mode only (the split-bf16 path scales through its own operands)");
     return gemm_f32_impl(stream, AAS_GEMM_TN, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, accumulate, 1, 0, 0, 0, 0, 0, 0, 0,
                          d_kscale, knb);
 }

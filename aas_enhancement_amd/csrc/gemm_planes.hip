@@ -256,6 +256,125 @@ __device__ __forceinline__ void split2(float x, unsigned short& h, unsigned shor
     l = __builtin_bit_cast(unsigned short, lb);
 }
 
+// ---- three-term operands for the fp32-EQUIVALENT products (aas_set_precision(2)) ----------------------------------------------
+// x = h + m + l EXACTLY, h = rne_bf16(x), m = rne_bf16(x - h), l = rne_bf16(x - h - m) (24 significant bits in three 8-bit terms).
+// The six products hh' + hm' + mh' + mm' + hl' + lh' (dropped: ml' + lm' + ll' <= 2^-25 |x y|, below fp32's rounding unit) are two
+// passes of the UNCHANGED three-product kernels (X_hi Y_hi + X_lo Y_hi + X_hi Y_lo) over two plane sets of every operand:
+//     set Q1 = (m | h):  m m' + h m' + m h'          set Q2 = (h | l):  h h' + l h' + h l'
+// the second pass accumulating into the first one's result (the small terms are summed first).
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const __bf16 hb = (__bf16)x;
+    h = __builtin_bit_cast(unsigned short, hb);
+    const float r1 = x - __uint_as_float((unsigned)h << 16);
+    const __bf16 mb = (__bf16)r1;
+    m = __builtin_bit_cast(unsigned short, mb);
+    const float r2 = r1 - __uint_as_float((unsigned)m << 16);
+    const __bf16 lb = (__bf16)r2;
+    l = __builtin_bit_cast(unsigned short, lb);
+}
+
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pu32x4 pack8(const unsigned short (&v)[8]) {
+    return (pu32x4){v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16)};
+}
+// 8 consecutive k of one row -> the two plane sets (16-byte stores into the hi / lo slots of the k-block's 128-byte line)
+__device__ __forceinline__ void store_sets(const float (&v)[8], char* q1, char* q2, int64_t row_bytes_off, int k) {
+    unsigned short h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3(v[e], h[e], m[e], l[e]);
+    const int64_t o = row_bytes_off + (k >> 5) * 128 + (k & 31) * 2;
+    const pu32x4 hv = pack8(h), mv = pack8(m), lv = pack8(l);
+    *reinterpret_cast<pu32x4*>(q1 + o) = mv;
+    *reinterpret_cast<pu32x4*>(q1 + o + 64) = hv;
+    *reinterpret_cast<pu32x4*>(q2 + o) = hv;
+    *reinterpret_cast<pu32x4*>(q2 + o + 64) = lv;
+}
+
+__global__ __launch_bounds__(256) void split_rows3_kernel(const float* __restrict__ src, int64_t ld, int64_t R, int K, int Kp,
+                                                          char* __restrict__ q1, char* __restrict__ q2) {
+    const int cpr = Kp / 8;
+    const int64_t total = R * cpr;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int k = (int)(i - r * cpr) * 8;
+        float v[8];
+        const float* s = src + r * ld + k;
+        if (vec && k + 8 <= K) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (k + e < K) ? s[e] : 0.f;
+        }
+        store_sets(v, q1, q2, r * (int64_t)Kp * 4, k);
+    }
+}
+
+__global__ __launch_bounds__(256) void add3_planes3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                           float* __restrict__ out, int64_t R, int K, int Kp, char* __restrict__ q1,
+                                                           char* __restrict__ q2) {
+    const int cpr = Kp / 8;
+    const int64_t total = R * cpr;
+    const bool vec = (K & 3) == 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int k = (int)(i - r * cpr) * 8;
+        float v[8];
+        const int64_t o = r * K + k;
+        if (vec && k + 8 <= K) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 x = *reinterpret_cast<const f32x4*>(a + o + 4 * h) + *reinterpret_cast<const f32x4*>(b + o + 4 * h);
+                if (c) x += *reinterpret_cast<const f32x4*>(c + o + 4 * h);
+                *reinterpret_cast<f32x4*>(out + o + 4 * h) = x;
+                v[4 * h] = x[0]; v[4 * h + 1] = x[1]; v[4 * h + 2] = x[2]; v[4 * h + 3] = x[3];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = 0.f;
+                if (k + e < K) {
+                    v[e] = a[o + e] + b[o + e] + (c ? c[o + e] : 0.f);
+                    out[o + e] = v[e];
+                }
+            }
+        }
+        store_sets(v, q1, q2, r * (int64_t)Kp * 4, k);
+    }
+}
+
+// transposing form (the weights' transposed operand of the input-gradient product): see split_rows_t_kernel
+__global__ __launch_bounds__(256) void split_rows_t3_kernel(const float* __restrict__ src, int64_t ld, int T, int nb, int nbp, int Cc,
+                                                            int64_t Kp, char* __restrict__ q1, char* __restrict__ q2, int64_t tstride) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64;
+    const int64_t k0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int64_t kpos = k0 + rr;
+        const int t = (int)(kpos / nbp), n = (int)(kpos - (int64_t)t * nbp);
+        const int c = c0 + tx;
+        float v = 0.f;
+        if (t < T && n < nb && c < Cc) v = src[(int64_t)t * tstride + (int64_t)n * ld + c];
+        tile[rr][tx] = v;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc;
+        const int64_t kpos = k0 + tx;
+        if (c < Cc && kpos < Kp) {
+            unsigned short h, m, l;
+            split3(tile[tx][cc], h, m, l);
+            const int64_t o = (int64_t)c * Kp * 4 + (kpos >> 5) * 128 + (kpos & 31) * 2;
+            *reinterpret_cast<unsigned short*>(q1 + o) = m;
+            *reinterpret_cast<unsigned short*>(q1 + o + 64) = h;
+            *reinterpret_cast<unsigned short*>(q2 + o) = h;
+            *reinterpret_cast<unsigned short*>(q2 + o + 64) = l;
+        }
+    }
+}
+
 // planes[r][k] = split(src[r*ld + k] * (rs ? rs[r % nb] : 1)), k < K; zero for K <= k < Kp.  8 elements per thread.
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int64_t ld, int64_t R, int K, int Kp,
                                                          char* __restrict__ planes, const float* __restrict__ rs, int nb) {
@@ -560,4 +679,42 @@ extern "C" int aas_split_planes_t2(aasStream_t stream, const float* src, int64_t
                                    int64_t Kp, void* planes, const float* row_scale) {
     AAS_CHECK(tstride != 0, "aas_split_planes_t2: tstride must be non-zero (it may be negative)");
     return split_planes_t_impl(stream, src, ld, T, nb, nbp, C, Kp, planes, row_scale, tstride);
+}
+
+// ---- producers of the three-term plane sets (aas_set_precision(2): see split3 above) --------------------------------------------
+extern "C" int aas_split_planes3(aasStream_t stream, const float* src, int64_t ld, int64_t rows, int K, int Kp, void* planes_q1, void* planes_q2) {
+    AAS_CHECK(src && planes_q1 && planes_q2 && rows >= 0 && K >= 0 && Kp >= K && Kp % 32 == 0, "aas_split_planes3: bad arguments (K=%d Kp=%d)", K, Kp);
+    if (rows == 0 || Kp == 0) return 0;
+    const int64_t total = rows * (Kp / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_rows3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, ld, rows, K, Kp, (char*)planes_q1,
+                       (char*)planes_q2);
+    AAS_LAUNCH_CHECK("aas_split_planes3");
+    return 0;
+}
+
+extern "C" int aas_add3_planes3_f32(aasStream_t stream, float* out, const float* a, const float* b, const float* c, int64_t rows, int K, int Kp,
+                                    void* planes_q1, void* planes_q2) {
+    AAS_CHECK(out && a && b && planes_q1 && planes_q2 && rows >= 0 && K >= 1 && Kp >= K && Kp % 32 == 0, "aas_add3_planes3_f32: bad arguments (K=%d Kp=%d)", K, Kp);
+    AAS_CHECK(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0,
+              "aas_add3_planes3_f32: operands must be 16-byte aligned");
+    if (rows == 0) return 0;
+    const int64_t total = rows * (Kp / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(add3_planes3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, out, rows, K, Kp,
+                       (char*)planes_q1, (char*)planes_q2);
+    AAS_LAUNCH_CHECK("aas_add3_planes3_f32");
+    return 0;
+}
+
+extern "C" int aas_split_planes_t3(aasStream_t stream, const float* src, int64_t ld, int64_t tstride, int T, int nb, int nbp, int C, int64_t Kp,
+                                   void* planes_q1, void* planes_q2) {
+    AAS_CHECK(src && planes_q1 && planes_q2 && T >= 1 && nb >= 1 && nbp >= nb && nbp % 8 == 0 && C >= 1 && Kp >= (int64_t)T * nbp && Kp % 32 == 0,
+              "aas_split_planes_t3: bad arguments (T=%d nb=%d nbp=%d C=%d Kp=%lld)", T, nb, nbp, C, (long long)Kp);
+    hipLaunchKernelGGL(split_rows_t3_kernel, dim3(cdiv(C, 64), (unsigned)((Kp + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src, ld, T, nb, nbp,
+                       C, Kp, (char*)planes_q1, (char*)planes_q2, tstride != 0 ? tstride : (int64_t)nb * ld);
+    AAS_LAUNCH_CHECK("aas_split_planes_t3");
+    return 0;
 }

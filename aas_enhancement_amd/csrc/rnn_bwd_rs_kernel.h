@@ -455,7 +455,7 @@ int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
 // d(gates)); the all-gather split kernel under debug flag 256; the counter-based fp32 kernel otherwise (and under debug bit 134217728)
 template <int MODE>
 int run_bwd_any(const char* name, RnnP p, hipStream_t s) {
-    if (p.xchg && aas_precision_value() != 0 && !(aas_debug_flags_value() & 256)) {
+    if (p.xchg && aas_precision_value() == 1 && !(aas_debug_flags_value() & 256)) {
         const int rc = run_bwd_rs<MODE, false>(name, p, s);
         if (rc >= 0) return rc;
     }
@@ -463,7 +463,7 @@ int run_bwd_any(const char* name, RnnP p, hipStream_t s) {
         aas_set_error("%s: plane output needs the split-bf16 reduce-scatter BPTT kernel (precision 1, exchange buffer, supported H)", name);
         return 3;
     }
-    if (p.xchg && aas_precision_value() == 0 && !(aas_debug_flags_value() & (256 | 134217728))) {
+    if (p.xchg && aas_precision_value() != 1 && !(aas_debug_flags_value() & (256 | 134217728))) {
         const int rc = run_bwd_rs<MODE, true>(name, p, s);
         if (rc >= 0) return rc;
     }

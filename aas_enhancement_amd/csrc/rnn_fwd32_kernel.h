@@ -327,7 +327,7 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
 template <int MODE>
 int run_fwd_any(const char* name, RnnP p, hipStream_t s) {
     aas_note_fwd_h_planes(0);
-    if (p.xchg && aas_precision_value() != 0) {
+    if (p.xchg && aas_precision_value() == 1) {
         const int rc = run_fwd32<MODE, false>(name, p, s);
         if (rc >= 0) return rc;
     } else if (p.xchg && !(aas_debug_flags_value() & 134217728)) {   // exact fp32 on the same data-is-the-flag kernels

@@ -582,7 +582,7 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
 // Debug bit 134217728: always the counter-based kernel in exact mode (the previous round's fp32 path, for A/B runs).
 template <int MODE>
 int run_any(const char* name, RnnP p, hipStream_t s) {
-    if (p.xchg && aas_precision_value() != 0) {
+    if (p.xchg && aas_precision_value() == 1) {
         const int rc = run_split<MODE, false>(name, p, s);
         if (rc >= 0) return rc;
     } else if (p.xchg && !(aas_debug_flags_value() & 134217728)) {

@@ -41,7 +41,7 @@ def main(config):
             kw = dict(device_id=torch.device("cuda", local_rank)) if config.dist_backend == "nccl" else {}
             dist.init_process_group(config.dist_backend, **kw)
     from . import ops
-    ops.set_precision(1 if getattr(config, "precision", "fp32") == "bf16x3" else 0)
+    ops.set_precision({"fp32": 0, "bf16x3": 1, "fp32eq": 2}[getattr(config, "precision", "fp32")])
     import numpy as np
     np.random.seed(config.random_seed)      # FeatSampler shuffles with numpy: identical batch order on every rank
     if config.gpu >= 0:

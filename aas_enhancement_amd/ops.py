@@ -110,7 +110,9 @@ _precision = [int(__import__('os').environ.get('AAS_PRECISION', '0'))]
 
 def set_precision(mode):
     """0 (library default) = fp32 operands on fp32-input MFMA, the reference's arithmetic; 1 = split-bf16 fast mode (operands as
-    bf16 hi/lo, 3 MFMAs per product, ~2^-17 per product: narrower than fp32, inside the parity budget).  `--precision` of main.py /
+    bf16 hi/lo, 3 MFMAs per product, ~2^-17 per product: narrower than fp32, inside the parity budget); 2 = fp32-EQUIVALENT: fp32
+    recurrent products and small GEMMs as in mode 0, the large GEMMs as six bf16 products of three-term operands (all 24 operand
+    bits, dropped cross terms <= 2^-25: `gemm_planes6`).  `--precision` of main.py /
     am_train.py and the AAS_PRECISION environment variable select it for a whole run."""
     check(lib().aas_set_precision(int(mode)), "aas_set_precision")
     _precision[0] = int(mode)
@@ -286,6 +288,53 @@ def _kp(K):
     return (K + 31) // 32 * 32
 
 
+class Planes3(object):
+    """The two plane sets of a three-term operand (include/aas_hip.h: aas_split_planes3): q1 = (m | h), q2 = (h | l), each in the
+    layout of `Planes`.  A product of two such operands is two passes of the three-product plane kernels (gemm_planes6)."""
+    __slots__ = ("q1", "q2", "rows", "K", "Kp")
+
+    def __init__(self, q1, q2, rows, K, Kp):
+        self.q1, self.q2, self.rows, self.K, self.Kp = q1, q2, rows, K, Kp
+
+    def sets(self):
+        return (Planes(self.q1, self.rows, self.K, self.Kp), Planes(self.q2, self.rows, self.K, self.Kp))
+
+    def to_float(self):
+        """[rows, Kp] fp32 reconstruction h + m + l (tests): exact."""
+        a = self.q1.view(self.rows, self.Kp // 32, 2, 32).float()    # (m | h)
+        b = self.q2.view(self.rows, self.Kp // 32, 2, 32).float()    # (h | l)
+        return ((a[:, :, 1, :] + a[:, :, 0, :]) + b[:, :, 1, :]).reshape(self.rows, self.Kp)
+
+
+def split_planes3(x2d, rows, K, ld=None, off=0):
+    Kp = _kp(K)
+    q1 = torch.empty((rows, 2 * Kp), device=x2d.device, dtype=torch.bfloat16)
+    q2 = torch.empty((rows, 2 * Kp), device=x2d.device, dtype=torch.bfloat16)
+    check(lib().aas_split_planes3(stream(), x2d.data_ptr() + 4 * off, ld if ld is not None else K, rows, K, Kp, ptr(q1), ptr(q2)), "aas_split_planes3")
+    return Planes3(q1, q2, rows, K, Kp)
+
+
+def add3_planes3(a, b, c, K):
+    """out = a + b (+ c) plus its three-term plane sets (the next layer's input operand in the fp32-equivalent mode)."""
+    out = torch.empty_like(a)
+    rows = a.numel() // K
+    Kp = _kp(K)
+    q1 = torch.empty((rows, 2 * Kp), device=a.device, dtype=torch.bfloat16)
+    q2 = torch.empty((rows, 2 * Kp), device=a.device, dtype=torch.bfloat16)
+    check(lib().aas_add3_planes3_f32(stream(), ptr(out), ptr(a), ptr(b), ptr(c), rows, K, Kp, ptr(q1), ptr(q2)), "aas_add3_planes3_f32")
+    return out, Planes3(q1, q2, rows, K, Kp)
+
+
+def gemm_planes6(M, N, K, A3, B3, C, ldc, bias=None, addend=None, ldd=0, accumulate=False, a_off=0, b_off=0, c_off=0):
+    """C[M,N] (+)= A[M,K] B[N,K]^T with every product carried to fp32's 24 operand bits: pass 1 on the (m | h) sets sums the small
+    terms m m' + h m' + m h' (+ bias / addend / the old C), pass 2 on the (h | l) sets adds h h' + l h' + h l'."""
+    (a1, a2), (b1, b2) = A3.sets(), B3.sets()
+    # (profiling: the two launches are ONE logical product - the algorithmic flops are counted once, on the first pass)
+    gemm_planes(M, N, K, a1, b1, C, ldc, bias=bias, addend=addend, ldd=ldd, accumulate=accumulate, a_off=a_off, b_off=b_off, c_off=c_off,
+                name="gemm_planes6")
+    gemm_planes(M, N, K, a2, b2, C, ldc, accumulate=True, a_off=a_off, b_off=b_off, c_off=c_off, name="gemm_planes6", count_flops=False)
+
+
 def split_planes(x2d, rows, K, ld=None, row_scale=None, nb=0, off=0):
     """planes of x2d[r*ld + off + k] (* row_scale[r % nb])."""
     Kp = _kp(K)
@@ -335,7 +384,7 @@ def _zero512(dev):
     return z
 
 
-def gemm_planes_tn(problems, Ns, Nb, dev, accumulate=True):
+def gemm_planes_tn(problems, Ns, Nb, dev, accumulate=True, name="gemm_planes_wgrad", count_flops=True):
     """Weight-gradient style products straight from ROW-MAJOR planes (include/aas_hip.h: aas_gemm_planes_tn), <= 8 per launch.
     Each problem is a dict: A, B (device byte addresses of row 0 of the planes), lda, ldb (bytes per plane row), acols, bcols
     (plane columns), acol0, M, N, K, C0, C1 (device addresses; C1 = 0 when msplit >= M), msplit, ldc, n0, ta, tb, alpha
@@ -346,18 +395,18 @@ def gemm_planes_tn(problems, Ns, Nb, dev, accumulate=True):
     ci = lambda k: (ctypes.c_int * n)(*[int(pr[k]) for pr in problems])
     c64 = lambda k: (ctypes.c_int64 * n)(*[int(pr[k]) for pr in problems])
     al = (ctypes.c_void_p * n)(*[pr["alpha"].data_ptr() if pr.get("alpha") is not None else None for pr in problems])
-    flops = sum(2.0 * pr["M"] * pr["N"] * pr["K"] for pr in problems)
-    with _timed("gemm", "gemm_planes_wgrad", flops):
+    flops = sum(2.0 * pr["M"] * pr["N"] * pr["K"] for pr in problems) if count_flops else 0.0
+    with _timed("gemm", name, flops):
         check(lib().aas_gemm_planes_tn(stream(), n, vp("A"), vp("B"), vp("C0"), vp("C1"), al, ci("M"), ci("N"), ci("K"), ci("msplit"),
                                        ci("acol0"), ci("n0"), ci("ta"), ci("tb"), c64("lda"), ci("acols"), c64("ldb"), ci("bcols"),
                                        c64("ldc"), Ns, Nb, ptr(_zero512(dev)), int(accumulate)), "aas_gemm_planes_tn")
 
 
 def gemm_planes(M, N, K, A, B, C, ldc, bias=None, addend=None, ldd=0, accumulate=False, batch=1, sA=0, sB=0, sC=0,
-                a_off=0, b_off=0, c_off=0, lda=None, ldb=None):
+                a_off=0, b_off=0, c_off=0, lda=None, ldb=None, name="gemm_planes", count_flops=True):
     """C[M,N] (+)= A[M,K] B[N,K]^T on Planes operands; K is the k extent actually multiplied (multiple of 32);
     a_off/b_off are offsets in elements (multiples of 32 within a row, or whole rows), c_off in elements."""
-    with _timed("gemm", "gemm_planes", 2.0 * M * N * K * batch):
+    with _timed("gemm", name, 2.0 * M * N * K * batch if count_flops else 0.0):
         check(lib().aas_gemm_planes(stream(), M, N, K, A.buf.data_ptr() + 4 * a_off, lda if lda is not None else A.Kp,
                                     B.buf.data_ptr() + 4 * b_off, ldb if ldb is not None else B.Kp,
                                     C.data_ptr() + 4 * c_off, ldc, ptr(bias), ptr(addend), ldd, int(accumulate), batch, sA, sB, sC),
@@ -590,6 +639,48 @@ def _wih_planes(w_ih, w_ih_r, GH, I):
     return wb
 
 
+def _wih_planes3(w_ih, w_ih_r, GH, I):
+    """[W_ih ; W_ih_rev] as three-term plane sets [2*GH rows][I]."""
+    ok, sig = _plane_sig(w_ih, w_ih_r, GH, I, "N3")
+    ent = getattr(w_ih, "_aas_planes3", None) if ok else None
+    if ent is not None and ent[0] == sig:
+        _planes_ready(w_ih)
+        return ent[1]
+    Kp = _kp(I)
+    q1 = torch.empty((2 * GH, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
+    q2 = torch.empty((2 * GH, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
+    check(lib().aas_split_planes3(stream(), ptr(w_ih), I, GH, I, Kp, ptr(q1), ptr(q2)), "aas_split_planes3")
+    check(lib().aas_split_planes3(stream(), ptr(w_ih_r), I, GH, I, Kp, q1.data_ptr() + GH * Kp * 4, q2.data_ptr() + GH * Kp * 4), "aas_split_planes3")
+    wb = Planes3(q1, q2, 2 * GH, I, Kp)
+    if ok:
+        try:
+            w_ih._aas_planes3 = (sig, wb)
+        except Exception:  # noqa: BLE001
+            pass
+    return wb
+
+
+def _wih_t_planes3(w_ih, w_ih_r, GH, I):
+    """[W_ih ; W_ih_rev]^T as three-term plane sets [I rows][k = d*GH + g]."""
+    ok, sig = _plane_sig(w_ih, w_ih_r, GH, I, "T3")
+    ent = getattr(w_ih, "_aas_planes3_t", None) if ok else None
+    if ent is not None and ent[0] == sig:
+        _planes_ready(w_ih)
+        return ent[1]
+    Kp = _kp(2 * GH)
+    q1 = torch.empty((I, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
+    q2 = torch.empty((I, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
+    dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4
+    check(lib().aas_split_planes_t3(stream(), ptr(w_ih), I, dw, 2, GH, GH, I, Kp, ptr(q1), ptr(q2)), "aas_split_planes_t3")
+    wt = Planes3(q1, q2, I, 2 * GH, Kp)
+    if ok and not torch.cuda.is_current_stream_capturing():
+        try:
+            w_ih._aas_planes3_t = (sig, wt)
+        except Exception:  # noqa: BLE001
+            pass
+    return wt
+
+
 _refresh_streams = {}
 
 
@@ -626,9 +717,14 @@ def refresh_weight_planes(module):
                 continue
             w, wr = m.weight_ih_l0, m.weight_ih_l0_reverse
             GH, I = w.shape
-            if _precision[0] == 1 and PLANES_PRE[0] and I >= 64:
+            if _precision[0] in (1, 2) and PLANES_PRE[0] and I >= 64 and getattr(m, "kind", "") != "rnn":
                 w._aas_planes_ready = None        # (the calls below must not wait for the previous refresh on this stream)
-                for t_ in (_wih_planes(w, wr, GH, I).buf,) + ((_wih_t_planes(w, wr, GH, I).buf,) if (PLANES_BWD[0] and w.requires_grad) else ()):
+                if _precision[0] == 1:
+                    bufs = (_wih_planes(w, wr, GH, I).buf,) + ((_wih_t_planes(w, wr, GH, I).buf,) if (PLANES_BWD[0] and w.requires_grad) else ())
+                else:
+                    p3 = (_wih_planes3(w, wr, GH, I),) + ((_wih_t_planes3(w, wr, GH, I),) if (PLANES_BWD[0] and w.requires_grad) else ())
+                    bufs = tuple(b_ for x_ in p3 for b_ in (x_.q1, x_.q2))
+                for t_ in bufs:
                     t_.record_stream(main)
                 done = torch.cuda.Event()
                 done.record(side)
@@ -678,7 +774,16 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None):
     pre = torch.empty((T, N, 2, G * H), device=dev, dtype=torch.float32)
     x2 = x.view(T * N, I)
     dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4  # element distance between the two directions' W_ih
-    if _precision[0] == 1 and PLANES_PRE[0] and T * N >= 1024 and I >= 64:
+    if _precision[0] == 2 and kind != "rnn" and PLANES_PRE[0] and T * N >= 1024 and I >= 64:
+        # fp32-equivalent mode: three-term plane sets of x and [W_ih; W_ih_rev], two passes of the plane GEMM (six products)
+        GH = G * H
+        xa = getattr(x, "_aas_planes3", None)
+        if xa is None or xa.rows != T * N or xa.K != I:
+            xa = split_planes3(x2, T * N, I)
+        if keep is not None:
+            keep["xp3"] = xa
+        gemm_planes6(T * N, 2 * GH, xa.Kp, xa, _wih_planes3(w_ih, w_ih_r, GH, I), pre, 2 * GH)
+    elif _precision[0] == 1 and PLANES_PRE[0] and T * N >= 1024 and I >= 64:
         # plane GEMM: x and [W_ih; W_ih_rev] as pre-split bf16 planes (one HBM-bound pass each; frozen weights are
         # split once), then one LDS-DMA-staged launch for both directions: pre[tn, d*GH + g]
         GH = G * H
@@ -741,6 +846,9 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     R = T * N
     use_planes = (_precision[0] == 1 and kind != "rnn" and PLANES_BWD[0] and R >= 1024 and H >= 64 and I >= 64 and GH % 8 == 0
                   and w_ih_r.data_ptr() != w_ih.data_ptr() and (w_ih_r.data_ptr() - w_ih.data_ptr()) % 4 == 0)
+    # fp32-equivalent mode: fp32 BPTT (exact kernels), then d(gates) as three-term plane sets for the six-product GEMMs
+    use_planes6 = (_precision[0] == 2 and kind != "rnn" and PLANES_BWD[0] and R >= 1024 and H >= 64 and I >= 64 and GH % 8 == 0
+                   and w_ih_r.data_ptr() != w_ih.data_ptr() and (w_ih_r.data_ptr() - w_ih.data_ptr()) % 4 == 0)
     rflops = 2.0 * 2 * T * N * H * GH
     lib().aas_set_rnn_launch_tag(2 * lid + 1 if lid else 1)
     # d(gates) straight in the operand form of the layer's GEMMs (row-major bf16 hi|lo planes) when the plane path is taken:
@@ -786,10 +894,14 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     ev_bptt.record(torch.cuda.current_stream())
     x2 = x.view(T * N, I)
     dx = None
+    dga3 = None
     if need_dx:
         dx = torch.empty((T, N, I), device=dev, dtype=torch.float32)
         dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4
-        if use_planes:
+        if use_planes6:
+            dga3 = split_planes3(dgx.view(R, 2 * GH), R, 2 * GH)
+            gemm_planes6(R, I, dga3.Kp, dga3, _wih_t_planes3(w_ih, w_ih_r, GH, I), dx, I, addend=dy if residual else None, ldd=I)
+        elif use_planes:
             # dx[R, I] = d(gates)[R, 2GH] [W_ih ; W_ih_rev]: the NT plane GEMM on a row-major split of d(gates) (one HBM pass)
             # and the transposed weight planes (2 GH x I elements; cached when the weights are frozen)
             dga = Planes(dgp, R, 2 * GH, Kpg) if dgp is not None else split_planes(dgx.view(R, 2 * GH), R, 2 * GH)
@@ -874,8 +986,41 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
             t_.record_stream(cur)
         return True
 
+    def wgrads_tn6(out):
+        """fp32-equivalent mode: the row-major weight-gradient products as two passes over three-term plane sets - d(gates) (split
+        above for the input-gradient product, or here), the input's sets from the forward projection, h_t split here from `hout`."""
+        if not (TN_WGRAD[0] and keep and "xp3" in keep):
+            return False
+        classes = [(0, N, None)] if rs is None else getattr(rs, "_aas_classes", None)
+        if not classes:
+            return False
+        xp3 = keep["xp3"]
+        if xp3.rows != R or xp3.K != I or not all(o.is_contiguous() for o in out):
+            return False
+        dg3 = dga3 if dga3 is not None else split_planes3(dgx.view(R, 2 * GH), R, 2 * GH)
+        dgh3 = dg3 if dgh is dgx else split_planes3(dgh.view(R, 2 * GH), R, 2 * GH)
+        h3 = split_planes3(hout.view(2 * R, H), 2 * R, H)
+        lda = 4 * dg3.Kp
+        for n0, ns, alpha in classes:
+            base = dict(lda=lda, acols=dg3.Kp, n0=n0, alpha=alpha)
+            for pi_, (a_x, a_h, b_x, b_h) in enumerate(((dg3.q1, dgh3.q1, xp3.q1, h3.q1), (dg3.q2, dgh3.q2, xp3.q2, h3.q2))):
+                hb, hpitch = b_h.data_ptr(), 4 * h3.Kp
+                probs = [dict(base, A=a_x.data_ptr(), B=b_x.data_ptr(), ldb=4 * xp3.Kp, bcols=xp3.Kp, acol0=0, M=2 * GH, N=I, K=T * ns,
+                              C0=out[0].data_ptr(), C1=out[2].data_ptr(), msplit=GH, ldc=I, ta=0, tb=0),
+                         dict(base, A=a_h.data_ptr(), B=hb, ldb=hpitch, bcols=h3.Kp, acol0=0, M=GH, N=H, K=(T - 1) * ns,
+                              C0=out[1].data_ptr(), C1=0, msplit=GH, ldc=H, ta=1, tb=0),
+                         dict(base, A=a_h.data_ptr(), B=hb + R * hpitch, ldb=hpitch, bcols=h3.Kp, acol0=GH, M=GH, N=H,
+                              K=(T - 1) * ns, C0=out[3].data_ptr(), C1=0, msplit=GH, ldc=H, ta=0, tb=1)]
+                gemm_planes_tn(probs, ns, N, dev, accumulate=True, name="gemm_planes6_wgrad", count_flops=(pi_ == 0))
+        cur = torch.cuda.current_stream()
+        for t_ in (dg3.q1, dg3.q2, dgh3.q1, dgh3.q2, xp3.q1, xp3.q2, h3.q1, h3.q2):
+            t_.record_stream(cur)
+        return True
+
     def wgrads(out, acc):
         if _SKIP_WGRAD:  # timing experiment only (AAS_SKIP_WGRAD=1): how much of the step the weight-gradient products hold
+            return
+        if use_planes6 and acc and T > 1 and wgrads_tn6(out):
             return
         if use_planes and acc and T > 1:
             if wgrads_tn(out):
@@ -913,7 +1058,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         # fp32 mode: with the weights folded into the GEMM (or none to apply) nothing mutates d(gates) either, so the products may
         # start right behind the BPTT launch there too
         fold_ok = _precision[0] == 0 and _TN_FOLD and all(o.is_contiguous() for o in direct)
-        no_mutation = use_planes or rs is None or fold_ok
+        no_mutation = use_planes or use_planes6 or rs is None or fold_ok
         ev = ev_bptt if (no_mutation and T > 1 and os.environ.get("AAS_WGRAD_EARLY", "1") == "1") else torch.cuda.Event()
         if ev is not ev_bptt:
             ev.record(main)
@@ -925,7 +1070,8 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
                 wgrads(direct, True)
                 if hook is not None:
                     hook(direct)
-        for t_ in (dgx, dgh, dgp, dghp, x, hout) + ((keep["xp"].buf if "xp" in keep else None, keep.get("hx")) if keep else ()):
+        for t_ in (dgx, dgh, dgp, dghp, x, hout) + ((keep["xp"].buf if "xp" in keep else None, keep.get("hx")) if keep else ()) + (
+                (dga3.q1, dga3.q2) if dga3 is not None else ()):
             if t_ is not None:
                 t_.record_stream(side)
         if DEFER_WGRAD[0] or lid in DEFER_LIDS:
@@ -955,7 +1101,10 @@ class _BiRNNLayer(torch.autograd.Function):
                           and not torch.cuda.is_current_stream_capturing()) else None
         hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid, keep=ctx.keep)
         T_, N_, H_ = hout.shape[1], hout.shape[2], hout.shape[3]
-        if _precision[0] == 1 and PLANES_PRE[0] and T_ * N_ >= 1024 and H_ >= 64 and H_ % 4 == 0:
+        if _precision[0] == 2 and kind != "rnn" and PLANES_PRE[0] and T_ * N_ >= 1024 and H_ >= 64 and H_ % 4 == 0:
+            y, yp = add3_planes3(hout[0], hout[1], x if residual else None, H_)
+            y._aas_planes3 = yp
+        elif _precision[0] == 1 and PLANES_PRE[0] and T_ * N_ >= 1024 and H_ >= 64 and H_ % 4 == 0:
             y, yp = add3_planes(hout[0], hout[1], x if residual else None, H_)
             y._aas_planes = yp        # consumed by the next recurrent layer's input projection (same Python object is passed on)
         else:

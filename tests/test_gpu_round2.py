@@ -25,7 +25,7 @@ def gpu():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[1, 0], ids=["splitbf16", "fp32"])
+@pytest.fixture(params=[1, 0, 2], ids=["splitbf16", "fp32", "fp32eq"])
 def precision(request, gpu):
     from aas_enhancement_amd import ops
     ops.set_precision(request.param)

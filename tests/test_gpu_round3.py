@@ -378,7 +378,7 @@ def test_exact_fp32_flag_kernels_vs_counter_kernels_and_xcd_variants(gpu, kind, 
 
 
 # ------------------------------------------------------------------------------------------------ vanilla `rnn` kind
-@pytest.fixture(params=[1, 0], ids=["splitbf16", "fp32"])
+@pytest.fixture(params=[1, 0, 2], ids=["splitbf16", "fp32", "fp32eq"])
 def precision(request, gpu):
     from aas_enhancement_amd import ops
     ops.set_precision(request.param)
@@ -395,7 +395,7 @@ def test_brnn_vanilla_rnn_golden(gpu, precision, tag):
     from tests.helpers import rel_err, sub
     z = load("f9_rnn_kind.npz")
     p = "brnn_rnn_%s." % tag
-    ft, gt = (1e-5, 1e-4) if precision == 0 else (1e-4, 5e-4)
+    ft, gt = (1e-5, 1e-4) if precision != 1 else (1e-4, 5e-4)
     if tag != "l":
         H = z[p + "x"].shape[2]
         m = BRNN(H, H, nn.RNN, bidirectional=True)
@@ -441,7 +441,7 @@ def test_stacked_brnn_vanilla_rnn_golden_and_dce_step(gpu, precision):
     x = torch.from_numpy(z[p + "x"]).cuda().requires_grad_(True)
     y = G(x)
     y.backward(torch.from_numpy(z[p + "gy"]).cuda())
-    ft, gt = (2e-5, 2e-4) if precision == 0 else (2e-4, 1e-3)
+    ft, gt = (2e-5, 2e-4) if precision != 1 else (2e-4, 1e-3)
     assert rel_err(y, z[p + "y"]) < ft and rel_err(x.grad, z[p + "gx"]) < gt
     for k, v in G.named_parameters():
         assert rel_err(v.grad, z[p + "gw." + k]) < gt, k
@@ -474,3 +474,114 @@ def test_gemm_tn_rowscaled_fp32(gpu):
         assert L.aas_gemm_tn_rowscaled_f32(_lib.stream(), M, N, K, A.data_ptr(), 2 * M, B.data_ptr(), N, C.data_ptr(), N, 0, sc.data_ptr(), nb) != 0
     finally:
         ops.set_precision(int(os.environ.get("AAS_PRECISION", "0")))
+
+
+# ------------------------------------------------------------------------------------------------ fp32-equivalent six-product GEMM
+@pytest.mark.parametrize("dist", ["randn", "positive", "wide"])
+@pytest.mark.parametrize("K", [500, 1000, 6016])
+def test_six_product_gemm_error_not_above_the_fp32_gemms(gpu, K, dist):
+    """aas_set_precision(2): three-term operands x = h + m + l (exact), six bf16 products as two passes of the three-product plane
+    kernel over the (m | h) and (h | l) plane sets.  Against fp64 its error - scaled by sum_k |a||b|, maximum and rms - is NOT ABOVE
+    the fp32-input MFMA GEMM's own error on the same operands, at the K of the enhancer's layers (500), the acoustic model's (1000)
+    and a weight-gradient reduction (6016 rows), on N(0,1) data, on all-positive data (no cancellation: accumulation rounding
+    dominates) and on data spread over 2^+-12 with random signs.  The three-product fast mode is shown to be 2-15x worse on the same
+    data - the reason it is not the headline."""
+    from aas_enhancement_amd import ops
+    g = torch.Generator().manual_seed(K)
+    M, N = 384, 256
+    if dist == "randn":
+        A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    elif dist == "positive":
+        A, B = torch.rand(M, K, generator=g) + 0.5, torch.rand(N, K, generator=g) + 0.5
+    else:
+        A = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-12, 12, (M, K), generator=g).float())
+        B = torch.randn(N, K, generator=g) * torch.exp2(torch.randint(-12, 12, (N, K), generator=g).float())
+    A, B = A.cuda(), B.cuda()
+    ref = A.double() @ B.double().t()
+    scale = A.double().abs() @ B.double().abs().t()
+    try:
+        ops.set_precision(0)
+        C32 = torch.empty(M, N, device="cuda")
+        ops.gemm(ops.NT, M, N, K, A, K, B, K, C32, N)
+        A3, B3 = ops.split_planes3(A, M, K), ops.split_planes3(B, N, K)
+        assert torch.equal(A3.to_float()[:, :K], A) and torch.equal(B3.to_float()[:, :K], B)      # h + m + l == x, bit for bit
+        assert float(A3.to_float()[:, K:].abs().sum()) == 0.0
+        C6 = torch.empty(M, N, device="cuda")
+        ops.gemm_planes6(M, N, A3.Kp, A3, B3, C6, N)
+        A2, B2 = ops.split_planes(A, M, K), ops.split_planes(B, N, K)
+        C3 = torch.empty(M, N, device="cuda")
+        ops.gemm_planes(M, N, A2.Kp, A2, B2, C3, N)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(int(os.environ.get("AAS_PRECISION", "0")))
+    e32, e6, e3 = [((c.double() - ref).abs() / scale) for c in (C32, C6, C3)]
+    assert float(e6.max()) <= float(e32.max()), (float(e6.max()), float(e32.max()))
+    assert float(e6.pow(2).mean().sqrt()) <= float(e32.pow(2).mean().sqrt())
+    assert float(e6.max()) < 2e-6                                     # a few units of fp32's 2^-24 at most
+    if dist != "positive":
+        assert float(e3.pow(2).mean().sqrt()) > 2.0 * float(e32.pow(2).mean().sqrt())    # the fast mode IS narrower
+
+
+@pytest.mark.parametrize("kind,T,N,H,classes", [("lstm", 200, 30, 500, 1), ("lstm", 64, 60, 500, 2), ("gru", 85, 30, 1000, 1), ("lstm", 9, 3, 16, 1)])
+def test_birnn_layer_fp32_equivalent_mode_vs_cpu(gpu, kind, T, N, H, classes):
+    """A recurrent layer in the fp32-equivalent mode (fp32 recurrent kernels + six-product projections / input gradients / row-major
+    weight gradients incl. two utterance classes) against torch's CPU nn.LSTM / nn.GRU, held to the fp32 mode's tolerances."""
+    from aas_enhancement_amd import ops
+    from aas_enhancement_amd.dist import FlatBuffers
+    from tests.helpers import rel_err
+    torch.manual_seed(0)
+    ref = (nn.LSTM if kind == "lstm" else nn.GRU)(H, H, bidirectional=True, bias=False)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(T, N, H, generator=g) * 0.5
+    gy = torch.randn(T, N, H, generator=g)
+    names = ("weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse")
+    holder = nn.ParameterList([nn.Parameter(getattr(ref, k).detach().clone()) for k in names]).cuda()
+    flat = FlatBuffers(holder)        # flat-buffer gradients: the side-stream accumulate path the trainers use
+    w = list(holder)
+    rs = None
+    scale = torch.ones(N)
+    if classes == 2:
+        rs = torch.empty(N, device="cuda")
+        rs[:N // 2] = -0.37
+        rs[N // 2:] = 1.0
+        rs._aas_classes = [(0, N // 2, rs[0:1]), (N // 2, N - N // 2, None)]
+        scale[:N // 2] = -0.37
+    try:
+        ops.set_precision(2)
+        xg = x.clone().cuda().requires_grad_(True)
+        yg = ops.birnn_layer(xg, *w, kind=kind, residual=True, rs=rs)
+        yg.backward(gy.cuda())
+        ops.sync_wgrad()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(int(os.environ.get("AAS_PRECISION", "0")))
+    assert not ops.rnn_timeout_flag()
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref(xr)
+    yr = yr[..., :H] + yr[..., H:] + xr
+    yr.backward(gy)
+    assert rel_err(yg, yr) < 2e-5 and rel_err(xg.grad, xr.grad) < 2e-4
+    if classes == 2:     # parameter gradients with per-utterance weights: a second reference backward with the weighted output gradient
+        for p_ in ref.parameters():
+            p_.grad = None
+        xr2 = x.clone().requires_grad_(True)
+        y2, _ = ref(xr2)
+        (y2[..., :H] + y2[..., H:] + xr2).backward(gy)       # = same graph; weights applied per utterance below via a hook-free trick:
+        # d(params) is linear in the per-utterance output gradients, so run one backward per class and combine
+        tot = {k: torch.zeros_like(getattr(ref, k)) for k in names}
+        for lo, hi, wgt in ((0, N // 2, -0.37), (N // 2, N, 1.0)):
+            for p_ in ref.parameters():
+                p_.grad = None
+            xs = x.clone().requires_grad_(True)
+            ys, _ = ref(xs)
+            gm = torch.zeros_like(gy)
+            gm[:, lo:hi] = gy[:, lo:hi]
+            # the residual path does not touch the parameters; the recurrent gradient of an utterance depends on its own rows only
+            (ys[..., :H] + ys[..., H:]).backward(gm)
+            for k in names:
+                tot[k] += wgt * getattr(ref, k).grad
+        for wg, k in zip(w, names):
+            assert rel_err(wg.grad, tot[k]) < 3e-4, k
+    else:
+        for wg, k in zip(w, names):
+            assert rel_err(wg.grad, getattr(ref, k).grad) < 2e-4, k

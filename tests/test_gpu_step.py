@@ -42,7 +42,7 @@ def build_tiny(z):
     return G, D, A
 
 
-@pytest.fixture(params=[1, 0], ids=["splitbf16", "fp32"])
+@pytest.fixture(params=[1, 0, 2], ids=["splitbf16", "fp32", "fp32eq"])
 def precision(request, gpu):
     from aas_enhancement_amd import ops
     ops.set_precision(request.param)
