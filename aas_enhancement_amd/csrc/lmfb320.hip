@@ -52,6 +52,14 @@ __device__ __forceinline__ void split2(float x, unsigned short& h, unsigned shor
     l = __builtin_bit_cast(unsigned short, lb);
 }
 
+// log1p(x) for x >= 0 on the hardware log: u = 1 + x rounds, log(u) * x / (u - 1) undoes that rounding (the classic correction), so
+// tiny mel energies keep their relative accuracy; ~8 instructions instead of the ~35 of ocml's log1pf.  Debug bit 32: ocml log1pf.
+__device__ __forceinline__ float log1p_fast(float x) {
+    const float u = 1.0f + x;
+    const float d = u - 1.0f;
+    return d == 0.0f ? x : __logf(u) * (x * __frcp_rn(d));
+}
+
 __global__ __launch_bounds__(256, 2) void lmfb320_kernel(LP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* a_hi = smem;                                        // [16][A_STRIDE]
@@ -247,7 +255,8 @@ __global__ __launch_bounds__(256, 2) void lmfb320_kernel(LP p) {
                     const float* wr = mw + m * MAXW;
                     for (int q = 0; q < cnt; ++q) acc = fmaf(pr[q], wr[q], acc);
                 }
-                if (f < nf && !(p.flags & 16)) p.out[((int64_t)n * p.n_mels + m) * p.T + t0 + f] = live ? log1pf(acc) : 0.f;
+                if (f < nf && !(p.flags & 16))
+                    p.out[((int64_t)n * p.n_mels + m) * p.T + t0 + f] = live ? ((p.flags & 32) ? log1pf(acc) : log1p_fast(acc)) : 0.f;
             }
         }
         // (the next tile's staging writes `seg`, its fold writes the A planes: both were last read before the barrier above;

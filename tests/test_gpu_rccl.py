@@ -194,3 +194,24 @@ def test_bench_gpus_2_on_a_one_gpu_box_fails_fast_with_a_clear_message():
     assert cp.returncode != 0
     assert "only %d device" % have in cp.stderr
     assert cp.stdout.strip() == ""
+
+
+def test_bench_launcher_path_relays_rank0_line_and_exit_code():
+    """The self-launching path of bench.py on the one GPU of the test box (AAS_BENCH_FORCE_SPAWN=1 takes it for N=1): the parent never
+    touches the GPU, starts `python -m torch.distributed.run --nproc-per-node 1 bench.py ...` as a child, relays exactly one JSON
+    line (rank 0's) on stdout and returns the workers' exit code; a failing worker (unknown flag) gives a non-zero code and no line."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "AAS_PRECISION")}
+    env["AAS_BENCH_FORCE_SPAWN"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-extras", "--no-cpu-baseline",
+           "--profile-steps", "0"]
+    cp = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    lines = [ln for ln in cp.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["dtype"] == "f32" and j["parity_gate"]["status"] == "ok" and j["value"] > 0
+    bad = subprocess.run(cmd + ["--no-such-flag"], capture_output=True, text=True, timeout=600, env=env)
+    assert bad.returncode != 0 and bad.stdout.strip() == ""

@@ -13,7 +13,7 @@ def main():
     mod = LMFB(n_mels=80).cuda()
     w = torch.from_numpy(prng.normal(126, (64, 31840), 0.0, 0.1)).cuda().repeat(n // 64, 1).contiguous()
     L = _lib.lib()
-    for fl in (0, 1, 2, 4, 8, 16, 31):
+    for fl in (0, 32, 1, 2, 4, 8, 16, 31):
         L.aas_set_debug_flags(fl)
         for _ in range(3):
             mod(w)

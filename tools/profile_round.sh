@@ -8,8 +8,8 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
-for P in 0 1; do
-  N=$([ $P = 0 ] && echo f32 || echo bf16x3)
+for P in 0 1 2; do
+  N=$([ $P = 0 ] && echo f32 || ([ $P = 1 ] && echo bf16x3 || echo f32eq))
   CMD="bench.py --precision $P --steps 20 --warmup 5 --no-cpu-baseline --no-extras --profile-steps 0"
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats_$N -o run -- python3 $R/$CMD > $O/${N}_bench_under_rocprof.json 2> /dev/null
   cp $(find /tmp/p_stats_$N -name "*kernel_stats.csv" | head -1) $O/${N}_kernel_stats.csv
