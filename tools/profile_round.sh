@@ -23,4 +23,7 @@ for c in 4 5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c$c -o run -- python3 $R/bench.py --config $c --steps 20 --no-cpu-baseline --profile-steps 0 > $O/config${c}_under_rocprof.json 2> /dev/null
   cp $(find /tmp/p_c$c -name "*kernel_stats.csv" | head -1) $O/config${c}_kernel_stats.csv
 done
+python3 $R/tools/x6_error.py > $O/x6_error.txt 2>&1
+python3 $R/tools/lmfb_bench.py 2048 > $O/lmfb_ablation.txt 2>&1
+bash $R/tools/r03_pmc_mfma.sh $TAG > /dev/null 2>&1
 ls -la $O
