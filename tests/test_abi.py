@@ -100,3 +100,32 @@ def test_config_flags_match_reference_defaults():
     c, _ = get_config([])
     assert (c.trainer, c.batch_size, c.nFeat, c.rnn_size, c.rnn_layers, c.lr, c.beta1, c.gamma, c.lambda_k, c.max_iter) == \
         ("AAS", 20, 40, 500, 4, 1e-5, 0.5, 0.5, 0.001, 30000000)
+
+
+def test_bench_launcher_builds_the_torchrun_command_and_relays(monkeypatch, capsys):
+    """bench.spawn_ranks (CPU, no GPU touched): fewer devices than ranks -> exit code 3 and a message; enough devices -> one child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`, rank 0's JSON
+    line relayed on stdout, the child's exit code returned."""
+    import subprocess
+    import sys
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert bench.spawn_ranks(2) == 3
+    assert "only 1 device" in capsys.readouterr().err
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7, stdout='RCCL banner\n{"metric": "m", "value": 1.0, "n_gpus": 4}\n')
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    rc = bench.spawn_ranks(4)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 7 and out == ['{"metric": "m", "value": 1.0, "n_gpus": 4}']
+    c = seen["cmd"]
+    assert c[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and c[c.index("--nproc-per-node") + 1] == "4"
+    assert c[c.index("--master-addr") + 1] == "127.0.0.1" and c[-4:] == ["--gpus", "4", "--steps", "3"] and c[-5].endswith("bench.py")
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
