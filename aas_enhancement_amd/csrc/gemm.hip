@@ -3,6 +3,8 @@
 // register-prefetch double buffering.  Exact fp32 (k-ordered fma chain).
 // Replaces the cuBLAS/cuDNN GEMMs below nn.LSTM/nn.GRU/nn.Conv1d/nn.Linear
 // (reference Speech_enhancement_by_AAS/model.py:73-74,94-95,216-217,289,297,317).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -34,13 +36,13 @@ __device__ __forceinline__ int64_t krow_addr(int r, int kdiv, int64_t kouter, in
     return kdiv > 0 ? (int64_t)(r / kdiv) * kouter + (int64_t)(r % kdiv) * ld : (int64_t)r * ld;
 }
 
-// k-contiguous operand: tile [128 rows][16 k]; two float4 per thread.
-template <bool VEC>
+// k-contiguous operand: tile [128 rows][16 k]; 512 / NTH float4 per thread (NTH = threads of the workgroup).
+template <bool VEC, int NTH = 256>
 __device__ __forceinline__ void load_kcontig(const float* __restrict__ base, int64_t ld, int row0, int rmax,
-                                             int k0, int kend, int tid, f32x4 (&r)[2]) {
+                                             int k0, int kend, int tid, f32x4 (&r)[512 / NTH]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int idx = tid + i * 256;
+    for (int i = 0; i < 512 / NTH; ++i) {
+        int idx = tid + i * NTH;
         int row = idx >> 2, kq = idx & 3;
         int gr = row0 + row, gk = k0 + kq * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -58,10 +60,11 @@ __device__ __forceinline__ void load_kcontig(const float* __restrict__ base, int
         r[i] = v;
     }
 }
-__device__ __forceinline__ void store_kcontig(float (*S)[LDT], int tid, const f32x4 (&r)[2]) {
+template <int NTH = 256>
+__device__ __forceinline__ void store_kcontig(float (*S)[LDT], int tid, const f32x4 (&r)[512 / NTH]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int idx = tid + i * 256;
+    for (int i = 0; i < 512 / NTH; ++i) {
+        int idx = tid + i * NTH;
         int row = idx >> 2, kq = idx & 3;
         S[kq * 4 + 0][row] = r[i].x;
         S[kq * 4 + 1][row] = r[i].y;
@@ -70,13 +73,13 @@ __device__ __forceinline__ void store_kcontig(float (*S)[LDT], int tid, const f3
     }
 }
 // row-contiguous operand ([K, cols], cols contiguous): tile [16 k][128 cols]
-template <bool VEC>
+template <bool VEC, int NTH = 256>
 __device__ __forceinline__ void load_rcontig(const float* __restrict__ base, int64_t ld, int kdiv, int64_t kouter,
-                                             int c0, int cmax, int k0, int kend, int tid, f32x4 (&r)[2],
+                                             int c0, int cmax, int k0, int kend, int tid, f32x4 (&r)[512 / NTH],
                                              const float* __restrict__ kscale = nullptr, int knb = 1) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int idx = tid + i * 256;
+    for (int i = 0; i < 512 / NTH; ++i) {
+        int idx = tid + i * NTH;
         int kr = idx >> 5, cq = idx & 31;
         int gk = k0 + kr, gc = c0 + cq * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -98,21 +101,27 @@ __device__ __forceinline__ void load_rcontig(const float* __restrict__ base, int
         r[i] = v;
     }
 }
-__device__ __forceinline__ void store_rcontig(float (*S)[LDT], int tid, const f32x4 (&r)[2]) {
+template <int NTH = 256>
+__device__ __forceinline__ void store_rcontig(float (*S)[LDT], int tid, const f32x4 (&r)[512 / NTH]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int idx = tid + i * 256;
+    for (int i = 0; i < 512 / NTH; ++i) {
+        int idx = tid + i * NTH;
         int kr = idx >> 5, cq = idx & 31;
         *reinterpret_cast<f32x4*>(&S[kr][cq * 4]) = r[i];
     }
 }
 
-template <bool A_KC, bool B_KC, bool VECA, bool VECB>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
+// W8: eight waves per workgroup (4 x 2, wave tile 32 x 64) instead of four (2 x 2, 64 x 64) - two waves per SIMD from ONE
+// workgroup and 65 registers per lane instead of 184-204, so up to four workgroups fit a CU: a single wave per SIMD had nothing to
+// cover its LDS and barrier waits (the plane GEMMs do the same for sparse grids, gemm_planes.hip).
+template <bool A_KC, bool B_KC, bool VECA, bool VECB, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256) void gemm_f32_kernel(GemmP p) {
+    constexpr int NTH = W8 ? 512 : 256, NLD = 512 / NTH, MI = W8 ? 1 : 2;
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const int mrow = wm * (W8 ? 32 : 64);       // first tile row of this wave
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     int z = blockIdx.z;
     const float* A = p.A;
@@ -132,24 +141,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
         C += (int64_t)z * p.sC;
         if (addend) addend += (int64_t)z * p.sC;
     }
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[2], rb[2];
+    f32x4 ra[NLD], rb[NLD];
     auto gload = [&](int k0) {
-        if (A_KC) load_kcontig<VECA>(A, p.lda, m0, p.M, k0, kend, tid, ra);
-        else load_rcontig<VECA>(A, p.lda, p.kdivA, p.kouterA, m0, p.M, k0, kend, tid, ra, p.kscale, p.knb);
-        if (B_KC) load_kcontig<VECB>(B, p.ldb, n0, p.N, k0, kend, tid, rb);
-        else load_rcontig<VECB>(B, p.ldb, p.kdivB, p.kouterB, n0, p.N, k0, kend, tid, rb);
+        if (A_KC) load_kcontig<VECA, NTH>(A, p.lda, m0, p.M, k0, kend, tid, ra);
+        else load_rcontig<VECA, NTH>(A, p.lda, p.kdivA, p.kouterA, m0, p.M, k0, kend, tid, ra, p.kscale, p.knb);
+        if (B_KC) load_kcontig<VECB, NTH>(B, p.ldb, n0, p.N, k0, kend, tid, rb);
+        else load_rcontig<VECB, NTH>(B, p.ldb, p.kdivB, p.kouterB, n0, p.N, k0, kend, tid, rb);
     };
     auto sstore = [&](int buf) {
-        if (A_KC) store_kcontig(As[buf], tid, ra); else store_rcontig(As[buf], tid, ra);
-        if (B_KC) store_kcontig(Bs[buf], tid, rb); else store_rcontig(Bs[buf], tid, rb);
+        if (A_KC) store_kcontig<NTH>(As[buf], tid, ra); else store_rcontig<NTH>(As[buf], tid, ra);
+        if (B_KC) store_kcontig<NTH>(Bs[buf], tid, rb); else store_rcontig<NTH>(Bs[buf], tid, rb);
     };
     gload(kbeg);
     sstore(0);
@@ -161,14 +170,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
         if (more) gload(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a0 = As[buf][kk + lh][wm * 64 + l31];
-            float a1 = As[buf][kk + lh][wm * 64 + 32 + l31];
+            float a0 = As[buf][kk + lh][mrow + l31];
             float b0 = Bs[buf][kk + lh][wn * 64 + l31];
             float b1 = Bs[buf][kk + lh][wn * 64 + 32 + l31];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if constexpr (!W8) {
+                float a1 = As[buf][kk + lh][mrow + 32 + l31];
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
         if (more) sstore(buf ^ 1);
         __syncthreads();
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool first = (p.splitk <= 1) || (z == 0);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MI; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             int n = n0 + wn * 64 + nt * 32 + l31;
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
             float bv = (p.bias && first) ? p.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int m = m0 + mrow + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= p.M) continue;
                 float v = acc[mt][nt][r] + bv;
                 if (addend && first) v += addend[(int64_t)m * p.ldd + n];
@@ -435,7 +446,13 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 template <bool A_KC, bool B_KC>
 void launch(const GemmP& p, bool va, bool vb, dim3 grid, hipStream_t s) {
-    if (va && vb) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, true>), grid, dim3(256), 0, s, p);
+    // eight waves per workgroup whenever both operands take 16-byte loads (debug bit 1073741824: always four; AAS_GEMM_W8_MAX=n: only
+    // for grids below n workgroups).  Same box, config-2 step: four waves 31.7-31.8 ms, eight waves below 512 workgroups 30.9-31.1,
+    // always 30.8; alone on the chip the 2000 x 500 x 6000 weight-gradient product 0.176 -> 0.149 ms, the GRU's 0.255 -> 0.204.
+    static const int64_t w8_max = getenv("AAS_GEMM_W8_MAX") ? atoll(getenv("AAS_GEMM_W8_MAX")) : (int64_t)1 << 40;
+    const bool w8 = va && vb && (int64_t)grid.x * grid.y * grid.z < w8_max && !(p.flags & 1073741824);
+    if (w8) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, true, true>), grid, dim3(512), 0, s, p);
+    else if (va && vb) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, true>), grid, dim3(256), 0, s, p);
     else if (va) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, false>), grid, dim3(256), 0, s, p);
     else if (vb) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, false>), grid, dim3(256), 0, s, p);
