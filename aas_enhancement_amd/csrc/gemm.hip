@@ -485,7 +485,10 @@ static int gemm_f32_impl(aasStream_t stream, int mode, int M, int N, int K, cons
     const bool split_prec = aas_precision_value() == 1;
     // TN (weight gradients: tiny MxN, deep K) wants >= 2 blocks per CU to hide the k-step latency; its atomic
     // epilogue traffic (splitk x MxN x 4 B at ~1.3 TB/s) stays far below the time saved
-    const int target = ((split_prec || (p.flags & 268435456)) && mode == AAS_GEMM_TN) ? 512 : 256;
+    // fp32 kernel (eight light waves per workgroup, up to four workgroups per CU): two workgroups per CU for every mode
+    // (config-2 step, same box: target 256: 30.9 ms, 384: 30.7-30.9, 512: 30.55-30.6, 640: 30.65-30.7, 1024: 31.2, 128: 32.6-33.1)
+    static const int sk_target = getenv("AAS_GEMM_SK_TARGET") ? atoi(getenv("AAS_GEMM_SK_TARGET")) : 0;   // experiment switch
+    const int target = sk_target > 0 ? sk_target : (!split_prec || mode == AAS_GEMM_TN) ? 512 : 256;
     if (batch == 1 && blocks < (target * 3) / 4 && K >= 1024) {
         int want = (target + blocks - 1) / blocks;
         int maxs = K / 256;
