@@ -448,9 +448,9 @@ class Trainer(object):
             # down, beside E's backward half of the chip is free.  Not all of them: E's backward phase has room for about two D
             # layers on top of E's own (16.7 -> 16.1 ms with two, 16.2 with three, 16.5 with one).
             ops.DEFER_LIDS.clear()
-            # (fp32 mode: the fp32 weight-gradient GEMMs keep their stream busy for the whole backward phase - 13 ms of launches
-            #  per step - so holding any of them back only lengthens the tail behind E's last BPTT launch: 32.3 vs 31.7 ms)
-            for net, env, dflt in ((self.D, "AAS_DEFER_D_LAYERS", 2 if ops.get_precision() == 1 else 0), (self.ASR, "AAS_DEFER_A_LAYERS", 0)):
+            # (fp32 mode, same-box runs: 0 / 1 / 2 / 3 / 4 held-back layers = 30.6-31.0 / 30.1 / 29.9-30.4 / 30.2-30.3 / 30.1-30.2 ms
+            #  with the eight-wave fp32 GEMM; with the four-wave one the weight-gradient stream was saturated and 0 was best)
+            for net, env, dflt in ((self.D, "AAS_DEFER_D_LAYERS", 2), (self.ASR, "AAS_DEFER_A_LAYERS", 0)):
                 ndef = int(os.environ.get(env, str(dflt)))
                 if ndef > 0:
                     lids = [m._aas_layer_id for m in net.modules() if getattr(m, "_aas_layer_id", None) is not None]
