@@ -108,7 +108,7 @@ def _run_child(target, *extra):
     return out
 
 
-@pytest.mark.parametrize("precision", ["0", "1"], ids=["fp32", "splitbf16"])
+@pytest.mark.parametrize("precision", ["0", "1", "2"], ids=["fp32", "splitbf16", "fp32eq"])
 def test_aas_async_steps_on_one_rank_rccl_config2_buckets_and_goldens(precision):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
