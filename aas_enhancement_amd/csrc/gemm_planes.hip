@@ -291,7 +291,7 @@ __device__ __forceinline__ void store_sets(const float (&v)[8], char* q1, char* 
 }
 
 __global__ __launch_bounds__(256) void split_rows3_kernel(const float* __restrict__ src, int64_t ld, int64_t R, int K, int Kp,
-                                                          char* __restrict__ q1, char* __restrict__ q2) {
+                                                          char* __restrict__ q1, char* __restrict__ q2, int64_t pitch) {
     const int cpr = Kp / 8;
     const int64_t total = R * cpr;
     const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
@@ -307,13 +307,13 @@ __global__ __launch_bounds__(256) void split_rows3_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (k + e < K) ? s[e] : 0.f;
         }
-        store_sets(v, q1, q2, r * (int64_t)Kp * 4, k);
+        store_sets(v, q1, q2, r * pitch, k);
     }
 }
 
 __global__ __launch_bounds__(256) void add3_planes3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
                                                            float* __restrict__ out, int64_t R, int K, int Kp, char* __restrict__ q1,
-                                                           char* __restrict__ q2) {
+                                                           char* __restrict__ q2, int64_t pitch) {
     const int cpr = Kp / 8;
     const int64_t total = R * cpr;
     const bool vec = (K & 3) == 0;
@@ -340,13 +340,13 @@ __global__ __launch_bounds__(256) void add3_planes3_kernel(const float* __restri
                 }
             }
         }
-        store_sets(v, q1, q2, r * (int64_t)Kp * 4, k);
+        store_sets(v, q1, q2, r * pitch, k);
     }
 }
 
 // transposing form (the weights' transposed operand of the input-gradient product): see split_rows_t_kernel
 __global__ __launch_bounds__(256) void split_rows_t3_kernel(const float* __restrict__ src, int64_t ld, int T, int nb, int nbp, int Cc,
-                                                            int64_t Kp, char* __restrict__ q1, char* __restrict__ q2, int64_t tstride) {
+                                                            int64_t Kp, char* __restrict__ q1, char* __restrict__ q2, int64_t tstride, int64_t pitch) {
     __shared__ float tile[64][65];
     const int c0 = blockIdx.x * 64;
     const int64_t k0 = (int64_t)blockIdx.y * 64;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void split_rows_t3_kernel(const float* __restr
         if (c < Cc && kpos < Kp) {
             unsigned short h, m, l;
             split3(tile[tx][cc], h, m, l);
-            const int64_t o = (int64_t)c * Kp * 4 + (kpos >> 5) * 128 + (kpos & 31) * 2;
+            const int64_t o = (int64_t)c * pitch + (kpos >> 5) * 128 + (kpos & 31) * 2;
             *reinterpret_cast<unsigned short*>(q1 + o) = m;
             *reinterpret_cast<unsigned short*>(q1 + o + 64) = h;
             *reinterpret_cast<unsigned short*>(q2 + o) = h;
@@ -682,20 +682,25 @@ extern "C" int aas_split_planes_t2(aasStream_t stream, const float* src, int64_t
 }
 
 // ---- producers of the three-term plane sets (aas_set_precision(2): see split3 above) --------------------------------------------
-extern "C" int aas_split_planes3(aasStream_t stream, const float* src, int64_t ld, int64_t rows, int K, int Kp, void* planes_q1, void* planes_q2) {
+extern "C" int aas_split_planes3(aasStream_t stream, const float* src, int64_t ld, int64_t rows, int K, int Kp, void* planes_q1, void* planes_q2,
+                                 int64_t row_pitch_bytes) {
     AAS_CHECK(src && planes_q1 && planes_q2 && rows >= 0 && K >= 0 && Kp >= K && Kp % 32 == 0, "aas_split_planes3: bad arguments (K=%d Kp=%d)", K, Kp);
+    const int64_t pitch = row_pitch_bytes > 0 ? row_pitch_bytes : (int64_t)Kp * 4;
+    AAS_CHECK(pitch >= (int64_t)Kp * 4 && pitch % 128 == 0, "aas_split_planes3: row pitch must be a multiple of 128 bytes and hold Kp columns");
     if (rows == 0 || Kp == 0) return 0;
     const int64_t total = rows * (Kp / 8);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(split_rows3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, ld, rows, K, Kp, (char*)planes_q1,
-                       (char*)planes_q2);
+                       (char*)planes_q2, pitch);
     AAS_LAUNCH_CHECK("aas_split_planes3");
     return 0;
 }
 
 extern "C" int aas_add3_planes3_f32(aasStream_t stream, float* out, const float* a, const float* b, const float* c, int64_t rows, int K, int Kp,
-                                    void* planes_q1, void* planes_q2) {
+                                    void* planes_q1, void* planes_q2, int64_t row_pitch_bytes) {
+    const int64_t pitch = row_pitch_bytes > 0 ? row_pitch_bytes : (int64_t)Kp * 4;
+    AAS_CHECK(pitch >= (int64_t)Kp * 4 && pitch % 128 == 0, "aas_add3_planes3_f32: row pitch must be a multiple of 128 bytes and hold Kp columns");
     AAS_CHECK(out && a && b && planes_q1 && planes_q2 && rows >= 0 && K >= 1 && Kp >= K && Kp % 32 == 0, "aas_add3_planes3_f32: bad arguments (K=%d Kp=%d)", K, Kp);
     AAS_CHECK(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0,
               "aas_add3_planes3_f32: operands must be 16-byte aligned");
@@ -704,17 +709,19 @@ extern "C" int aas_add3_planes3_f32(aasStream_t stream, float* out, const float*
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(add3_planes3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, out, rows, K, Kp,
-                       (char*)planes_q1, (char*)planes_q2);
+                       (char*)planes_q1, (char*)planes_q2, pitch);
     AAS_LAUNCH_CHECK("aas_add3_planes3_f32");
     return 0;
 }
 
 extern "C" int aas_split_planes_t3(aasStream_t stream, const float* src, int64_t ld, int64_t tstride, int T, int nb, int nbp, int C, int64_t Kp,
-                                   void* planes_q1, void* planes_q2) {
+                                   void* planes_q1, void* planes_q2, int64_t row_pitch_bytes) {
+    const int64_t pitch = row_pitch_bytes > 0 ? row_pitch_bytes : Kp * 4;
+    AAS_CHECK(pitch >= Kp * 4 && pitch % 128 == 0, "aas_split_planes_t3: row pitch must be a multiple of 128 bytes and hold Kp columns");
     AAS_CHECK(src && planes_q1 && planes_q2 && T >= 1 && nb >= 1 && nbp >= nb && nbp % 8 == 0 && C >= 1 && Kp >= (int64_t)T * nbp && Kp % 32 == 0,
               "aas_split_planes_t3: bad arguments (T=%d nb=%d nbp=%d C=%d Kp=%lld)", T, nb, nbp, C, (long long)Kp);
     hipLaunchKernelGGL(split_rows_t3_kernel, dim3(cdiv(C, 64), (unsigned)((Kp + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src, ld, T, nb, nbp,
-                       C, Kp, (char*)planes_q1, (char*)planes_q2, tstride != 0 ? tstride : (int64_t)nb * ld);
+                       C, Kp, (char*)planes_q1, (char*)planes_q2, tstride != 0 ? tstride : (int64_t)nb * ld, pitch);
     AAS_LAUNCH_CHECK("aas_split_planes_t3");
     return 0;
 }

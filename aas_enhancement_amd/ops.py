@@ -290,49 +290,58 @@ def _kp(K):
 
 class Planes3(object):
     """The two plane sets of a three-term operand (include/aas_hip.h: aas_split_planes3): q1 = (m | h), q2 = (h | l), each in the
-    layout of `Planes`.  A product of two such operands is two passes of the three-product plane kernels (gemm_planes6)."""
-    __slots__ = ("q1", "q2", "rows", "K", "Kp")
+    layout of `Planes`, side by side in ONE buffer `buf` [rows, 2 * 2*Kp] bf16 - set 1 in the first 4 Kp bytes of a row, set 2 in
+    the next 4 Kp.  Read as a single operand of k extent 2 Kp the row is (Q1 | Q2), so an NT product of two such operands is ONE
+    launch of the three-product plane kernel (gemm_planes6); the row-major weight-gradient products take the column halves."""
+    __slots__ = ("buf", "rows", "K", "Kp")
 
-    def __init__(self, q1, q2, rows, K, Kp):
-        self.q1, self.q2, self.rows, self.K, self.Kp = q1, q2, rows, K, Kp
+    def __init__(self, buf, rows, K, Kp):
+        self.buf, self.rows, self.K, self.Kp = buf, rows, K, Kp
 
-    def sets(self):
-        return (Planes(self.q1, self.rows, self.K, self.Kp), Planes(self.q2, self.rows, self.K, self.Kp))
+    @property
+    def pitch(self):
+        return 8 * self.Kp                   # bytes per row of either set
+
+    def set_ptr(self, i, row0=0):
+        return self.buf.data_ptr() + row0 * self.pitch + i * 4 * self.Kp
 
     def to_float(self):
         """[rows, Kp] fp32 reconstruction h + m + l (tests): exact."""
-        a = self.q1.view(self.rows, self.Kp // 32, 2, 32).float()    # (m | h)
-        b = self.q2.view(self.rows, self.Kp // 32, 2, 32).float()    # (h | l)
+        v = self.buf.view(self.rows, 2, self.Kp // 32, 2, 32).float()
+        a, b = v[:, 0], v[:, 1]                                       # (m | h), (h | l)
         return ((a[:, :, 1, :] + a[:, :, 0, :]) + b[:, :, 1, :]).reshape(self.rows, self.Kp)
 
 
-def split_planes3(x2d, rows, K, ld=None, off=0):
+def _new_planes3(rows, K, dev):
     Kp = _kp(K)
-    q1 = torch.empty((rows, 2 * Kp), device=x2d.device, dtype=torch.bfloat16)
-    q2 = torch.empty((rows, 2 * Kp), device=x2d.device, dtype=torch.bfloat16)
-    check(lib().aas_split_planes3(stream(), x2d.data_ptr() + 4 * off, ld if ld is not None else K, rows, K, Kp, ptr(q1), ptr(q2)), "aas_split_planes3")
-    return Planes3(q1, q2, rows, K, Kp)
+    return Planes3(torch.empty((rows, 4 * Kp), device=dev, dtype=torch.bfloat16), rows, K, Kp)
+
+
+def split_planes3(x2d, rows, K, ld=None, off=0):
+    p3 = _new_planes3(rows, K, x2d.device)
+    check(lib().aas_split_planes3(stream(), x2d.data_ptr() + 4 * off, ld if ld is not None else K, rows, K, p3.Kp, p3.set_ptr(0), p3.set_ptr(1),
+                                  p3.pitch), "aas_split_planes3")
+    return p3
 
 
 def add3_planes3(a, b, c, K):
     """out = a + b (+ c) plus its three-term plane sets (the next layer's input operand in the fp32-equivalent mode)."""
     out = torch.empty_like(a)
-    rows = a.numel() // K
-    Kp = _kp(K)
-    q1 = torch.empty((rows, 2 * Kp), device=a.device, dtype=torch.bfloat16)
-    q2 = torch.empty((rows, 2 * Kp), device=a.device, dtype=torch.bfloat16)
-    check(lib().aas_add3_planes3_f32(stream(), ptr(out), ptr(a), ptr(b), ptr(c), rows, K, Kp, ptr(q1), ptr(q2)), "aas_add3_planes3_f32")
-    return out, Planes3(q1, q2, rows, K, Kp)
+    p3 = _new_planes3(a.numel() // K, K, a.device)
+    check(lib().aas_add3_planes3_f32(stream(), ptr(out), ptr(a), ptr(b), ptr(c), p3.rows, K, p3.Kp, p3.set_ptr(0), p3.set_ptr(1), p3.pitch),
+          "aas_add3_planes3_f32")
+    return out, p3
 
 
-def gemm_planes6(M, N, K, A3, B3, C, ldc, bias=None, addend=None, ldd=0, accumulate=False, a_off=0, b_off=0, c_off=0):
-    """C[M,N] (+)= A[M,K] B[N,K]^T with every product carried to fp32's 24 operand bits: pass 1 on the (m | h) sets sums the small
-    terms m m' + h m' + m h' (+ bias / addend / the old C), pass 2 on the (h | l) sets adds h h' + l h' + h l'."""
-    (a1, a2), (b1, b2) = A3.sets(), B3.sets()
-    # (profiling: the two launches are ONE logical product - the algorithmic flops are counted once, on the first pass)
-    gemm_planes(M, N, K, a1, b1, C, ldc, bias=bias, addend=addend, ldd=ldd, accumulate=accumulate, a_off=a_off, b_off=b_off, c_off=c_off,
-                name="gemm_planes6")
-    gemm_planes(M, N, K, a2, b2, C, ldc, accumulate=True, a_off=a_off, b_off=b_off, c_off=c_off, name="gemm_planes6", count_flops=False)
+def gemm_planes6(M, N, K, A3, B3, C, ldc, bias=None, addend=None, ldd=0, accumulate=False):
+    """C[M,N] (+)= A[M,K] B[N,K]^T with every product carried to fp32's 24 operand bits, in one launch: over the (m | h) halves of
+    the rows the three-product kernel sums the small terms m m' + h m' + m h', over the (h | l) halves h h' + l h' + h l' - the
+    k extent it multiplies is 2 K (K = the operands' Kp)."""
+    assert K == A3.Kp == B3.Kp
+    # (profiling: the algorithmic flops of the ONE logical product, 2 M N K)
+    with _timed("gemm", "gemm_planes6", 2.0 * M * N * K):
+        check(lib().aas_gemm_planes(stream(), M, N, 2 * K, A3.buf.data_ptr(), 2 * A3.Kp, B3.buf.data_ptr(), 2 * B3.Kp, C.data_ptr(), ldc,
+                                    ptr(bias), ptr(addend), ldd, int(accumulate), 1, 0, 0, 0), "aas_gemm_planes")
 
 
 def split_planes(x2d, rows, K, ld=None, row_scale=None, nb=0, off=0):
@@ -646,12 +655,10 @@ def _wih_planes3(w_ih, w_ih_r, GH, I):
     if ent is not None and ent[0] == sig:
         _planes_ready(w_ih)
         return ent[1]
-    Kp = _kp(I)
-    q1 = torch.empty((2 * GH, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
-    q2 = torch.empty((2 * GH, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
-    check(lib().aas_split_planes3(stream(), ptr(w_ih), I, GH, I, Kp, ptr(q1), ptr(q2)), "aas_split_planes3")
-    check(lib().aas_split_planes3(stream(), ptr(w_ih_r), I, GH, I, Kp, q1.data_ptr() + GH * Kp * 4, q2.data_ptr() + GH * Kp * 4), "aas_split_planes3")
-    wb = Planes3(q1, q2, 2 * GH, I, Kp)
+    wb = _new_planes3(2 * GH, I, w_ih.device)
+    for d_, w_ in enumerate((w_ih, w_ih_r)):
+        check(lib().aas_split_planes3(stream(), ptr(w_), I, GH, I, wb.Kp, wb.set_ptr(0, d_ * GH), wb.set_ptr(1, d_ * GH), wb.pitch),
+              "aas_split_planes3")
     if ok:
         try:
             w_ih._aas_planes3 = (sig, wb)
@@ -667,12 +674,9 @@ def _wih_t_planes3(w_ih, w_ih_r, GH, I):
     if ent is not None and ent[0] == sig:
         _planes_ready(w_ih)
         return ent[1]
-    Kp = _kp(2 * GH)
-    q1 = torch.empty((I, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
-    q2 = torch.empty((I, 2 * Kp), device=w_ih.device, dtype=torch.bfloat16)
+    wt = _new_planes3(I, 2 * GH, w_ih.device)
     dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4
-    check(lib().aas_split_planes_t3(stream(), ptr(w_ih), I, dw, 2, GH, GH, I, Kp, ptr(q1), ptr(q2)), "aas_split_planes_t3")
-    wt = Planes3(q1, q2, I, 2 * GH, Kp)
+    check(lib().aas_split_planes_t3(stream(), ptr(w_ih), I, dw, 2, GH, GH, I, wt.Kp, wt.set_ptr(0), wt.set_ptr(1), wt.pitch), "aas_split_planes_t3")
     if ok and not torch.cuda.is_current_stream_capturing():
         try:
             w_ih._aas_planes3_t = (sig, wt)
@@ -723,7 +727,7 @@ def refresh_weight_planes(module):
                     bufs = (_wih_planes(w, wr, GH, I).buf,) + ((_wih_t_planes(w, wr, GH, I).buf,) if (PLANES_BWD[0] and w.requires_grad) else ())
                 else:
                     p3 = (_wih_planes3(w, wr, GH, I),) + ((_wih_t_planes3(w, wr, GH, I),) if (PLANES_BWD[0] and w.requires_grad) else ())
-                    bufs = tuple(b_ for x_ in p3 for b_ in (x_.q1, x_.q2))
+                    bufs = tuple(x_.buf for x_ in p3)
                 for t_ in bufs:
                     t_.record_stream(main)
                 done = torch.cuda.Event()
@@ -775,7 +779,7 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None):
     x2 = x.view(T * N, I)
     dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4  # element distance between the two directions' W_ih
     if _precision[0] == 2 and kind != "rnn" and PLANES_PRE[0] and T * N >= 1024 and I >= 64:
-        # fp32-equivalent mode: three-term plane sets of x and [W_ih; W_ih_rev], two passes of the plane GEMM (six products)
+        # fp32-equivalent mode: three-term plane sets of x and [W_ih; W_ih_rev], one plane-GEMM launch over both (six products)
         GH = G * H
         xa = getattr(x, "_aas_planes3", None)
         if xa is None or xa.rows != T * N or xa.K != I:
@@ -1000,20 +1004,19 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         dg3 = dga3 if dga3 is not None else split_planes3(dgx.view(R, 2 * GH), R, 2 * GH)
         dgh3 = dg3 if dgh is dgx else split_planes3(dgh.view(R, 2 * GH), R, 2 * GH)
         h3 = split_planes3(hout.view(2 * R, H), 2 * R, H)
-        lda = 4 * dg3.Kp
         for n0, ns, alpha in classes:
-            base = dict(lda=lda, acols=dg3.Kp, n0=n0, alpha=alpha)
-            for pi_, (a_x, a_h, b_x, b_h) in enumerate(((dg3.q1, dgh3.q1, xp3.q1, h3.q1), (dg3.q2, dgh3.q2, xp3.q2, h3.q2))):
-                hb, hpitch = b_h.data_ptr(), 4 * h3.Kp
-                probs = [dict(base, A=a_x.data_ptr(), B=b_x.data_ptr(), ldb=4 * xp3.Kp, bcols=xp3.Kp, acol0=0, M=2 * GH, N=I, K=T * ns,
+            base = dict(lda=dg3.pitch, acols=dg3.Kp, n0=n0, alpha=alpha)
+            for pi_ in (0, 1):                 # pass 1 on the (m | h) sets, pass 2 on the (h | l) sets, into the same gradients
+                hb = h3.set_ptr(pi_)
+                probs = [dict(base, A=dg3.set_ptr(pi_), B=xp3.set_ptr(pi_), ldb=xp3.pitch, bcols=xp3.Kp, acol0=0, M=2 * GH, N=I, K=T * ns,
                               C0=out[0].data_ptr(), C1=out[2].data_ptr(), msplit=GH, ldc=I, ta=0, tb=0),
-                         dict(base, A=a_h.data_ptr(), B=hb, ldb=hpitch, bcols=h3.Kp, acol0=0, M=GH, N=H, K=(T - 1) * ns,
+                         dict(base, A=dgh3.set_ptr(pi_), B=hb, ldb=h3.pitch, bcols=h3.Kp, acol0=0, M=GH, N=H, K=(T - 1) * ns,
                               C0=out[1].data_ptr(), C1=0, msplit=GH, ldc=H, ta=1, tb=0),
-                         dict(base, A=a_h.data_ptr(), B=hb + R * hpitch, ldb=hpitch, bcols=h3.Kp, acol0=GH, M=GH, N=H,
+                         dict(base, A=dgh3.set_ptr(pi_), B=hb + R * h3.pitch, ldb=h3.pitch, bcols=h3.Kp, acol0=GH, M=GH, N=H,
                               K=(T - 1) * ns, C0=out[3].data_ptr(), C1=0, msplit=GH, ldc=H, ta=0, tb=1)]
                 gemm_planes_tn(probs, ns, N, dev, accumulate=True, name="gemm_planes6_wgrad", count_flops=(pi_ == 0))
         cur = torch.cuda.current_stream()
-        for t_ in (dg3.q1, dg3.q2, dgh3.q1, dgh3.q2, xp3.q1, xp3.q2, h3.q1, h3.q2):
+        for t_ in (dg3.buf, dgh3.buf, xp3.buf, h3.buf):
             t_.record_stream(cur)
         return True
 
@@ -1076,7 +1079,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
                 if hook is not None:
                     hook(direct)
         for t_ in (dgx, dgh, dgp, dghp, x, hout) + ((keep["xp"].buf if "xp" in keep else None, keep.get("hx")) if keep else ()) + (
-                (dga3.q1, dga3.q2) if dga3 is not None else ()):
+                (dga3.buf,) if dga3 is not None else ()):
             if t_ is not None:
                 t_.record_stream(side)
         if DEFER_WGRAD[0] or lid in DEFER_LIDS:

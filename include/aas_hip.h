@@ -66,8 +66,8 @@ int aas_set_wgrad_wg_cap(int workgroups);
  *                 hi*hi + lo*hi + hi*lo with fp32 accumulation (16+ mantissa bits per operand, ~2^-17 per product: NARROWER than
  *                 fp32, inside the 1e-3 / 1e-2 parity budget; 3 bf16 MFMAs instead of 16 fp32-MFMA issue slots);
  *   2           = fp32-EQUIVALENT: the recurrent products and the small GEMMs as in mode 0 (fp32-input MFMA); the large GEMMs are
- *                 the caller's to run as six bf16 products of three-term operands (aas_split_planes3 + two passes of the plane
- *                 kernels, below): every product keeps all 24 operand bits, dropped cross terms <= 2^-25 relative. */
+ *                 the caller's to run as six bf16 products of three-term operands (aas_split_planes3 + the plane
+ *                 kernels over both plane sets, below): every product keeps all 24 operand bits, dropped cross terms <= 2^-25 relative. */
 int aas_set_precision(int mode);
 /* cap on the CUs one persistent recurrent launch occupies (0 = whole device): lets two independent chains of recurrent
  * launches (trainer_AAS.py:153-172: discriminator pass and acoustic pass) run side by side on two streams */
@@ -306,16 +306,21 @@ int aas_edit_distance(const int* h_a, int na, const int* h_b, int nb);
 
 /* ---------------------------------------------------------------- fp32-equivalent products on the bf16 pipes (precision 2) ----
  * Three-term operands: x = h + m + l exactly (h = rne_bf16(x), m = rne_bf16(x - h), l = rne_bf16(x - h - m): 24 significant bits).
- * The six products hh' + hm' + mh' + mm' + hl' + lh' (dropped terms <= 2^-25 |x y|: below fp32's rounding unit) are TWO passes of
- * the three-product plane kernels (aas_gemm_planes / aas_gemm_planes_tn) over two plane sets of each operand, both in the plane layout
- * of aas_split_planes:  set Q1 = (m | h)  ->  m m' + h m' + m h',   set Q2 = (h | l)  ->  h h' + l h' + h l';  the second pass
- * accumulates into the first one's result.  These entry points write both sets in one pass over the fp32 source. */
-int aas_split_planes3(aasStream_t stream, const float* src, int64_t ld, int64_t rows, int K, int Kp, void* planes_q1, void* planes_q2);
+ * The six products hh' + hm' + mh' + mm' + hl' + lh' (dropped terms <= 2^-25 |x y|: below fp32's rounding unit) are the
+ * three-product plane kernels (aas_gemm_planes / aas_gemm_planes_tn) over two plane sets of each operand, both in the plane layout
+ * of aas_split_planes:  set Q1 = (m | h)  ->  m m' + h m' + m h',   set Q2 = (h | l)  ->  h h' + l h' + h l';  the two partial
+ * results add up (in the accumulators of one launch, or by a second, accumulating launch).  These entry points write both sets in one pass over the fp32 source.
+ * `row_pitch_bytes` (0 = 4 Kp): bytes between the rows of each set.  With ONE buffer of pitch 8 Kp, set Q1 at its start and set Q2 at
+ * byte 4 Kp of every row, the two sets are the two halves of a k-extent of 2 Kp: an NT product then takes ONE launch of
+ * aas_gemm_planes with K = 2 Kp (both passes accumulate in registers); the row-major weight-gradient product (reduction over rows)
+ * still takes two launches, on the two column halves. */
+int aas_split_planes3(aasStream_t stream, const float* src, int64_t ld, int64_t rows, int K, int Kp, void* planes_q1, void* planes_q2,
+                      int64_t row_pitch_bytes);
 int aas_add3_planes3_f32(aasStream_t stream, float* out, const float* a, const float* b, const float* c, int64_t rows, int K, int Kp,
-                         void* planes_q1, void* planes_q2);
+                         void* planes_q1, void* planes_q2, int64_t row_pitch_bytes);
 /* transposed sets (aas_split_planes_t2's addressing): src[(t*tstride) + n*ld + c] -> planes[c][t*nbp + n] */
 int aas_split_planes_t3(aasStream_t stream, const float* src, int64_t ld, int64_t tstride, int T, int nb, int nbp, int C, int64_t Kp,
-                        void* planes_q1, void* planes_q2);
+                        void* planes_q1, void* planes_q2, int64_t row_pitch_bytes);
 
 /* ---------------------------------------------------------------- optimiser -------------------
  * torch.optim.Adam(amsgrad=True/False) element-wise update (trainer_AAS.py:127-129,185-188;
