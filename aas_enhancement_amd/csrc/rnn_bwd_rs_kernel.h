@@ -30,7 +30,13 @@ namespace {
 
 // MODE = LSTM_BWD or GRU_BWD; U = units per workgroup (16: 256 threads, 32: 512 threads - half as many slices, so
 // half the exchanged bytes chip-wide); NTW = 16-column result tiles per wave (P <= 4*NTW)
-template <int MODE, int U, int NTW, int LKSP = -1, bool EX = false>
+//
+// R4 (exact mode, row groups of <= 8 rows): the partial product on v_mfma_f32_4x4x1_16B_f32 - sixteen independent 4 x 4 x 1 blocks
+// per instruction, here 64 columns x 4 batch rows x one k (block b, D[lane 4b+j][reg i] = A[lane 4b+i] * B[lane 4b+j]: A = the W
+// value of column 4b+i, B = d(gates) of row j).  A 16 x 16 x 4 tile spends its 32 cycles on 16 rows whether 4 or 16 of them
+// exist; this form spends 8 cycles per k on every 4 rows that do, at the same peak rate - E's BPTT (N=30 over the whole chip:
+// 4 rows per group; over half of it: 8) issues a quarter / half of the MFMA cycles.
+template <int MODE, int U, int NTW, int LKSP = -1, bool EX = false, bool R4 = false>
 __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     using C = Cfg<MODE>;
     constexpr int G = C::G;
@@ -52,6 +58,9 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     // fragments of its last k-step live in LDS instead (64 KB, re-read once per step) so that nothing spills
     constexpr int LKS = LKSP >= 0 ? LKSP : ((!LSTM && U == 32 && NTW == 8) ? AAS_GRU_BWD_LKS : 0);
     __shared__ u32x4 bl_lds[LKS ? LKS * NTW : 1][LKS ? THREADS : 1];
+    static_assert(!R4 || (EX && LKS == 0 && NTW % 4 == 0), "R4: exact mode, all of W in registers, 64-column groups per wave");
+    constexpr int CG = R4 ? NTW / 4 : 1;                  // 64-column groups per wave
+    constexpr int KT = KSTEPS * 32;                       // k extent of my d(gates) slice (padded)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware launch (p.xcd != 0; 8 (direction, row group) sets): 1-D grid, workgroup b -> set b % 8, slice b / 8.  Workgroups
@@ -74,8 +83,19 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
 
     // ---- B fragments: rows {g*H + u0 + u} of W_hh (k' = g*16 + u, padded to 64) x all Hp columns --------------
     const float* W = d == 0 ? p.w_hh : p.w_hh_r;
-    u32x4 b0[KSTEPS][NTW], b1[KSTEPS][NTW];     // (rnn_split_kernel.h: frag_make)
-    {
+    u32x4 b0[R4 ? 1 : KSTEPS][R4 ? 1 : NTW], b1[R4 ? 1 : KSTEPS][R4 ? 1 : NTW];     // (rnn_split_kernel.h: frag_make)
+    float wr[R4 ? CG : 1][R4 ? KT : 1];         // R4: W[k' row][my column] - lane l of column group cg owns column (wave*NTW*16 + cg*64 + l)
+    if constexpr (R4) {
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+            const int col = wave * NTW * 16 + cg * 64 + lane;
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) {
+                const int gate = kk / U, unit = u0 + kk % U;
+                wr[cg][kk] = (gate < G && unit < H && col < H) ? W[(int64_t)(gate * H + unit) * H + col] : 0.f;
+            }
+        }
+    } else {
         const int n = lane & 15, q = lane >> 4;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks)
@@ -326,6 +346,47 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
         if (stamp) st3 = __builtin_amdgcn_s_memrealtime();
 
         // ---- partial dh for all units: [16 rows x 64] x [64 x Hp], published to the consumers' blocks ---
+        if constexpr (R4) {
+            if (s + 1 < T) {
+                const unsigned tag = (unsigned)(s % 3);
+                const int slot = s & 1;
+                const int j = lane & 3, b4 = (lane >> 2) * 4;        // batch row within the 4-row block; first of my 4 result columns
+                const int nrb = (nrows + 3) >> 2;
+                for (int rb = 0; rb < nrb; ++rb) {
+                    const int prow = rb * 4 + j;
+                    const float* arow = &a_f[par][prow][0];
+#pragma unroll
+                    for (int cg = 0; cg < CG; ++cg) {
+                        // four independent accumulation chains (k mod 4): back-to-back issue without waiting on the previous result
+                        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+                        if (!(p.flags & 2)) {
+#pragma unroll
+                            for (int k4 = 0; k4 < KT / 4; ++k4) {
+                                const f32x4 dv = *reinterpret_cast<const f32x4*>(arow + k4 * 4);
+                                c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[cg][k4 * 4 + 0], dv[0], c0, 0, 0, 0);
+                                c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[cg][k4 * 4 + 1], dv[1], c1, 0, 0, 0);
+                                c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[cg][k4 * 4 + 2], dv[2], c2, 0, 0, 0);
+                                c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[cg][k4 * 4 + 3], dv[3], c3, 0, 0, 0);
+                            }
+                        }
+                        const f32x4 acc = (c0 + c1) + (c2 + c3);
+                        const int col = wave * NTW * 16 + cg * 64 + b4;      // lane holds columns col .. col+3 of batch row prow
+                        const int c = col / U;
+                        if (c < P && prow < nrows && !(p.flags & 8)) {
+                            u32x4 o;    // (tag in the two low mantissa bits, rounded to nearest: see below)
+                            o.x = ((__float_as_uint(acc[0]) + 2u) & ~3u) | tag;
+                            o.y = ((__float_as_uint(acc[1]) + 2u) & ~3u) | tag;
+                            o.z = ((__float_as_uint(acc[2]) + 2u) & ~3u) | tag;
+                            o.w = ((__float_as_uint(acc[3]) + 2u) & ~3u) | tag;
+                            const int64_t rblk = ((int64_t)(slot * 2 + d) * N + q0 + prow) * P;
+                            const unsigned boff = (unsigned)((((rblk + c) * P + pslice) * U + col % U) * 4);
+                            if ((local >> c) & 1ull) __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b128(o, rs_x, (int)boff, 0, 16);
+                        }
+                    }
+                }
+            }
+        } else
         if (s + 1 < T) {
             const int m = lane & 15, q = lane >> 4;
             u32x4 ah[KSTEPS], al[KSTEPS];
@@ -402,6 +463,13 @@ template <int MODE, int U, bool EX>
 int launch_rs(const RnnP& p, hipStream_t s) {
     dim3 grid(p.P, p.Q, 2), block(16 * U);
     if (p.xcd) grid = dim3(p.P * p.Q * 2);
+    if constexpr (EX && MODE == LSTM_BWD && U == 32) {
+        // <= 8 rows per group: the 4 x 4 x 1 block form (debug bit 268435456: the 16 x 16 x 4 tiles)
+        if (p.rpg <= 8 && p.P > 8 && p.P <= 16 && !(p.flags & 268435456)) {
+            hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 4, -1, true, true>), grid, block, 0, s, p);
+            return 0;
+        }
+    }
     if (p.P <= 8) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 2, -1, EX>), grid, block, 0, s, p);
     else if (p.P <= 16) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 4, -1, EX>), grid, block, 0, s, p);
     else if (p.P <= 32) {

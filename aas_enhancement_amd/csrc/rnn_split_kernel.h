@@ -134,7 +134,14 @@ __device__ __forceinline__ bool xcd_set_colocated(unsigned* tab, int set, int ps
 }
 
 // MODE, MT = 16-row batch tiles per workgroup, KS = 32-wide k chunks per wave
-template <int MODE, int MT, int KS, bool EX = false>
+//
+// NRB > 0 (exact forward modes, row groups of <= 4 NRB <= 8 rows): the recurrent product on v_mfma_f32_4x4x1_16B_f32 - sixteen 4 x 4 x 1
+// blocks per instruction, D[lane 4b+j][reg i] = A[lane 4b+i] * B[lane 4b+j], and with the A broadcast (cbsz = 4, abid = a) every block
+// takes block a's A lanes (tools/probe/mfma4x4.hip).  Here B = the W value of gate column `lane`, A = h_{t-1}: lane 4b+i of a 16-byte
+// exchange load holds row i, k = 4b .. 4b+3, so ONE load per 64 k feeds 64 instructions (abid = b picks the k quad) with no LDS and no
+// lane shuffles.  A 16 x 16 x 4 tile spends 32 cycles on 16 rows whether 8 or 16 exist; this form spends 8 cycles per k on each 4 rows
+// that do, at the same peak rate: E's forward (N=30 over the chip: 8 rows per group) issues half the MFMA cycles.
+template <int MODE, int MT, int KS, bool EX = false, int NRB = 0>
 __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     using C = Cfg<MODE>;
     constexpr int G = C::G, U = C::U, NT = C::NT;
@@ -142,6 +149,9 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     constexpr bool LSTM = (MODE == LSTM_FWD || MODE == LSTM_BWD);
     constexpr int LDR = red_ld(NT, U);
     constexpr int ROWS = MT * 16;
+    constexpr bool R4 = NRB > 0;
+    static_assert(!R4 || (EX && (MODE == LSTM_FWD || MODE == GRU_FWD) && MT == 1 && KS % 2 == 0 && G * U <= 64 && NRB <= NT), "R4: exact forward, one 64-column group");
+    constexpr int KT = KS * 32, KG = KS / 2;             // R4: k extent per wave, 64-wide k groups
     constexpr int EPT = (ROWS * U + 255) / 256;         // (row, unit) slots per thread; lanes l, l^1 hold a unit pair
     // double-buffered by step parity (one barrier per step) when it fits the 64 KB static LDS limit
     constexpr bool DB = (2 * 4 * ROWS * LDR * 4 <= 65536);
@@ -166,8 +176,16 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 
     // ---- B fragments (hi / lo) of this workgroup's W_hh slice ---------------------------------
     const float* W = d == 0 ? p.w_hh : p.w_hh_r;
-    u32x4 b0[KS][NT], b1[KS][NT];
-    {
+    u32x4 b0[R4 ? 1 : KS][R4 ? 1 : NT], b1[R4 ? 1 : KS][R4 ? 1 : NT];
+    float wr[R4 ? KT : 1];                               // R4: W[gate column `lane`][k of this wave]
+    if constexpr (R4) {
+        const int gate = lane / U, unit = u0 + lane % U;
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const int k = kb + kk;
+            wr[kk] = (lane < G * U && unit < H && k < H) ? W[(int64_t)(gate * H + unit) * H + k] : 0.f;
+        }
+    } else {
         const int n = lane & 15, q = lane >> 4;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -340,6 +358,70 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                 }
             }
             if (stamp) st1 = __builtin_amdgcn_s_memrealtime();
+            if constexpr (R4) {
+                // lane 4b+i: row q0 + 4 rb + i, k = kb + 64 kg + 4b .. +3 (16 bytes of the fp32 exchange row)
+                const int i4 = lane & 3, bq = lane >> 2;
+                u32x4 hf[NRB][KG];
+                unsigned hoff[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const int gr = q0 + rb * 4 + i4;
+                    const int64_t xr = ((int64_t)d * T + tp) * N + gr;
+                    hoff[rb] = (gr < NB && !(p.flags & 1)) ? (unsigned)(xr * KC * 128 + (kb + bq * 4) * 4) : OOB;
+                }
+                auto load_all = [&]() {
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                        for (int kg = 0; kg < KG; ++kg) {
+                            const unsigned off = (kb + kg * 64 + bq * 4 < Kxp) ? hoff[rb] + (unsigned)(kg * 256) : OOB;
+                            hf[rb][kg] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 16));
+                        }
+                };
+                auto any_poison = [&]() -> bool {
+                    unsigned mx = 0u;
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                        for (int kg = 0; kg < KG; ++kg) mx = max(mx, max(max(hf[rb][kg].x, hf[rb][kg].y), max(hf[rb][kg].z, hf[rb][kg].w)));
+                    return __any(mx == POISON) != 0;
+                };
+                load_all();
+                if (!(p.flags & 4) && any_poison()) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    unsigned spins = 0;
+                    do {
+                        load_all();
+                        if ((++spins & 63u) == 0) {
+                            if (ld_cnt(err) != 0) break;
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
+                                if (lane == 0) __hip_atomic_store(err, (unsigned)p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                    } while (any_poison());
+                }
+                // NRB x 4 independent accumulation chains (row block, k mod 4)
+                f32x4 cc[NRB][4];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) cc[rb][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!(p.flags & 2)) {
+#pragma unroll
+                    for (int kg = 0; kg < KG; ++kg) {
+#define AAS_R4_STEP(B_)                                                                                                              \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                  \
+        cc[rb][v] = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(hf[rb][kg][v]), wr[kg * 64 + (B_) * 4 + v], cc[rb][v], 4, (B_), 0);
+                        AAS_R4_STEP(0) AAS_R4_STEP(1) AAS_R4_STEP(2) AAS_R4_STEP(3) AAS_R4_STEP(4) AAS_R4_STEP(5) AAS_R4_STEP(6) AAS_R4_STEP(7)
+                        AAS_R4_STEP(8) AAS_R4_STEP(9) AAS_R4_STEP(10) AAS_R4_STEP(11) AAS_R4_STEP(12) AAS_R4_STEP(13) AAS_R4_STEP(14) AAS_R4_STEP(15)
+#undef AAS_R4_STEP
+                    }
+                }
+                // result: lane = gate column, register i = row 4 rb + i  ->  acc[0][rb] (re-used below as the reduction source)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = (cc[rb][0] + cc[rb][1]) + (cc[rb][2] + cc[rb][3]);
+            } else {
 #pragma unroll
             for (int c = 0; c < DEPTH && c < NCH; ++c) issue(c, ahb[c % (DEPTH + 1)], alb[c % (DEPTH + 1)]);
 #pragma unroll
@@ -372,11 +454,19 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                         }
                 }
             }
+            }
         }
         if (stamp) st2 = __builtin_amdgcn_s_memrealtime();
         float (*red)[ROWS][LDR] = red2[DB ? (s & 1) : 0];
         // ---- cross-wave reduction through LDS ---------------------------------------------------
-        {
+        if constexpr (R4) {
+            if (lane < NT * 16) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave][rb * 4 + r][lane] = acc[0][rb][r];
+            }
+        } else {
             const int col = lane & 15, rq = (lane >> 4) * 4;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -514,6 +604,14 @@ template <int MODE, int MT, int KS, bool EX>
 int launch_sk(const RnnP& p, hipStream_t s) {
     dim3 grid(p.P, p.Q, 2);
     if (p.xcd) grid = dim3(p.P * p.Q * 2);
+    if constexpr (EX && (MODE == LSTM_FWD || MODE == GRU_FWD) && MT == 1 && KS % 2 == 0 && KS <= 4) {
+        // <= 8 rows per group: the 4 x 4 x 1 block form (debug bit 268435456: the 16 x 16 x 4 tiles)
+        if (p.rpg <= 8 && !(p.flags & 268435456)) {
+            if (p.rpg <= 4) hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX, 1>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX, 2>), grid, dim3(256), 0, s, p);
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX>), grid, dim3(256), 0, s, p);
     return 0;
 }

@@ -328,12 +328,15 @@ def test_train_loop_dp_with_sharding_loader_and_syncbn_across_save_iter(gpu, tmp
 
 # ------------------------------------------------------------------------------------------------ exact-fp32 recurrent kernels
 @pytest.mark.parametrize("half_chip", [True, False])
-@pytest.mark.parametrize("kind,T,N,H", [("lstm", 60, 30, 500), ("lstm", 60, 60, 500), ("gru", 40, 30, 1000), ("lstm", 25, 30, 64), ("gru", 9, 5, 24)])
+@pytest.mark.parametrize("kind,T,N,H", [("lstm", 60, 30, 500), ("lstm", 60, 60, 500), ("gru", 40, 30, 1000), ("lstm", 25, 30, 64), ("gru", 9, 5, 24),
+                                        ("lstm", 20, 4, 200), ("gru", 20, 7, 256), ("gru", 12, 3, 500), ("lstm", 15, 13, 384)])
 def test_exact_fp32_flag_kernels_vs_counter_kernels_and_xcd_variants(gpu, kind, T, N, H, half_chip):
     """aas_set_precision(0) runs the data-is-the-flag kernels (all-gather forward, reduce-scatter BPTT) with fp32-input MFMA on fp32
     exchange words.  Against the counter-based fp32 kernels of round 1 (debug bit 134217728: same products, another summation
     order) they agree to fp32 rounding; their XCD-aware launch variants (262144 plain grid, 524288 write-through stores) are bit
-    identical; no timeout.  Config-2 layer shapes on half-chip and whole-chip grids, plus shapes only the fallback covers."""
+    identical; no timeout.  Config-2 layer shapes on half-chip and whole-chip grids, plus shapes only the fallback covers.  Row groups of
+    <= 8 rows run the 4 x 4 x 1 block form of the product (forward: one / two row blocks, LSTM and GRU; LSTM BPTT): it agrees with the
+    16 x 16 x 4 tile form (debug bit 268435456) to fp32 rounding - same products, k summed in four interleaved chains."""
     from aas_enhancement_amd import _lib, ops
     L = _lib.lib()
     G = 4 if kind == "lstm" else 3
@@ -349,7 +352,7 @@ def test_exact_fp32_flag_kernels_vs_counter_kernels_and_xcd_variants(gpu, kind, 
         sync, xc = ops._sync_buf(torch.device(dev, 0)), ops._xchg_buf(torch.device(dev, 0), T, N, H, G)
         s, p = _lib.stream(), _lib.ptr
         res = {}
-        for fl in (134217728, 262144, 524288, 0):
+        for fl in (134217728, 268435456, 262144, 524288, 0):
             L.aas_set_debug_flags(fl)
             hout = torch.zeros(2, T, N, H, device=dev)
             gact = torch.zeros(2, T, N, H, 4, device=dev)
@@ -368,8 +371,9 @@ def test_exact_fp32_flag_kernels_vs_counter_kernels_and_xcd_variants(gpu, kind, 
         for fl in (524288, 0):
             for a, b in zip(res[fl], res[262144]):
                 assert torch.equal(a, b), (kind, fl)
-        for a, b in zip(res[0], res[134217728]):     # summation order differs (K split over waves / producers): fp32 rounding only
-            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, kind
+        for other in (134217728, 268435456):         # summation order differs (K split over waves / producers / chains): fp32 rounding only
+            for a, b in zip(res[0], res[other]):
+                assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, (kind, other)
         assert torch.isfinite(res[0][3]).all() and res[0][3].abs().max() > 0
     finally:
         L.aas_set_debug_flags(0)
