@@ -32,7 +32,7 @@ def collect(d, counter):
 # launch classes of bench.py's roofline object (ops.Profiler names) -> kernel-name prefixes of either arithmetic mode
 # (persistent grids: P x Q x 2 x threads; the same kernel at two batch sizes has the same grid here, so one entry serves both)
 CLASS_PATTERNS = {
-    "lstm_bwd[N=60,H=500]": "rnn_bwd_rs_kernel<1, ", "lstm_bwd[N=30,H=500]": "rnn_bwd_rs_kernel<1, ", "gru_bwd[N=30,H=1000]": "rnn_bwd_rs_kernel<3, ",
+    "lstm_bwd[N=60,H=500]": "rnn_bwd_rs_kernel<1, ", "lstm_bwd[N=30,H=500]": ("rnn_bwd_rs_kernel<1, 32, 4, -1, true, true>", "rnn_bwd_rs_kernel<1, "), "gru_bwd[N=30,H=1000]": "rnn_bwd_rs_kernel<3, ",
     "lstm_fwd[N=60,H=500]": "rnn_fwd32_kernel<0, ", "lstm_fwd[N=30,H=500]": "rnn_split_kernel<0, ", "gru_fwd[N=30,H=1000]": "rnn_fwd32_kernel<2, ",
     "gemm_planes_wgrad": "gemm_planes_tn_kernel<", "gemm_planes": "gemm_planes_kernel<256, 256",
     "gemm_tn": "gemm_f32_kernel<false, false", "gemm_nn": "gemm_f32_kernel<true, false", "gemm_nt": "gemm_f32_kernel<true, true"}
@@ -40,8 +40,12 @@ CLASS_PATTERNS = {
 
 def classes_of(kernels):
     by_class = {}
-    for cname, pat in CLASS_PATTERNS.items():
-        hit = [(k, v) for k, v in kernels.items() if k.startswith(pat)]
+    for cname, pats in CLASS_PATTERNS.items():
+        hit = []
+        for pat in ((pats,) if isinstance(pats, str) else pats):      # (a tuple: the first pattern that matches anything wins)
+            hit = [(k, v) for k, v in kernels.items() if k.startswith(pat)]
+            if hit:
+                break
         if hit:
             k, v = max(hit, key=lambda kv: kv[1]["dispatches"])
             by_class[cname] = dict(v, kernel=k)
