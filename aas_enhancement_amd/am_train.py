@@ -28,6 +28,19 @@ from .optim import FlatAdam, FlatSGD
 from .utils import AverageMeter, _get_variable_nograd
 
 
+# CUs the persistent recurrent launches of the step may occupy (0 = the whole device).  Backward default: half of the device in the
+# fp32-class modes - with 15 rows per workgroup instead of 8 the MFMA-bound BPTT launch issues the same 16-row tiles, and the
+# weight-gradient GEMMs get the other half (config 5: 14.4 -> 13.5 ms); the latency-bound split-bf16 mode keeps the whole device
+# (7.2 vs 8.1 ms).
+_FWD_CUS = int(os.environ.get("AAS_AM_FWD_CUS", "0"))
+
+
+def _bwd_cus():
+    if os.environ.get("AAS_AM_BWD_CUS") is not None:
+        return int(os.environ["AAS_AM_BWD_CUS"])
+    return 0 if ops._precision[0] == 1 else ops.device_cus() // 2
+
+
 class AMTrainer(object):
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), dp=None, labels=None, sync_bn=False, optim="adam", momentum=0.9):
         self.model = model
@@ -68,6 +81,7 @@ class AMTrainer(object):
             out = self.model(inputs).transpose(0, 1)
             loss = self.criterion(out, targets, sizes, target_sizes, prepared=meta)
             loss = loss * (1.0 / counts.get(0)).float() if self.dp.active else loss / N
+            ops.set_rnn_cu_limit(_bwd_cus())
             loss.backward()
             ops.sync_wgrad()
             if self._reducer is not None:
@@ -75,6 +89,7 @@ class AMTrainer(object):
                 self._reducer.wait()
         finally:
             ops.WGRAD_HOOK[0] = None
+            ops.set_rnn_cu_limit(0)
         v = self.dp.reduce_scalars(loss.detach().reshape(1).clone())
         loss_value = float(v)                                  # host read-back: a synchronisation point
         is_inf = loss_value in (float("inf"), float("-inf"))
@@ -109,9 +124,11 @@ class AMTrainer(object):
             self._reducer.begin()
             ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
         try:
+            ops.set_rnn_cu_limit(_FWD_CUS)
             out = self.model(inputs).transpose(0, 1)
             loss = self.criterion(out, targets, sizes, target_sizes, prepared=meta)
             loss = loss * (1.0 / counts.get(0)).float() if self.dp.active else loss / N
+            ops.set_rnn_cu_limit(_bwd_cus())
             loss.backward()
             ops.sync_wgrad()
             if self._reducer is not None:
@@ -119,6 +136,7 @@ class AMTrainer(object):
                 self._reducer.wait()
         finally:
             ops.WGRAD_HOOK[0] = None
+            ops.set_rnn_cu_limit(0)
         v = self.dp.reduce_scalars(loss.detach().reshape(1).clone())
         self.opt.step_dev()
         ring = getattr(self, "_loss_ring", None)

@@ -12,7 +12,10 @@
 namespace {
 
 // MODE = LSTM_FWD or GRU_FWD; KS = 32-wide k chunks per wave (Hp = 256*KS); LKS = k-steps whose lo fragments are in LDS
-template <int MODE, int KS, int LKS, bool EX = false>
+// NRB > 0 (exact LSTM, KS = 2, row groups of <= 4 NRB <= 8 rows): the product on 4 x 4 x 1 MFMA blocks with the A broadcast, as in
+// rnn_split_kernel.h - B = W[gate column 64 cg + lane][k], A = h_{t-1} (lane 4b+i of ONE 16-byte exchange load per row block:
+// row i, k = 4b .. 4b+3; abid = b picks the quad): half the MFMA cycles of the 16-row tiles at 8 rows per group.
+template <int MODE, int KS, int LKS, bool EX = false, int NRB = 0>
 __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
     using C = Cfg<MODE>;
     constexpr int G = C::G, U = 32, NW = 8;
@@ -20,6 +23,9 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
     constexpr int NT = G * U / 16;                       // 16-column tiles of the workgroup's G*U gate columns
     constexpr int LDR = NT * 16 + 16;
     constexpr bool DB = LSTM;                            // parity-double-buffered reduction (one barrier per step)
+    constexpr bool R4 = NRB > 0;
+    static_assert(!R4 || (EX && LSTM && KS == 2 && LKS == 0 && NRB <= 2), "R4: exact LSTM, 64 k per wave, all of W in registers");
+    constexpr int CG = NT / 4;                           // R4: 64-column groups
     __shared__ __attribute__((aligned(16))) float red2[DB ? 2 : 1][NW][16][LDR];
     __shared__ u32x4 bl_lds[LKS ? LKS * NT : 1][LKS ? 512 : 1];
 
@@ -39,8 +45,17 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
 
     // ---- B fragments (hi / lo) of this workgroup's W_hh slice: rows {gate*H + unit}, this wave's k range ------------
     const float* W = d == 0 ? p.w_hh : p.w_hh_r;
-    u32x4 b0[KS][NT], b1[KS][NT];     // (rnn_split_kernel.h: frag_make - bf16 hi / lo words, or the 8 fp32 values of the exact mode)
-    {
+    u32x4 b0[R4 ? 1 : KS][R4 ? 1 : NT], b1[R4 ? 1 : KS][R4 ? 1 : NT];     // (rnn_split_kernel.h: frag_make - bf16 hi / lo words, or the 8 fp32 values of the exact mode)
+    float wr[R4 ? CG : 1][R4 ? 64 : 1];                  // R4: W[gate column 64 cg + lane][k of this wave]
+    if constexpr (R4) {
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+            const int c = cg * 64 + lane;
+            const int gate = c % G, unit = u0 + c / G;
+#pragma unroll
+            for (int kk = 0; kk < 64; ++kk) wr[cg][kk] = (unit < H && kb + kk < H) ? W[(int64_t)(gate * H + unit) * H + kb + kk] : 0.f;
+        }
+    } else {
         const int n = lane & 15, q = lane >> 4;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -129,6 +144,54 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
                 }
             }
             if (stamp) st1 = __builtin_amdgcn_s_memrealtime();
+            if constexpr (R4) {
+                const int i4 = lane & 3, bq = lane >> 2;
+                u32x4 hf[NRB];
+                unsigned hoff[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const int grr = q0 + rb * 4 + i4;
+                    hoff[rb] = (grr < NB && kb + bq * 4 < Hp && !(p.flags & 1)) ? (unsigned)(((xr0 + rb * 4 + i4) * KC) * 128 + (kb + bq * 4) * 4) : OOB;
+                }
+                unsigned spins = 0;
+                unsigned long long t0 = 0;
+                while (true) {
+                    unsigned mx = 0u;
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) {
+                        hf[rb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)hoff[rb], 0, 16));
+                        mx = max(mx, max(max(hf[rb].x, hf[rb].y), max(hf[rb].z, hf[rb].w)));
+                    }
+                    if ((p.flags & 4) || !__any(mx == POISON)) break;
+                    if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
+                    if ((++spins & 63u) == 0) {
+                        if (ld_cnt(err) != 0) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
+                            if (lane == 0) __hip_atomic_store(err, (unsigned)p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                // NRB x CG x 2 independent accumulation chains (row block, column group, k parity)
+                f32x4 cc[NRB][CG][2];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int cg = 0; cg < CG; ++cg) cc[rb][cg][0] = cc[rb][cg][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!(p.flags & 2)) {
+#define AAS_R4_STEP(B_)                                                                                                              \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) _Pragma("unroll") for (int cg = 0; cg < CG; ++cg) \
+        cc[rb][cg][v & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(hf[rb][v]), wr[cg][(B_) * 4 + v], cc[rb][cg][v & 1], 4, (B_), 0);
+                    AAS_R4_STEP(0) AAS_R4_STEP(1) AAS_R4_STEP(2) AAS_R4_STEP(3) AAS_R4_STEP(4) AAS_R4_STEP(5) AAS_R4_STEP(6) AAS_R4_STEP(7)
+                    AAS_R4_STEP(8) AAS_R4_STEP(9) AAS_R4_STEP(10) AAS_R4_STEP(11) AAS_R4_STEP(12) AAS_R4_STEP(13) AAS_R4_STEP(14) AAS_R4_STEP(15)
+#undef AAS_R4_STEP
+                }
+                // lane = gate column within the group, register i = row 4 rb + i: parked in acc[] for the reduction write below
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int cg = 0; cg < CG; ++cg) acc[rb * CG + cg] = cc[rb][cg][0] + cc[rb][cg][1];
+            } else {
             const int grm = q0 + m;
             const unsigned roff = (grm < NB && !(p.flags & 1)) ? (unsigned)(((xr0 + m) * KC + wave * KS) * 128) + frag_off0<EX>(q) : OOB;
             u32x4 ah[KS], al[KS];
@@ -176,10 +239,18 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
                     }
                 }
             }
+            }
         }
         if (stamp) st2 = __builtin_amdgcn_s_memrealtime();
         float (*red)[16][LDR] = red2[DB ? (s & 1) : 0];
-        {
+        if constexpr (R4) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave][rb * 4 + r][cg * 64 + lane] = acc[rb * CG + cg][r];
+        } else {
             const int col = lane & 15, rq = (lane >> 4) * 4;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -311,7 +382,13 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
         if (p.xcd) grid = dim3(p.P * p.Q * 2);
         if constexpr (LSTM) {
             if (ks == 1) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 1, 0, EX>), grid, block, 0, s, p);
-            else if (ks == 2) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0, EX>), grid, block, 0, s, p);
+            else if (ks == 2) {
+                // <= 8 rows per group: the 4 x 4 x 1 block form (debug bit 268435456: the 16 x 16 x 4 tiles)
+                // (this kernel is only chosen when the 16-unit kernel would get more than 8 rows per workgroup, so groups of <= 4 rows do not
+                //  occur in practice: two row blocks always)
+                if (EX && rpg <= 8 && !(p.flags & 268435456)) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0, EX, EX ? 2 : 0>), grid, block, 0, s, p);
+                else hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0, EX>), grid, block, 0, s, p);
+            }
             else return -1;   // 128 gate columns x more than 512 k do not fit the register file
         } else {
             if (ks == 1) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 1, 0, EX>), grid, block, 0, s, p);
