@@ -43,7 +43,10 @@ int aas_device_cus(void);
  *     67108864 plain grid for the forward launches with more than 8 rows per group (default: XCD-aware grid, write-through),
  *   8388608 / 33554432 256x256 / 256x128 tiles for the wide products of aas_gemm_planes_tn (default 128x128),
  *   65536 / 131072 four waves per workgroup (one per SIMD) instead of eight in aas_gemm_planes_tn / the 128x128 aas_gemm_planes,
- *   32768 the 1000-unit GRU BPTT kernel with one (not two) k-steps of lo weight fragments in LDS (the older, spilling variant). */
+ *   32768 the 1000-unit GRU BPTT kernel with one (not two) k-steps of lo weight fragments in LDS (the older, spilling variant),
+ *   134217728 fp32 mode on the counter-based kernels of round 1 instead of the data-is-the-flag ones, 268435456 fp32 mode: 16x16x4
+ *     MFMA tiles also for row groups of <= 8 rows (default there: 4x4x1 blocks - same products, k summed in interleaved chains),
+ *   1073741824 four-wave workgroups in aas_gemm_f32 (default: eight waves where both operands take 16-byte loads). */
 int aas_set_debug_flags(int flags);
 /* Tag (>= 1) of the persistent recurrent launches queued after the call.  Every bounded spin in those kernels gives
  * up after ~0.5 s and stores the tag of its launch in a sticky error word at byte 4096 of the launch's `sync` buffer
