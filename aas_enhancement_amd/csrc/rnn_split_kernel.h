@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     constexpr int LDR = red_ld(NT, U);
     constexpr int ROWS = MT * 16;
     constexpr bool R4 = NRB > 0;
-    static_assert(!R4 || (EX && (MODE == LSTM_FWD || MODE == GRU_FWD) && MT == 1 && KS % 2 == 0 && G * U <= 64 && NRB <= NT), "R4: exact forward, one 64-column group");
+    static_assert(!R4 || (EX && (MODE == LSTM_FWD || MODE == GRU_FWD) && MT == 1 && KS % 2 == 0 && G * U <= 64 && NRB <= 4), "R4: exact forward, one 64-column group");
     constexpr int KT = KS * 32, KG = KS / 2;             // R4: k extent per wave, 64-wide k groups
     constexpr int EPT = (ROWS * U + 255) / 256;         // (row, unit) slots per thread; lanes l, l^1 hold a unit pair
     // double-buffered by step parity (one barrier per step) when it fits the 64 KB static LDS limit
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 
         // ---- recurrent product ------------------------------------------------------------------
         f32x4 acc[MT][NT];
+        f32x4 r4[R4 ? NRB : 1];                          // R4: lane = gate column, register i = row 4 rb + i
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -418,9 +419,8 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 #undef AAS_R4_STEP
                     }
                 }
-                // result: lane = gate column, register i = row 4 rb + i  ->  acc[0][rb] (re-used below as the reduction source)
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = (cc[rb][0] + cc[rb][1]) + (cc[rb][2] + cc[rb][3]);
+                for (int rb = 0; rb < NRB; ++rb) r4[rb] = (cc[rb][0] + cc[rb][1]) + (cc[rb][2] + cc[rb][3]);
             } else {
 #pragma unroll
             for (int c = 0; c < DEPTH && c < NCH; ++c) issue(c, ahb[c % (DEPTH + 1)], alb[c % (DEPTH + 1)]);
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[wave][rb * 4 + r][lane] = acc[0][rb][r];
+                    for (int r = 0; r < 4; ++r) red[wave][rb * 4 + r][lane] = (s > 0) ? r4[rb][r] : 0.f;
             }
         } else {
             const int col = lane & 15, rq = (lane >> 4) * 4;
@@ -605,9 +605,12 @@ int launch_sk(const RnnP& p, hipStream_t s) {
     dim3 grid(p.P, p.Q, 2);
     if (p.xcd) grid = dim3(p.P * p.Q * 2);
     if constexpr (EX && (MODE == LSTM_FWD || MODE == GRU_FWD) && MT == 1 && KS % 2 == 0 && KS <= 4) {
-        // <= 8 rows per group: the 4 x 4 x 1 block form (debug bit 268435456: the 16 x 16 x 4 tiles)
-        if (p.rpg <= 8 && !(p.flags & 268435456)) {
-            if (p.rpg <= 4) hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX, 1>), grid, dim3(256), 0, s, p);
+        // <= 8 rows per group: the 4 x 4 x 1 block form (debug bit 268435456: the 16 x 16 x 4 tiles).  (Tried for the 1000-unit GRU
+        // over the whole chip too - KS = 8, four row blocks, 63 slices x 2 groups x 2 directions instead of the 32-unit kernel's
+        // 8-row tiles: 8.26 vs 8.23 us / step, its sixteen exchange loads are not overlapped with the MFMAs - not kept.)
+        const int rows = (p.n1 - p.n0) < p.rpg ? (p.n1 - p.n0) : p.rpg;
+        if (rows <= 8 && !(p.flags & 268435456)) {
+            if (rows <= 4) hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX, 1>), grid, dim3(256), 0, s, p);
             else hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX, 2>), grid, dim3(256), 0, s, p);
             return 0;
         }
