@@ -36,7 +36,13 @@ namespace {
 // value of column 4b+i, B = d(gates) of row j).  A 16 x 16 x 4 tile spends its 32 cycles on 16 rows whether 4 or 16 of them
 // exist; this form spends 8 cycles per k on every 4 rows that do, at the same peak rate - E's BPTT (N=30 over the whole chip:
 // 4 rows per group; over half of it: 8) issues a quarter / half of the MFMA cycles.
-template <int MODE, int U, int NTW, int LKSP = -1, bool EX = false, bool R4 = false>
+//
+// X6 (aas_set_precision(2), LSTM): the partial product as SIX bf16 products of three-term operands - d(gates) = h + m + l and
+// W = h' + m' + l' exactly, hh' + hm' + mh' + mm' + hl' + lh' (dropped <= 2^-25 relative: the fp32-equivalent form of
+// gemm_planes.hip) - on v_mfma_f32_16x16x32_bf16: 6 x 16 cycles per 32 k instead of the exact mode's 8 x 32.  W's h' and m'
+// fragments stay in registers, the l' fragments (used once per tile and k-step) live in LDS (128 KB); the partials are tagged with
+// round-to-nearest as in the exact mode.
+template <int MODE, int U, int NTW, int LKSP = -1, bool EX = false, bool R4 = false, bool X6 = false>
 __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     using C = Cfg<MODE>;
     constexpr int G = C::G;
@@ -54,9 +60,11 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     __shared__ __attribute__((aligned(16))) unsigned short a_hi[EX ? 1 : 2][EX ? 1 : 16][EX ? 8 : RS_LDA];
     __shared__ __attribute__((aligned(16))) unsigned short a_lo[EX ? 1 : 2][EX ? 1 : 16][EX ? 8 : RS_LDA];
     __shared__ __attribute__((aligned(16))) float a_f[EX ? 2 : 1][EX ? 16 : 1][EX ? EX_LDA : 4];
+    __shared__ __attribute__((aligned(16))) unsigned short a_mi[X6 ? 2 : 1][X6 ? 16 : 1][X6 ? RS_LDA : 8];
+    static_assert(!X6 || (!EX && !R4 && LKSP < 0), "X6 is an arithmetic of its own");
     // the 1000-unit GRU at U = 32 needs 192 VGPRs for its W fragments alone (of 256 at two waves per SIMD): the lo
     // fragments of its last k-step live in LDS instead (64 KB, re-read once per step) so that nothing spills
-    constexpr int LKS = LKSP >= 0 ? LKSP : ((!LSTM && U == 32 && NTW == 8) ? AAS_GRU_BWD_LKS : 0);
+    constexpr int LKS = X6 ? KSTEPS : (LKSP >= 0 ? LKSP : ((!LSTM && U == 32 && NTW == 8) ? AAS_GRU_BWD_LKS : 0));
     __shared__ u32x4 bl_lds[LKS ? LKS * NTW : 1][LKS ? THREADS : 1];
     static_assert(!R4 || (EX && LKS == 0 && NTW % 4 == 0), "R4: exact mode, all of W in registers, 64-column groups per wave");
     constexpr int CG = R4 ? NTW / 4 : 1;                  // 64-column groups per wave
@@ -110,10 +118,19 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                     wv[e] = (gate < G && unit < H && col < H) ? W[(int64_t)(gate * H + unit) * H + col] : 0.f;
                 }
                 u32x4 w0, w1;
+                if constexpr (X6) {   // h' and m' in registers, l' in LDS (every k-step)
+                    unsigned h[8], m[8], l[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) split3_bf16(wv[e], h[e], m[e], l[e]);
+                    b0[ks][nt] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+                    b1[ks][nt] = (u32x4){m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16)};
+                    bl_lds[ks * NTW + nt][tid] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+                } else {
                 frag_make<EX>(wv, w0, w1);
                 b0[ks][nt] = w0;
                 if (ks >= KSTEPS - LKS) bl_lds[LKS ? (ks - (KSTEPS - LKS)) * NTW + nt : 0][LKS ? tid : 0] = w1;
                 else b1[ks][nt] = w1;
+                }
             }
     }
     // plain (L2-resident) publish stores when the whole set shares an XCD (rnn_split_kernel.h: xcd_set_colocated)
@@ -131,6 +148,7 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
         for (int i = tid; i < 2 * 16 * RS_LDA; i += THREADS) {
             (&a_hi[0][0][0])[i] = 0;
             (&a_lo[0][0][0])[i] = 0;
+            if constexpr (X6) (&a_mi[0][0][0])[i] = 0;
         }
     }
     __syncthreads();
@@ -280,8 +298,11 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
             }
         }
         const int par = s & 1;
-        unsigned h16[4] = {0, 0, 0, 0}, l16[4] = {0, 0, 0, 0};
-        if constexpr (!EX) {
+        unsigned h16[4] = {0, 0, 0, 0}, l16[4] = {0, 0, 0, 0}, m16[4] = {0, 0, 0, 0};
+        if constexpr (X6) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) split3_bf16(xv[g], h16[g], m16[g], l16[g]);
+        } else if constexpr (!EX) {
 #pragma unroll
             for (int g = 0; g < G; ++g) split_bf16(xv[g], h16[g], l16[g]);
         }
@@ -292,6 +313,7 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                 else {
                     a_hi[par][row][g * U + unit] = (unsigned short)h16[g];
                     a_lo[par][row][g * U + unit] = (unsigned short)l16[g];
+                    if constexpr (X6) a_mi[par][row][g * U + unit] = (unsigned short)m16[g];
                 }
             }
         }
@@ -389,9 +411,10 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
         } else
         if (s + 1 < T) {
             const int m = lane & 15, q = lane >> 4;
-            u32x4 ah[KSTEPS], al[KSTEPS];
+            u32x4 ah[KSTEPS], al[KSTEPS], am[X6 ? KSTEPS : 1];
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
+                if constexpr (X6) am[ks] = *reinterpret_cast<const u32x4*>(&a_mi[par][m][ks * 32 + q * 8]);
                 if constexpr (EX) {
                     ah[ks] = *reinterpret_cast<const u32x4*>(&a_f[par][m][ks * 32 + q * 8]);
                     al[ks] = *reinterpret_cast<const u32x4*>(&a_f[par][m][ks * 32 + q * 8 + 4]);
@@ -416,7 +439,17 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                         u32x4 w1;
                         if (ks >= KSTEPS - LKS) w1 = bl_lds[LKS ? (ks - (KSTEPS - LKS)) * NTW + nt : 0][LKS ? tid : 0];
                         else w1 = b1[ks][nt];
-                        if constexpr (EX) acc = mma_chunk<true>(acc, b0[ks][nt], w1, ah[ks], al[ks]);
+                        if constexpr (X6) {   // the small terms first; W is the MFMA's first operand (transposed product, see above)
+                            const bf16x8 wh = __builtin_bit_cast(bf16x8, b0[ks][nt]), wm = __builtin_bit_cast(bf16x8, b1[ks][nt]);
+                            const bf16x8 wl = __builtin_bit_cast(bf16x8, w1);
+                            const bf16x8 dh = __builtin_bit_cast(bf16x8, ah[ks]), dm = __builtin_bit_cast(bf16x8, am[ks]), dl = __builtin_bit_cast(bf16x8, al[ks]);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dl, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, dh, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, dm, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dm, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, dh, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dh, acc, 0, 0, 0);
+                        } else if constexpr (EX) acc = mma_chunk<true>(acc, b0[ks][nt], w1, ah[ks], al[ks]);
                         else {   // (the order of the three products is part of the bit-exact contract between the kernel variants)
                             const bf16x8 whi = __builtin_bit_cast(bf16x8, b0[ks][nt]), wlo = __builtin_bit_cast(bf16x8, w1);
                             const bf16x8 dhi = __builtin_bit_cast(bf16x8, ah[ks]), dlo = __builtin_bit_cast(bf16x8, al[ks]);
@@ -431,7 +464,7 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                 if (c < P && prow < nrows && !(p.flags & 8)) {
                     // the tag replaces the two low mantissa bits: exact mode rounds to nearest there (an unbiased 22-bit partial,
                     // |error| <= 2 ulp, below the rounding noise of any fp32 summation order); split mode truncates as before
-                    constexpr unsigned RND = EX ? 2u : 0u;
+                    constexpr unsigned RND = (EX || X6) ? 2u : 0u;
                     u32x4 o;
                     o.x = ((__float_as_uint(acc[0]) + RND) & ~3u) | tag;
                     o.y = ((__float_as_uint(acc[1]) + RND) & ~3u) | tag;
@@ -459,10 +492,19 @@ inline size_t rs_ring_bytes(int N, int H, int U) {
     return (size_t)4 * N * P * P * U * 4;
 }
 
-template <int MODE, int U, bool EX>
+template <int MODE, int U, bool EX, bool X6 = false>
 int launch_rs(const RnnP& p, hipStream_t s) {
     dim3 grid(p.P, p.Q, 2), block(16 * U);
     if (p.xcd) grid = dim3(p.P * p.Q * 2);
+    if constexpr (X6) {
+        if constexpr (MODE == LSTM_BWD && U == 32) {
+            if (p.P > 8 && p.P <= 16) {
+                hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 4, -1, false, false, true>), grid, block, 0, s, p);
+                return 0;
+            }
+        }
+        return -1;
+    } else {
     if constexpr (EX && MODE == LSTM_BWD && U == 32) {
         // <= 8 rows per group: the 4 x 4 x 1 block form (debug bit 268435456: the 16 x 16 x 4 tiles)
         if (p.rpg <= 8 && p.P > 8 && p.P <= 16 && !(p.flags & 268435456)) {
@@ -479,9 +521,10 @@ int launch_rs(const RnnP& p, hipStream_t s) {
     else if (U == 16 && p.P <= 64) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, 16, 16, -1, EX>), grid, block, 0, s, p);
     else return -1;
     return 0;
+    }
 }
 
-template <int MODE, bool EX = false>
+template <int MODE, bool EX = false, bool X6 = false>
 int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
     AAS_CHECK(p.T >= 1 && p.N >= 1 && p.H >= 1, "%s: bad sizes T=%d N=%d H=%d", name, p.T, p.N, p.H);
     const int cus = aas_rnn_cus();
@@ -492,6 +535,7 @@ int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
     // through the fabric; small layers keep 16-unit slices so that enough workgroups share the work
     const int U = (p.H >= 256 && !(p.flags & 512)) ? 32 : 16;
     p.P = cdiv(p.H, U);
+    if (X6 && !(MODE == LSTM_BWD && U == 32 && p.P > 8 && p.P <= 16)) return -1;   // (before anything is queued)
     if (p.P > (U == 16 ? 64 : 32)) return -1;              // one poll lane per producer, <= 8/16 tiles per wave
     AAS_CHECK(p.P * 2 <= cus, "%s: H=%d needs %d resident workgroups, device has %d CUs", name, p.H, p.P * 2, cus);
     const size_t rbytes = rs_ring_bytes(p.N, p.H, U);
@@ -512,7 +556,7 @@ int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
         // 8 (direction, row group) sets of at most 32 workgroups: XCD-aware grid (debug bit 262144: the plain 3-D grid,
         // 524288: XCD-aware grid but write-through publish stores)
         p.xcd = (p.flags & 262144) ? 0 : ((p.Q * 2) % 8 == 0 && p.P * (p.Q * 2 / 8) <= 32) ? 1 : (p.Q * 2 == 4 && p.P <= 64 && p.P % 2 == 0) ? 2 : 0;
-        const int rc = (U == 32) ? launch_rs<MODE, 32, EX>(p, s) : launch_rs<MODE, 16, EX>(p, s);
+        const int rc = (U == 32) ? launch_rs<MODE, 32, EX, X6>(p, s) : launch_rs<MODE, 16, EX, X6>(p, s);
         if (rc != 0) return -1;
         AAS_LAUNCH_CHECK(name);
     }
@@ -530,6 +574,11 @@ int run_bwd_any(const char* name, RnnP p, hipStream_t s) {
     if (p.dgp1) {   // only the split-bf16 reduce-scatter kernel writes operand planes: the caller falls back to fp32 d(gates) + a split pass
         aas_set_error("%s: plane output needs the split-bf16 reduce-scatter BPTT kernel (precision 1, exchange buffer, supported H)", name);
         return 3;
+    }
+    if (p.xchg && aas_precision_value() == 2 && !(aas_debug_flags_value() & (256 | 134217728 | 536870912))) {
+        // fp32-equivalent mode: six-product bf16 form where it is instantiated (500-unit LSTM); debug bit 536870912: exact kernels
+        const int rc = run_bwd_rs<MODE, false, true>(name, p, s);
+        if (rc >= 0) return rc;
     }
     if (p.xchg && aas_precision_value() != 1 && !(aas_debug_flags_value() & (256 | 134217728))) {
         const int rc = run_bwd_rs<MODE, true>(name, p, s);

@@ -34,6 +34,18 @@ __device__ __forceinline__ void split_bf16(float x, unsigned& hi16, unsigned& lo
     lo16 = (unsigned)__builtin_bit_cast(unsigned short, l);
 }
 
+// three bf16 terms, x = h + m + l EXACTLY (24 significant bits; the same split as gemm_planes.hip: split3)
+__device__ __forceinline__ void split3_bf16(float x, unsigned& h16, unsigned& m16, unsigned& l16) {
+    const __bf16 hb = (__bf16)x;
+    h16 = (unsigned)__builtin_bit_cast(unsigned short, hb);
+    const float r1 = x - __uint_as_float(h16 << 16);
+    const __bf16 mb = (__bf16)r1;
+    m16 = (unsigned)__builtin_bit_cast(unsigned short, mb);
+    const float r2 = r1 - __uint_as_float(m16 << 16);
+    const __bf16 lb = (__bf16)r2;
+    l16 = (unsigned)__builtin_bit_cast(unsigned short, lb);
+}
+
 __device__ __forceinline__ void st_sc1_u32(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

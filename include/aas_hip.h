@@ -46,6 +46,7 @@ int aas_device_cus(void);
  *   32768 the 1000-unit GRU BPTT kernel with one (not two) k-steps of lo weight fragments in LDS (the older, spilling variant),
  *   134217728 fp32 mode on the counter-based kernels of round 1 instead of the data-is-the-flag ones, 268435456 fp32 mode: 16x16x4
  *     MFMA tiles also for row groups of <= 8 rows (default there: 4x4x1 blocks - same products, k summed in interleaved chains),
+ *   536870912 mode 2: the exact (fp32-input MFMA) LSTM BPTT kernel instead of the six-product one,
  *   1073741824 four-wave workgroups in aas_gemm_f32 (default: eight waves where both operands take 16-byte loads). */
 int aas_set_debug_flags(int flags);
 /* Tag (>= 1) of the persistent recurrent launches queued after the call.  Every bounded spin in those kernels gives
@@ -68,7 +69,8 @@ int aas_set_wgrad_wg_cap(int workgroups);
  *   1           = split-bf16 fast mode: each fp32 operand is carried as bf16 hi + bf16 lo and the product as
  *                 hi*hi + lo*hi + hi*lo with fp32 accumulation (16+ mantissa bits per operand, ~2^-17 per product: NARROWER than
  *                 fp32, inside the 1e-3 / 1e-2 parity budget; 3 bf16 MFMAs instead of 16 fp32-MFMA issue slots);
- *   2           = fp32-EQUIVALENT: the recurrent products and the small GEMMs as in mode 0 (fp32-input MFMA); the large GEMMs are
+ *   2           = fp32-EQUIVALENT: the small GEMMs and the recurrent products as in mode 0 (fp32-input MFMA), except that aas_lstm_bwd
+ *                 runs its partial products as six bf16 products of three-term operands where instantiated (256 < H <= 512); the large GEMMs are
  *                 the caller's to run as six bf16 products of three-term operands (aas_split_planes3 + the plane
  *                 kernels over both plane sets, below): every product keeps all 24 operand bits, dropped cross terms <= 2^-25 relative. */
 int aas_set_precision(int mode);

@@ -591,3 +591,57 @@ def test_birnn_layer_fp32_equivalent_mode_vs_cpu(gpu, kind, T, N, H, classes):
     else:
         for wg, k in zip(w, names):
             assert rel_err(wg.grad, getattr(ref, k).grad) < 2e-4, k
+
+
+@pytest.mark.parametrize("N", [30, 60])
+def test_six_product_bptt_layer_error_vs_fp64_at_the_fp32_modes_level(gpu, N):
+    """aas_set_precision(2) runs the 500-unit LSTM's BPTT with SIX bf16 products of three-term operands (rnn_bwd_rs_kernel<.., X6>:
+    d(gates) = h + m + l and W = h' + m' + l' exactly, dropped cross terms <= 2^-25) instead of fp32-input MFMA.  Against an fp64
+    nn.LSTM (errors scaled by the largest element, rms and maximum; tools/r03_x6_bptt_error.py prints the table):
+      * the six-product BPTT changes nothing measurable: every gradient's error equals the one with the exact BPTT kernel (debug
+        bit 536870912) within the run-to-run spread of the atomics' arrival order;
+      * the input gradient of mode 2 is not above the fp32 mode's (1.5e-8 vs 2.1e-8 rms);
+      * the weight gradients of mode 2 (row-major six-product plane GEMM) stay at fp32's rounding level - 1.2-1.5x the fp32 mode's rms
+        (4.8-6.7e-8 vs 4.0-4.3e-8: its reduction chains over T N rows are longer than the fp32 GEMM's split-K ones), 8-10x below the
+        three-product fast mode's (5.4e-7)."""
+    from aas_enhancement_amd import _lib, ops
+    from aas_enhancement_amd.dist import FlatBuffers
+    T, H = 48, 500
+    torch.manual_seed(3)
+    ref = nn.LSTM(H, H, bidirectional=True, bias=False).double()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(T, N, H, generator=g) * 0.5
+    gy = torch.randn(T, N, H, generator=g)
+    names = ("weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse")
+    xr = x.double().requires_grad_(True)
+    yr, _ = ref(xr)
+    (yr[..., :H] + yr[..., H:] + xr).backward(gy.double())
+    want = [xr.grad] + [getattr(ref, k).grad for k in names]
+
+    def run(mode, flags=0):
+        holder = nn.ParameterList([nn.Parameter(getattr(ref, k).detach().float().clone()) for k in names]).cuda()
+        FlatBuffers(holder)
+        try:
+            ops.set_precision(mode)
+            _lib.lib().aas_set_debug_flags(flags)
+            xg = x.clone().cuda().requires_grad_(True)
+            ops.birnn_layer(xg, *list(holder), kind="lstm", residual=True).backward(gy.cuda())
+            ops.sync_wgrad()
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().aas_set_debug_flags(0)
+            ops.set_precision(int(os.environ.get("AAS_PRECISION", "0")))
+        assert not ops.rnn_timeout_flag()
+        got = [xg.grad] + [p_.grad for p_ in holder]
+        out = []
+        for a, b in zip(got, want):
+            e = (a.detach().double().cpu() - b).abs() / b.abs().max()
+            out.append((float(e.pow(2).mean().sqrt()), float(e.max())))
+        return out
+    e0, e2, e2x, e1 = run(0), run(2), run(2, 536870912), run(1)
+    for i in range(5):
+        assert e2[i][0] <= 1.15 * e2x[i][0] + 1e-9 and e2[i][1] <= 1.6 * e2x[i][1] + 1e-8, (i, e2[i], e2x[i])     # X6 BPTT == exact BPTT
+        assert e1[i][0] > 5.0 * e2[i][0], (i, e1[i], e2[i])                                                       # the fast mode IS narrower
+    assert e2[0][0] <= 1.1 * e0[0][0] and e2[0][1] <= 1.5 * e0[0][1], (e2[0], e0[0])                            # input gradient
+    for i in range(1, 5):
+        assert e2[i][0] <= 2.0 * e0[i][0] and e2[i][0] < 1e-7 and e2[i][1] < 3e-6, (i, e2[i], e0[i])             # weight gradients: fp32's rounding level
