@@ -36,6 +36,7 @@ SIGNATURES = {
     "aas_set_wgrad_wg_cap": [c_int],
     "aas_gemm_planes_tn": [c_vp, c_int] + [c_vp] * 18 + [c_int, c_int, c_vp, c_int],
     "aas_split_planes": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_int],
+    "aas_lstm_bwd_planes3": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp],
     "aas_split_planes3": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_i64],
     "aas_add3_planes3_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_i64],
     "aas_split_planes_t3": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp, c_i64],

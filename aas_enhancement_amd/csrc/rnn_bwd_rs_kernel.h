@@ -317,7 +317,31 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                 }
             }
         }
-        if (p.dgp1) {
+        if (X6 && p.dgp1) {
+            // d(gates) straight as the two three-term plane sets of the six-product GEMMs (aas_split_planes3's form: row (t, n) =
+            // Q1 | Q2, each dgKp columns of 128-byte blocks; Q1 block = 64 B of m | 64 B of h, Q2 block = 64 B of h | 64 B of l)
+            if (ok) {
+                char* r1 = reinterpret_cast<char*>(p.dgp1) + tn * (int64_t)p.dgKp * 8;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int k = d * GH + g * H + gunit;
+                    char* o = r1 + (k >> 5) * 128 + (k & 31) * 2;
+                    *reinterpret_cast<unsigned short*>(o) = (unsigned short)m16[g];
+                    *reinterpret_cast<unsigned short*>(o + 64) = (unsigned short)h16[g];
+                    *reinterpret_cast<unsigned short*>(o + (int64_t)p.dgKp * 4) = (unsigned short)h16[g];
+                    *reinterpret_cast<unsigned short*>(o + (int64_t)p.dgKp * 4 + 64) = (unsigned short)l16[g];
+                }
+            }
+            if (rowok && d == 1 && pslice == P - 1) {   // zero pad columns [2*G*H, Kp) of my rows in both sets
+                for (int k = 2 * GH + unit; k < p.dgKp; k += U) {
+                    char* o = reinterpret_cast<char*>(p.dgp1) + tn * (int64_t)p.dgKp * 8 + (k >> 5) * 128 + (k & 31) * 2;
+                    *reinterpret_cast<unsigned short*>(o) = 0;
+                    *reinterpret_cast<unsigned short*>(o + 64) = 0;
+                    *reinterpret_cast<unsigned short*>(o + (int64_t)p.dgKp * 4) = 0;
+                    *reinterpret_cast<unsigned short*>(o + (int64_t)p.dgKp * 4 + 64) = 0;
+                }
+            }
+        } else if (p.dgp1) {
             // d(gates) for the layer's GEMMs straight in their operand form: row (t, n) of interleaved bf16 hi | lo planes
             // (per 32-wide k block 64 B of hi then 64 B of lo), k = d*G*H + g*H + unit - no fp32 copy, no split pass
             if (ok) {
@@ -570,6 +594,14 @@ int run_bwd_any(const char* name, RnnP p, hipStream_t s) {
     if (p.xchg && aas_precision_value() == 1 && !(aas_debug_flags_value() & 256)) {
         const int rc = run_bwd_rs<MODE, false>(name, p, s);
         if (rc >= 0) return rc;
+    }
+    if (p.dgp1 && p.dgsets == 3) {   // three-term plane sets: only the six-product kernel of the fp32-equivalent mode writes them
+        if (p.xchg && aas_precision_value() == 2 && !(aas_debug_flags_value() & (256 | 134217728 | 536870912))) {
+            const int rc = run_bwd_rs<MODE, false, true>(name, p, s);
+            if (rc >= 0) return rc;
+        }
+        aas_set_error("%s: three-term plane output needs the six-product BPTT kernel (precision 2, exchange buffer, 256 < H <= 512)", name);
+        return 3;
     }
     if (p.dgp1) {   // only the split-bf16 reduce-scatter kernel writes operand planes: the caller falls back to fp32 d(gates) + a split pass
         aas_set_error("%s: plane output needs the split-bf16 reduce-scatter BPTT kernel (precision 1, exchange buffer, supported H)", name);

@@ -45,6 +45,7 @@ struct RnnP {
     unsigned short* dgp1; // bwd, optional: dg1 / dg2 as interleaved bf16 hi|lo PLANES [T*N rows][dgKp] (k = d*G*H + g*H + unit)
     unsigned short* dgp2; //   instead of fp32 - the operand form of the layer's input-gradient and weight-gradient GEMMs
     int dgKp;
+    int dgsets;          // 3: dgp1 is a three-term plane-set pair (Q1 | Q2 side by side, row pitch 8 dgKp bytes: aas_split_planes3's form)
     unsigned* sync;
     unsigned* xchg;      // split-bf16 exchange arrays (hi | lo), NULL -> exact fp32 kernels
     int P, Q;

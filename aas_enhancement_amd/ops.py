@@ -876,7 +876,18 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
             dgp = dghp = None
         else:
             check(rc, "aas_%s_bwd_planes" % kind)
-    if dgp is None:
+    dga3 = None
+    if use_planes6 and PLANES_EMIT[0] and kind == "lstm" and T > 1 and (direct is not None or not need_dw):
+        # fp32-equivalent mode: the six-product BPTT kernel writes d(gates) as the three-term plane sets of the layer's GEMMs
+        dga3 = _new_planes3(R, 2 * GH, dev)
+        with _timed("rnn", "lstm_bwd[N=%d,H=%d]" % (N, H), rflops, T):
+            rc = lib().aas_lstm_bwd_planes3(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), dga3.buf.data_ptr(), dga3.Kp,
+                                            ptr(sync), ptr(xchg))
+        if rc == 3:          # no six-product kernel for this shape: exact BPTT + the split pass below
+            dga3 = None
+        else:
+            check(rc, "aas_lstm_bwd_planes3")
+    if dgp is None and dga3 is None:
         dgx = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
         if kind == "rnn":
             with _timed("rnn", "rnn_bwd[N=%d,H=%d]" % (N, H), rflops, T):
@@ -898,12 +909,12 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     ev_bptt.record(torch.cuda.current_stream())
     x2 = x.view(T * N, I)
     dx = None
-    dga3 = None
     if need_dx:
         dx = torch.empty((T, N, I), device=dev, dtype=torch.float32)
         dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4
         if use_planes6:
-            dga3 = split_planes3(dgx.view(R, 2 * GH), R, 2 * GH)
+            if dga3 is None:
+                dga3 = split_planes3(dgx.view(R, 2 * GH), R, 2 * GH)
             gemm_planes6(R, I, dga3.Kp, dga3, _wih_t_planes3(w_ih, w_ih_r, GH, I), dx, I, addend=dy if residual else None, ldd=I)
         elif use_planes:
             # dx[R, I] = d(gates)[R, 2GH] [W_ih ; W_ih_rev]: the NT plane GEMM on a row-major split of d(gates) (one HBM pass)
@@ -1023,8 +1034,11 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     def wgrads(out, acc):
         if _SKIP_WGRAD:  # timing experiment only (AAS_SKIP_WGRAD=1): how much of the step the weight-gradient products hold
             return
+        nonlocal dgx, dgh
         if use_planes6 and acc and T > 1 and wgrads_tn6(out):
             return
+        if dgx is None and dga3 is not None:      # (the BPTT wrote plane sets only and the plane product could not take them: fp32 again)
+            dgx = dgh = dga3.to_float()[:, :2 * GH].contiguous().view(T, N, 2, GH)
         if use_planes and acc and T > 1:
             if wgrads_tn(out):
                 return

@@ -214,6 +214,12 @@ int aas_lstm_bwd_planes(aasStream_t stream, int T, int N, int H, const float* dy
                         const float* gact, const float* cst, void* dgates_planes, int Kp, void* sync, void* xchg);
 int aas_gru_bwd_planes(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
                        const float* hout, const float* gact, void* dgx_planes, void* dgh_planes, int Kp, void* sync, void* xchg);
+/* aas_lstm_bwd in the fp32-equivalent mode (precision 2) with d(gates) written as the two three-term plane sets of the six-product
+ * GEMMs - what aas_split_planes3 would make of the fp32 tensor with row_pitch_bytes = 8 Kp (set Q1 at the start of a row, set Q2 at
+ * byte 4 Kp), without that tensor or the pass.  Returns 3 (and does nothing) where the six-product BPTT kernel is not instantiated
+ * (other modes, no exchange buffer, H outside (256, 512]): the caller then uses aas_lstm_bwd + aas_split_planes3. */
+int aas_lstm_bwd_planes3(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
+                         const float* gact, const float* cst, void* dgates_sets, int Kp, void* sync, void* xchg);
 
 /* nn.RNN(nonlinearity='tanh', bias=False, bidirectional=True) - the `rnn` entry of supported_rnns (model.py:12-17), selectable with
  * --rnn_type rnn (config.py:44):  h_t = tanh(pre_t + W_hh h_{t-1}).
