@@ -450,7 +450,9 @@ class Trainer(object):
             ops.DEFER_LIDS.clear()
             # (fp32 mode, same-box runs: 0 / 1 / 2 / 3 / 4 held-back layers = 30.6-31.0 / 30.1 / 29.9-30.4 / 30.2-30.3 / 30.1-30.2 ms
             #  with the eight-wave fp32 GEMM; with the four-wave one the weight-gradient stream was saturated and 0 was best)
-            for net, env, dflt in ((self.D, "AAS_DEFER_D_LAYERS", 2), (self.ASR, "AAS_DEFER_A_LAYERS", 0)):
+            # (fp32-equivalent mode, with the six-product BPTT: 0 / 1 / 2 = 23.9-24.2 / 24.1-24.2 / 24.5-24.6 ms - its weight-gradient
+            #  products are cheap enough to run beside the chains)
+            for net, env, dflt in ((self.D, "AAS_DEFER_D_LAYERS", 0 if ops._precision[0] == 2 else 2), (self.ASR, "AAS_DEFER_A_LAYERS", 0)):
                 ndef = int(os.environ.get(env, str(dflt)))
                 if ndef > 0:
                     lids = [m._aas_layer_id for m in net.modules() if getattr(m, "_aas_layer_id", None) is not None]
