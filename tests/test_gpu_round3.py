@@ -645,3 +645,42 @@ def test_six_product_bptt_layer_error_vs_fp64_at_the_fp32_modes_level(gpu, N):
     assert e2[0][0] <= 1.1 * e0[0][0] and e2[0][1] <= 1.5 * e0[0][1], (e2[0], e0[0])                            # input gradient
     for i in range(1, 5):
         assert e2[i][0] <= 2.0 * e0[i][0] and e2[i][0] < 1e-7 and e2[i][1] < 3e-6, (i, e2[i], e0[i])             # weight gradients: fp32's rounding level
+
+
+def test_six_product_bptt_plane_sets_equal_the_split_of_its_fp32_output(gpu):
+    """aas_lstm_bwd_planes3 (precision 2) writes d(gates) as the two three-term plane sets of the layer's GEMMs: bit for bit what
+    aas_split_planes3 makes of aas_lstm_bwd's fp32 output (pad columns zero), so the layer's gradients do not depend on which of
+    the two forms the BPTT launch delivered (ops.PLANES_EMIT)."""
+    from aas_enhancement_amd import _lib, ops
+    L = _lib.lib()
+    T, N, H, G = 40, 60, 500, 4
+    g = torch.Generator().manual_seed(11)
+    R_ = lambda *shape, scale=1.0: (torch.randn(*shape, generator=g) * scale).cuda()
+    ops.set_precision(2)
+    try:
+        w = [R_(G * H, H, scale=1.0 / H ** 0.5) for _ in range(2)]
+        pre, dy = R_(T, N, 2, G * H), R_(T, N, H)
+        dev = torch.device("cuda", 0)
+        sync, xc = ops._sync_buf(dev), ops._xchg_buf(dev, T, N, H, G)
+        s, p = _lib.stream(), _lib.ptr
+        hout, gact, cst = torch.zeros(2, T, N, H, device="cuda"), torch.zeros(2, T, N, H, 4, device="cuda"), torch.zeros(2, T, N, H, device="cuda")
+        ops.check(L.aas_lstm_fwd(s, T, N, H, p(pre), p(w[0]), p(w[1]), p(hout), p(gact), p(cst), p(sync), p(xc)), "fwd")
+        dgx = torch.zeros(T, N, 2, G * H, device="cuda")
+        ops.check(L.aas_lstm_bwd(s, T, N, H, p(dy), p(w[0]), p(w[1]), p(gact), p(cst), p(dgx), p(sync), p(xc)), "bwd")
+        want = ops.split_planes3(dgx.view(T * N, 2 * G * H), T * N, 2 * G * H)
+        got = ops._new_planes3(T * N, 2 * G * H, dev)
+        got.buf.fill_(7)     # (stale contents must not survive, pad columns included)
+        ops.check(L.aas_lstm_bwd_planes3(s, T, N, H, p(dy), p(w[0]), p(w[1]), p(gact), p(cst), got.buf.data_ptr(), got.Kp, p(sync), p(xc)), "bwd planes3")
+        torch.cuda.synchronize()
+        assert not ops.rnn_timeout_flag()
+        assert got.Kp == want.Kp and torch.equal(got.buf.view(torch.int16), want.buf.view(torch.int16))
+        assert torch.equal(got.to_float()[:, :2 * G * H], dgx.view(T * N, 2 * G * H))       # h + m + l == the fp32 value, exactly
+        # a shape without a six-product kernel: refused with code 3, nothing written
+        H2 = 64
+        w2 = [R_(G * H2, H2) for _ in range(2)]
+        dgs = ops._new_planes3(T * N, 2 * G * H2, dev)
+        rc = L.aas_lstm_bwd_planes3(s, T, N, H2, p(dy[..., :H2].contiguous()), p(w2[0]), p(w2[1]), p(gact[..., :H2, :].contiguous()),
+                                    p(cst[..., :H2].contiguous()), dgs.buf.data_ptr(), dgs.Kp, p(sync), p(ops._xchg_buf(dev, T, N, H2, G)))
+        assert rc == 3
+    finally:
+        ops.set_precision(int(os.environ.get("AAS_PRECISION", "0")))
