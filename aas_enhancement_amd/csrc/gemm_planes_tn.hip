@@ -42,6 +42,7 @@ struct PTN {
     int Ns, Nb;
     const char* zero;
     int accumulate, flags, per, tiles, maxwg;
+    int ksplit;     // > 1: every tile's k extent is shared by `ksplit` workgroups that add their partial results with atomics
 };
 
 template <int PITCH>
@@ -75,8 +76,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_planes_tn_kernel(PTN p) {
     // XCD x (workgroups with blockIdx % 8 == x) takes the contiguous run of tiles [x*per, (x+1)*per); with a capped grid a
     // workgroup walks its XCD's run in strides of gridDim/8
     for (int slot = blockIdx.x >> 3; slot < p.per; slot += gridDim.x >> 3) {
-    const int qt = (blockIdx.x & 7) * p.per + slot;
-    if (qt >= p.tiles) break;
+    const int qw = (blockIdx.x & 7) * p.per + slot;          // work item = (tile, k share); the shares of a tile are neighbours
+    if (qw >= p.tiles * p.ksplit) break;
+    const int qt = qw / p.ksplit, kshare = qw - qt * p.ksplit;
     __syncthreads();             // (the previous tile's LDS reads are done before this tile's first writes)
     int pr = 0;
     while (pr + 1 < p.nprob && qt >= p.tile0[pr + 1]) ++pr;
@@ -84,6 +86,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_planes_tn_kernel(PTN p) {
     const int gx = p.gx[pr];
     const int m0 = (qq / gx) * BMC, n0t = (qq % gx) * BNC;
     const int K = p.K[pr], Ns = p.Ns, Nb = p.Nb;
+    // this workgroup's k-steps [ks0, ks1) of the problem's ceil(K / 32)
+    const int nk_all = (K + 31) / 32, nk_per = (nk_all + p.ksplit - 1) / p.ksplit;
+    const int ks0 = kshare * nk_per, ks1 = min(nk_all, ks0 + nk_per);
+    if (ks0 >= ks1) continue;
+    const int koff = ks0 * 32;
     const char* Ab = p.A[pr];
     const char* Bb = p.B[pr];
     const int64_t lda = p.lda[pr], ldb = p.ldb[pr];
@@ -113,8 +120,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_planes_tn_kernel(PTN p) {
         const int ca = p.acol0[pr] + m0 + 16 * piece + 8 * half;
         const bool va = (m0 + 16 * piece + 8 * half < p.M[pr]) && (ca + 8 <= p.acols[pr]);
         const int cbyte = (ca >> 5) * 128 + hl * 64 + (ca & 31) * 2;
-        const int t0 = kr / Ns;
-        na[j] = kr - t0 * Ns;
+        const int t0 = (kr + koff) / Ns;
+        na[j] = (kr + koff) - t0 * Ns;
         if constexpr (A_P == 1024) {
             rowa[j] = (int64_t)t0 * Nb + na[j] + arow0;
             offa[j] = va ? cbyte : -1;
@@ -132,8 +139,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_planes_tn_kernel(PTN p) {
         const int cb = n0t + 16 * piece + 8 * half;
         const bool vb = (cb < p.N[pr]) && (cb + 8 <= p.bcols[pr]);
         const int cbyte = (cb >> 5) * 128 + hl * 64 + (cb & 31) * 2;
-        const int t0 = kr / Ns;
-        nb_[j] = kr - t0 * Ns;
+        const int t0 = (kr + koff) / Ns;
+        nb_[j] = (kr + koff) - t0 * Ns;
         if constexpr (B_P == 1024) {
             rowb[j] = (int64_t)t0 * Nb + nb_[j] + brow0;
             offb[j] = vb ? cbyte : -1;
@@ -206,13 +213,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_planes_tn_kernel(PTN p) {
         for (int j = 0; j < NJ; ++j) fb[j][hl] = TILE_A + (8 * g + qp) * B_P + 8 * (pp & 1) + ((((wn * NJ + j) * 4 + 2 * hl) ^ fq) + (pp >> 1)) * 16;
     }
 
-    const int nk = (K + 31) / 32;
-    if (nk > 0) { load(0); put(0); }
-    if (nk > 1) load(32);
+    const int nk = ks1 - ks0;
+    if (nk > 0) { load(koff); put(0); }
+    if (nk > 1) load(koff + 32);
     for (int i = 0; i < nk; ++i) {
         __syncthreads();   // slot i&1 is complete; everyone is done reading slot (i+1)&1
         if (i + 1 < nk && !(p.flags & 32)) put((i + 1) & 1);
-        if (i + 2 < nk && !(p.flags & 128)) load((i + 2) * 32);
+        if (i + 2 < nk && !(p.flags & 128)) load(koff + (i + 2) * 32);
         if (!(p.flags & 16)) {
             const char* sb = smem + (i & 1) * STAGE_B;
             bf16x8 ah[MI], al[MI];
@@ -252,7 +259,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_planes_tn_kernel(PTN p) {
             if (n >= N) continue;
             const f32x4 v = acc[i][j] * alpha;
             float* cp = crow + n;
-            if (n + 3 < N && vec) {
+            if (p.ksplit > 1) {          // shared tile (accumulating launch): partial results meet in atomics
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) atomicAdd(cp + r, v[r]);
+            } else if (n + 3 < N && vec) {
                 if (p.accumulate) {
                     const f32x4 o = *reinterpret_cast<const f32x4*>(cp);
                     *reinterpret_cast<f32x4*>(cp) = o + v;
@@ -282,7 +293,16 @@ int launch_tn(PTN& p, const int* h_M, const int* h_N, int count, hipStream_t s) 
     }
     p.tile0[count] = tiles;
     p.tiles = tiles;
-    p.per = (tiles + 7) / 8;
+    // k shares per tile (AAS_TN_KSPLIT, default 1; accumulating launches only - the partial results are ADDED with atomics).
+    // Two shares bring the fp32-equivalent mode's weight-gradient error from 1.2-1.5x the fp32 mode's down to it (shorter
+    // accumulation chains, as the fp32 GEMM's split-K has), but every launch then pays ~40 us of atomics: config-2 step
+    // 23.6 -> 25.5 ms (four shares 28.6), fast mode 16.0 -> 17.2 - so it stays an option.
+    static const int ks_env = getenv("AAS_TN_KSPLIT") ? atoi(getenv("AAS_TN_KSPLIT")) : 1;
+    int ksplit = ks_env;
+    if (ksplit > 8) ksplit = 8;
+    if (!p.accumulate || ksplit < 1) ksplit = 1;
+    p.ksplit = ksplit;
+    p.per = (tiles * ksplit + 7) / 8;
     constexpr int LDS = 2 * 32 * (BMC + BNC) * 4;
     static bool attr_done = false;
     if (!attr_done) {
