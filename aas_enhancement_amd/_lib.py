@@ -28,6 +28,9 @@ SIGNATURES = {
     "aas_set_rnn_cu_limit": [c_int],
     "aas_gemm_f32": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                      c_int, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_i64],
+    "aas_gemm_f32_multi": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int],
+    "aas_set_gemm_variant": [c_int],
+    "aas_set_gemm_max_steps": [c_int],
     "aas_gemm_tn_rowscaled_f32": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_int],
     "aas_gemm_planes": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                         c_int, c_i64, c_i64, c_i64],
@@ -106,6 +109,11 @@ def lib():
             L.aas_set_wgrad_wg_cap(int(os.environ["AAS_WGRAD_WGS"]))
         if os.environ.get("AAS_DEBUG_FLAGS"):             # A/B kernel-selection bits of aas_set_debug_flags (include/aas_hip.h)
             L.aas_set_debug_flags(int(os.environ["AAS_DEBUG_FLAGS"]))
+        # The host side above this binding is the TRAINING STEP: its GEMMs run beside persistent recurrent launches that become
+        # resident only when enough CUs are free at once, so a GEMM workgroup lives at most 48 k-steps (~0.1 ms) here - deeper
+        # products are split further along K.  Same box, config-2 fp32 step: no cap 28.6 ms, 48: 27.55, 24: 27.7.  (The C library's
+        # own default is no cap: the best choice for a product alone on the chip.)
+        L.aas_set_gemm_max_steps(int(os.environ.get("AAS_GEMM32_MAXSTEPS", "48")))
         if os.environ.get("AAS_PRECISION") in ("0", "1", "2"):  # 0 = fp32 MFMA (library default), 1 = split-bf16 fast mode
             L.aas_set_precision(int(os.environ["AAS_PRECISION"]))
         _lib = L

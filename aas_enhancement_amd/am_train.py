@@ -334,8 +334,8 @@ def main(argv=None):
     ap.add_argument("--preprocess", default="file", help="file: LMFB .pt7 tensors | code: waveforms + the LMFB HIP kernel")
     ap.add_argument("--sortagrad", default=False, type=lambda v: str(v).lower() in ("true", "1"),
                     help="first epoch in manifest (increasing length) order, no reshuffling afterwards (train.py:109,270-272,484-486)")
-    ap.add_argument("--precision", default="fp32", choices=("fp32", "fp32eq", "bf16x3"),
-                    help="fp32 (the reference's arithmetic) | fp32eq (fp32-equivalent six-product GEMMs) | bf16x3 (split-bf16 fast mode)")
+    ap.add_argument("--precision", default=None, choices=("fp32", "fp32eq", "bf16x3"),
+                    help="absent: AAS_PRECISION from the environment, else fp32 | fp32 (the reference's arithmetic) | fp32eq (fp32-equivalent six-product GEMMs) | bf16x3 (split-bf16 fast mode)")
     ap.add_argument("--optim", default="adam", help="adam|sgd (sgd: momentum, nesterov; train.py:171-174)")
     ap.add_argument("--momentum", default=0.9, type=float)
     ap.add_argument("--seed", default=123456, type=int)
@@ -351,7 +351,8 @@ def main(argv=None):
         dist.init_process_group(a.dist_backend, **(dict(device_id=torch.device("cuda", a.gpu)) if a.dist_backend == "nccl" else {}))
     torch.manual_seed(a.seed); np.random.seed(a.seed); random.seed(a.seed)
     torch.cuda.set_device(a.gpu)
-    ops.set_precision({"fp32": 0, "bf16x3": 1, "fp32eq": 2}[a.precision])
+    if a.precision is not None:
+        ops.set_precision({"fp32": 0, "bf16x3": 1, "fp32eq": 2}[a.precision])
     from .data_loader import DataLoader
     with open(a.labels_path) as f:
         labels = str("".join(json.load(f)))

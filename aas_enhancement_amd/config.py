@@ -49,8 +49,8 @@ parser.add_argument("--fsegan_as_written", type=str2bool, default=False)
 parser.add_argument("--sync_bn", type=str2bool, default=False,
                     help="data parallel: all-reduce A's BatchNorm statistics (global-batch BN; default: local-batch BN per rank)")
 parser.add_argument("--dist_backend", default="nccl", help="torch.distributed backend under torchrun: nccl (= RCCL on ROCm) | gloo")
-parser.add_argument("--precision", default="fp32", choices=("fp32", "fp32eq", "bf16x3"),
-                    help="arithmetic of the GEMMs and recurrent products: fp32 (the reference's; default) | fp32eq (fp32 recurrent "
+parser.add_argument("--precision", default=None, choices=("fp32", "fp32eq", "bf16x3"),
+                    help="arithmetic of the GEMMs and recurrent products (absent: AAS_PRECISION from the environment, else fp32): fp32 (the reference's) | fp32eq (fp32 recurrent "
                          "products, large GEMMs as six bf16 products of three-term operands: fp32-equivalent, ~8 %% faster) | bf16x3 "
                          "(split-bf16 fast mode: hi*hi + lo*hi + hi*lo on bf16 MFMA, ~2x faster, inside the 1e-3 / 1e-2 parity budget)")
 parser.add_argument("--preprocess", default="file", help="file: manifests list precomputed LMFB .pt7 tensors (the reference's only "

@@ -17,6 +17,11 @@ int aas_precision_value();
 int aas_wgrad_wg_cap();                       // 0 = no cap on the grid of aas_gemm_planes_tn
 void aas_note_fwd_h_planes(int pitch_bytes);  // what the last forward recurrent launch left in its exchange buffer (0: nothing usable)
 int aas_rnn_launch_tag_value();  // >= 1: what a timed-out persistent launch leaves in its sticky error word
+// gemm32.hip: the LDS-DMA fp32 GEMM; -> 0 launched, 1 error, -1 not applicable to these operands (take the general kernel)
+int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                   int64_t ldc, const float* bias, const float* addend, int64_t ldd, int accumulate, int batch, int64_t strideA,
+                   int64_t strideB, int64_t strideC, int kdivA, int64_t kouterA, int kdivB, int64_t kouterB, int nmulti,
+                   const float* const* Am, const float* const* Bm, float* const* Cm, const int* Km);
 int aas_rnn_cus();  // aas_device_cus() capped by aas_set_rnn_cu_limit()
 
 #define AAS_CHECK(cond, ...)            \

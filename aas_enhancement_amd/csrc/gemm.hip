@@ -471,6 +471,12 @@ static int gemm_f32_impl(aasStream_t stream, int mode, int M, int N, int K, cons
     AAS_CHECK(!(batch > 1 && mode == AAS_GEMM_TN), "aas_gemm_f32: batch>1 unsupported for TN");
     if (M == 0 || N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (aas_precision_value() != 1 && kscale == nullptr) {
+        // fp32 arithmetic: the LDS-DMA kernel (gemm32.hip) wherever both operands take 16-byte chunks
+        const int rc32 = aas_gemm32_try(s, mode, M, N, K, A, lda, B, ldb, C, ldc, bias, addend, ldd, accumulate, batch, strideA, strideB,
+                                        strideC, kdivA, kouterA, kdivB, kouterB, 0, nullptr, nullptr, nullptr, nullptr);
+        if (rc32 >= 0) return rc32;
+    }
     GemmP p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.addend = addend;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldd = ldd;
@@ -538,6 +544,29 @@ extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, c
                             int64_t kouterB) {
     return gemm_f32_impl(stream, mode, M, N, K, A, lda, B, ldb, C, ldc, bias, addend, ldd, accumulate, batch, strideA, strideB, strideC,
                          kdivA, kouterA, kdivB, kouterB, nullptr, 0);
+}
+
+extern "C" int aas_gemm_f32_multi(aasStream_t stream, int mode, int n, int M, int N, const int* K, const float* const* A, int64_t lda,
+                                  const float* const* B, int64_t ldb, float* const* C, int64_t ldc, int accumulate) {
+    AAS_CHECK(mode >= 0 && mode <= 2 && n >= 1 && n <= 4, "aas_gemm_f32_multi: bad mode %d / problem count %d", mode, n);
+    AAS_CHECK(M >= 0 && N >= 0 && K && A && B && C, "aas_gemm_f32_multi: bad sizes M=%d N=%d or null arrays", M, N);
+    int kmax = 0;
+    for (int i = 0; i < n; ++i) {
+        AAS_CHECK(K[i] >= 0 && A[i] && B[i] && C[i], "aas_gemm_f32_multi: problem %d: K=%d or a null operand", i, K[i]);
+        kmax = K[i] > kmax ? K[i] : kmax;
+    }
+    if (M == 0 || N == 0) return 0;
+    if (aas_precision_value() != 1) {
+        const int rc32 = aas_gemm32_try((hipStream_t)stream, mode, M, N, kmax, nullptr, lda, nullptr, ldb, nullptr, ldc, nullptr, nullptr, 0,
+                                        accumulate, 1, 0, 0, 0, 0, 0, 0, 0, n, A, B, C, K);
+        if (rc32 >= 0) return rc32;
+    }
+    for (int i = 0; i < n; ++i) {   // operands that do not take 16-byte chunks (or the fast mode): one general launch per problem
+        const int rc = gemm_f32_impl(stream, mode, M, N, K[i], A[i], lda, B[i], ldb, C[i], ldc, nullptr, nullptr, 0, accumulate, 1, 0, 0, 0, 0,
+                                     0, 0, 0, nullptr, 0);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" int aas_gemm_tn_rowscaled_f32(aasStream_t stream, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,

@@ -30,8 +30,24 @@ def _host_group():
         return None
     if be not in _HOST_GROUPS:
         import datetime
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        _HOST_GROUPS[be] = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=24))
+        # Single node (every rank of the job is local, or the rendezvous address is loopback): gloo's interface discovery
+        # resolves the container hostname, which may not resolve here - pin the loopback interface for the CREATION of this
+        # group only and put the caller's environment back.  Multi-node jobs keep gloo's own choice (or the user's
+        # GLOO_SOCKET_IFNAME): loopback cannot rendezvous across nodes.
+        world = dist.get_world_size()
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
+        addr = os.environ.get("MASTER_ADDR", "")
+        single_node = (local > 0 and local == world) or addr in ("127.0.0.1", "localhost", "::1")
+        had, prev = "GLOO_SOCKET_IFNAME" in os.environ, os.environ.get("GLOO_SOCKET_IFNAME")
+        if single_node and not had:
+            os.environ["GLOO_SOCKET_IFNAME"] = "lo"
+        try:
+            _HOST_GROUPS[be] = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=24))
+        finally:
+            if single_node and not had:
+                os.environ.pop("GLOO_SOCKET_IFNAME", None)
+            elif had:
+                os.environ["GLOO_SOCKET_IFNAME"] = prev
     return _HOST_GROUPS[be]
 
 
@@ -146,10 +162,8 @@ class DPContext(object):
         if pct is not None and not pct.is_cuda:
             # T_i = pct_i * T_max exactly as _collate_fn formed it (lengths / T_max in fp64, rounded to fp32)
             m.n_valid = int(torch.round(pct.index_select(0, idx).double() * inputs.size(2)).sum().item())
-        elif not mask.is_cuda:
-            m.n_valid = int(m.numel()) - int(m.sum().item())
         else:
-            m.n_valid = int(m.numel()) - int(m.sum().item())     # (device mask and no host lengths: one read-back)
+            m.n_valid = int(m.numel()) - int(m.sum().item())     # (no host lengths; a device mask costs one read-back)
         return (inputs.index_select(0, idx.to(inputs.device)), tg, pct.index_select(0, idx), tsz.index_select(0, idx), m)
 
 

@@ -133,6 +133,13 @@ class FeatSampler(Sampler):
         ids = list(range(0, len(data_source)))
         self.bins = [ids[i:i + batch_size] for i in range(0, len(ids), batch_size)]
         self.log = None       # tests: a list that receives (global ids of the bin, this rank's ids) per batch
+        dropped = [b for b in self.bins if not self._usable(b)]
+        uneven = sum(1 for b in self.bins if self._usable(b) and len(b) % self.world)
+        if self.world > 1 and self.rank == 0 and (dropped or uneven):
+            # said once, at construction: what data parallelism changes about the epoch
+            print("FeatSampler: %d ranks - %d bin(s) with fewer utterances than ranks (%d utterances) are skipped every epoch; %d bin(s) "
+                  "do not divide evenly, so ranks get shards of different sizes there (per-rank BatchNorm statistics then differ: "
+                  "--sync_bn makes them global)" % (self.world, len(dropped), sum(len(b) for b in dropped), uneven))
 
     def shard(self, ids):
         return sorted(ids, reverse=True)[self.rank::self.world]

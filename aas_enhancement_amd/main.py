@@ -15,8 +15,7 @@ def main(config):
         from .trainer_DCE import Trainer
         paired = True
     elif config.trainer == "acoustic_supervision":
-        from .trainer_AAS import Trainer  # AAS with w_adversarial = 0 (trainer_acoustic.py:120-142)
-        config.w_adversarial = 0
+        from .trainer_acoustic import Trainer  # E + A only, loss = CTC / N (trainer_acoustic.py:120-142): no discriminator runs
         paired = False
     elif config.trainer == "AAS":
         from .trainer_AAS import Trainer
@@ -41,7 +40,10 @@ def main(config):
             kw = dict(device_id=torch.device("cuda", local_rank)) if config.dist_backend == "nccl" else {}
             dist.init_process_group(config.dist_backend, **kw)
     from . import ops
-    ops.set_precision({"fp32": 0, "bf16x3": 1, "fp32eq": 2}[getattr(config, "precision", "fp32")])
+    # --precision given: it selects the arithmetic of the run; absent: the library's setting stands (AAS_PRECISION in the
+    # environment, else fp32)
+    if getattr(config, "precision", None) is not None:
+        ops.set_precision({"fp32": 0, "bf16x3": 1, "fp32eq": 2}[config.precision])
     import numpy as np
     np.random.seed(config.random_seed)      # FeatSampler shuffles with numpy: identical batch order on every rank
     if config.gpu >= 0:

@@ -269,6 +269,17 @@ def _gemm_raw(mode, M, N, K, A, lda, B, ldb, C, ldc, bias, addend, ldd, accumula
                              batch, sA, sB, sC, kdivA, kouterA, kdivB, kouterB), "aas_gemm_f32")
 
 
+def gemm_multi(mode, M, N, Ks, As, lda, Bs, ldb, Cs, ldc, accumulate=False):
+    """<= 4 products of equal shape in ONE launch (include/aas_hip.h: aas_gemm_f32_multi): As / Bs / Cs are device byte addresses,
+    Ks the reduction extent of each problem."""
+    import ctypes
+    n = len(Ks)
+    vp = lambda xs: (ctypes.c_void_p * n)(*[int(x) for x in xs])
+    ks = (ctypes.c_int * n)(*[int(k) for k in Ks])
+    with _timed("gemm", "gemm_%s" % ("nt", "nn", "tn")[mode], sum(2.0 * M * N * k for k in Ks)):
+        check(lib().aas_gemm_f32_multi(stream(), mode, n, M, N, ks, vp(As), lda, vp(Bs), ldb, vp(Cs), ldc, int(accumulate)), "aas_gemm_f32_multi")
+
+
 # ---- pre-split operand planes (split-bf16 GEMM with the fp32 -> hi/lo split hoisted out of the k-loop) ----------
 class Planes(object):
     """Interleaved bf16 hi/lo planes of a [rows, K] operand (include/aas_hip.h: aas_gemm_planes): `buf` is
@@ -765,6 +776,7 @@ _GATES = {"lstm": 4, "gru": 3, "rnn": 1}
 # behind the BPTT launch and take CUs from the input-gradient GEMM on the critical path, and the per-row weight lengthens the TN
 # kernel's prefetch - so it is off by default.
 _TN_FOLD = os.environ.get("AAS_TN_FOLD", "0") == "1"
+MULTI_WGRAD = [os.environ.get("AAS_MULTI_WGRAD", "1") == "1"]   # fp32 arithmetic: a layer's four weight-gradient products as one aas_gemm_f32_multi launch
 TN_WGRAD = [os.environ.get("AAS_TN_WGRAD", "1") == "1"]   # weight-gradient products from row-major planes (aas_gemm_planes_tn)
 
 
@@ -1058,6 +1070,23 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
                 xw = scale_rows(x2, rs, N)
                 if T > 1:
                     hw = scale_rows(hout.view(2 * R, H), rs, N)
+        if MULTI_WGRAD[0] and _precision[0] != 1 and not (rs is not None and _precision[0] == 0 and _TN_FOLD) and all(o.is_contiguous() for o in out):
+            # the four products of the layer (both directions' dW_ih and dW_hh) share d(gates): ONE launch of 4 x (GH/128 x I/128)
+            # tiles fills the chip without split-K (two launches when the input and hidden widths differ)
+            a0, ah, b0, bh = dgx.data_ptr(), dgh.data_ptr(), xw.data_ptr(), hw.data_ptr()
+            ih = ([a0, a0 + 4 * GH], [b0, b0], [out[0].data_ptr(), out[2].data_ptr()], [R, R])
+            Rm = (T - 1) * N
+            hh = ([ah + 4 * N * 2 * GH, ah + 4 * GH], [bh, bh + 4 * (T * N * H + N * H)], [out[1].data_ptr(), out[3].data_ptr()], [Rm, Rm])
+            if T > 1 and I == H:
+                gemm_multi(TN, GH, I, ih[3] + hh[3], ih[0] + hh[0], 2 * GH, ih[1] + hh[1], I, ih[2] + hh[2], I, accumulate=acc)
+            else:
+                gemm_multi(TN, GH, I, ih[3], ih[0], 2 * GH, ih[1], I, ih[2], I, accumulate=acc)
+                if T > 1:
+                    gemm_multi(TN, GH, H, hh[3], hh[0], 2 * GH, hh[1], H, hh[2], H, accumulate=acc)
+                elif not acc:
+                    out[1].zero_()
+                    out[3].zero_()
+            return
         tn(GH, I, R, dgx, 2 * GH, xw, I, out[0], I, accumulate=acc)
         tn(GH, I, R, dgx, 2 * GH, xw, I, out[2], I, a_off=GH, accumulate=acc)
         if T > 1:

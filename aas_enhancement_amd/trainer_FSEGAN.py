@@ -76,7 +76,12 @@ class Trainer(object):
 
     def _batch(self, data_list):
         mask = data_list[2]
-        attach_n_valid(mask) if not mask.is_cuda else None
+        if not mask.is_cuda:
+            attach_n_valid(mask)
+        elif getattr(mask, "n_valid", None) is None:
+            # a loader that hands out device masks without the host-side count: one read-back here, so that both step forms
+            # (and read_scalars() behind train_step_async) see the same state - the synchronous fallback read it back anyway
+            mask.n_valid = int(mask.numel()) - int(mask.sum().item())
         return _get_variable_nograd(data_list[0]), _get_variable_nograd(data_list[1]), _get_variable_nograd(mask)
 
     def _forward_backward(self, mixture, cleans, rs, s_adv, s_dce):

@@ -1,0 +1,223 @@
+"""Acoustic-supervision trainer on the MI355X HIP path - same API as the reference's
+Speech_enhancement_by_AAS/trainer_acoustic.py (Trainer.train, hot loop :120-142): the enhancer E is trained through the
+acoustic model A alone, loss = CTC(A(E(x))) / N.  There is NO discriminator in this trainer: none is built, none runs
+(`main.py --trainer acoustic_supervision`; it used to be mapped onto the AAS trainer with w_adversarial = 0, which still ran
+D's two forward and two backward passes and multiplied them by zero).
+
+The step is one serial chain - E forward, A forward, CTC, A backward, E backward - so every persistent recurrent launch
+takes the whole chip; the weight-gradient products run on the side stream as in the AAS trainer.  `train_step_async` keeps
+the loss and the running CTC average of the log line on the device (no host synchronisation per step).
+"""
+import torch
+
+from . import ops
+from .trainer_AAS import Trainer as _AASTrainer
+
+
+class Trainer(_AASTrainer):
+    def build_model(self):
+        from .model import DeepSpeech, stackedBRNN, supported_rnns
+        c = self.config
+        print("initialize enhancement model")
+        self.G = stackedBRNN(I=c.nFeat, H=c.rnn_size, L=c.rnn_layers, rnn_type=supported_rnns[c.rnn_type])
+        self.D = _NoNet()
+        print("load pre-trained ASR model")
+        package_ASR = torch.load(c.ASR_path, map_location=lambda storage, loc: storage)
+        self.ASR = DeepSpeech.load_model_package(package_ASR)
+
+    def __init__(self, config, data_loader=None, models=None):
+        if models is not None and len(models) == 2:   # (E, A): the shared plumbing iterates G, D, ASR - D is an empty stand-in
+            models = (models[0], _NoNet(), models[1])
+        super().__init__(config, data_loader, models)
+
+    def make_optimizers(self):
+        """Adam(amsgrad) on E and A (:117-118), flat buffers as in the AAS trainer."""
+        from .dist import BucketReducer, DPContext, FlatBuffers
+        from .optim import FlatAdam
+        c = self.config
+        self.dp = getattr(self, "dp", None) or DPContext.from_env()
+        for name, m in (("G", self.G), ("ASR", self.ASR)):
+            ops.name_layers(m, name)
+        self._frozen_asr = self.asr_frozen()
+        if self._frozen_asr:
+            for p in self.ASR.parameters():
+                p.requires_grad_(False)
+        self._flat = {"G": FlatBuffers(self.G)}
+        if not self._frozen_asr:
+            self._flat["A"] = FlatBuffers(self.ASR)
+        mk = lambda f: FlatAdam(f, lr=c.lr, betas=(self.beta1, self.beta2), amsgrad=True)
+        self._opts = (mk(self._flat["G"]), mk(self._flat["A"]) if "A" in self._flat else None, None)
+        self._reducer = BucketReducer(self.dp, self._flat.values()) if self.dp.active else None
+        ops.SYNC_BN[0] = self.dp if (self.dp.active and getattr(c, "sync_bn", False)) else None
+        return self._opts
+
+    # ---- one iteration of :120-142 -------------------------------------------------------------
+    def _core(self, inputs, ctc_meta, scale, it, targets=None, sizes=None, target_sizes=None, n_glob=None):
+        """E forward -> A forward -> CTC -> backward through A and E -> Adam.  `scale` = 1 / N (python float, or a device
+        scalar when data parallel); returns (enhanced, prob, l_CTC) as device tensors."""
+        c = self.config
+        optimizer_g, optimizer_asr, _ = self._opts
+        asr_steps = optimizer_asr is not None and it > c.allow_ASR_update_iter
+        ops.sync_wgrad()
+        for f in self._flat.values():
+            f.flat_g.zero_()
+        if self._reducer is not None:
+            self._reducer.begin()
+            ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
+        try:
+            ops.set_rnn_cu_limit(0)
+            enhanced = self.G(inputs)
+            prob = self.ASR(enhanced).transpose(0, 1)
+            if targets is None:
+                l_CTC = ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) * scale
+            else:
+                l_CTC = self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / n_glob
+            l_CTC.backward()
+            ops.sync_wgrad()
+            if self._reducer is not None:
+                for f in self._flat.values():
+                    self._reducer.flush(f)
+                self._reducer.wait()
+        finally:
+            ops.WGRAD_HOOK[0] = None
+        return enhanced, prob, l_CTC, asr_steps
+
+    def train_step(self, data_list, iter):
+        """Synchronous form: returns the host scalars the reference logs (:139-147)."""
+        if self._opts is None:
+            self.make_optimizers()
+        if getattr(self, "_acc_live", False):
+            self.read_scalars()
+        inputs, targets, input_percentages, target_sizes, _ = self._prep(data_list)
+        N = inputs.size(0)
+        t_out = self.ASR.output_length(inputs.size(2))
+        sizes = input_percentages.clone().mul_(int(t_out)).int()
+        ctc_meta = self.CTCLoss.prepare(targets, sizes, target_sizes, inputs.device)
+        n_glob = self.dp.global_counts([N])[0] if self.dp.active else N
+        enhanced, prob, l_CTC, asr_steps = self._core(inputs, ctc_meta, None, iter, targets, sizes, target_sizes, n_glob)
+        self._opts[0].step()
+        if asr_steps:
+            self._opts[1].step()
+            ops.refresh_weight_planes(self.ASR)
+        ops.refresh_weight_planes(self.G)
+        l_ctc = float(self.dp.reduce_scalars(l_CTC.detach().reshape(1).double()).item())
+        ops.check_rnn_health((l_ctc,))
+        self.ctc_tr_local.update(l_ctc, n_glob)
+        return dict(l_ctc=l_ctc, enhanced=enhanced, prob=prob)
+
+    def train_step_async(self, data_list, iter):
+        """The same iteration without a host synchronisation: the loss and the running CTC average stay on the device;
+        `read_scalars()` fetches them when a log line needs them."""
+        if self._opts is None:
+            self.make_optimizers()
+        inputs, targets, input_percentages, target_sizes, _ = self._prep(data_list)
+        N, dev = inputs.size(0), inputs.device
+        t_out = self.ASR.output_length(inputs.size(2))
+        sizes = input_percentages.clone().mul_(int(t_out)).int()
+        meta = ops.ctc_prepare(targets, sizes, target_sizes, "cpu")
+        meta = dict(meta, meta=self._upload_small(meta["meta"], dev))
+        if getattr(self, "_acc", None) is None:
+            self._acc = torch.zeros(3, device=dev, dtype=torch.float64)      # last loss, sum(loss * N), sum(N)
+        if self.dp.active:
+            from .dist import DeviceCounts
+            cnt = DeviceCounts(self.dp, [N], dev, ops.refresh_stream(dev))
+            n_dev = cnt.get(0)
+            scale = (1.0 / n_dev).float()
+        else:
+            n_dev, scale = float(N), 1.0 / N
+        enhanced, prob, l_CTC, asr_steps = self._core(inputs, meta, scale, iter)
+        self._opts[0].step_dev()
+        if asr_steps:
+            self._opts[1].step_dev()
+            ops.refresh_weight_planes(self.ASR)
+        ops.refresh_weight_planes(self.G)
+        l = l_CTC.detach().reshape(1).double()
+        if self.dp.active:
+            l = self.dp.reduce_scalars(l)     # every rank's loss is already divided by the global N
+        self._acc[0:1].copy_(l)
+        self._acc[1:2].add_(l * n_dev)
+        self._acc[2:3].add_(n_dev)
+        self._acc_live = True
+        return dict(enhanced=enhanced, prob=prob, scalars=self._acc)
+
+    def read_scalars(self):
+        """One D2H copy: the last queued step's loss; feeds the running CTC average of the log line; a synchronisation
+        point - raises if a persistent kernel timed out or the run diverged."""
+        l_ctc, s, n = self._acc.tolist()
+        self._acc[1:3].zero_()
+        self._acc_live = False
+        ops.check_rnn_health((l_ctc,))
+        if n > 0:
+            self.ctc_tr_local.update(s / n, n)
+        return dict(l_ctc=l_ctc)
+
+    def zero_grad_all(self):
+        ops.sync_wgrad()
+        for f in (self._flat or {}).values():
+            f.zero_grad()
+
+    def train(self):
+        """:113-200: iterations that print nothing are queued without a read-back; the log line reads the running average."""
+        from tqdm import trange
+        c = self.config
+        self.make_optimizers()
+        rank0 = self.dp.rank == 0
+        for iter in trange(c.start_iter, c.max_iter, disable=not rank0):
+            data_list = self.data_loader.next(cl_ny="ny", type="train")
+            if self.dp.active and getattr(self.data_loader, "dp", None) is None:
+                data_list = self.dp.shard_collated(data_list)
+            self.train_step_async(data_list, iter)
+            if (iter + 1) % c.log_iter == 0:
+                self.read_scalars()
+                s = "[{}/{}] (train) CTC: {:.7f}".format(iter, c.max_iter, self.ctc_tr_local.avg)
+                if rank0:
+                    print(s)
+                if self.logFile:
+                    self.logFile.write(s + "\n")
+                    self.logFile.flush()
+                self.ctc_tr_local.reset()
+            if (iter + 1) % c.save_iter == 0:
+                if getattr(self, "_acc_live", False):
+                    self.read_scalars()
+                if rank0:
+                    armed, ops.SYNC_BN[0] = ops.SYNC_BN[0], None
+                    try:
+                        self.validate_and_checkpoint(iter)
+                    finally:
+                        ops.SYNC_BN[0] = armed
+                if self.dp.active:
+                    self.dp.barrier()
+
+    def greedy_decoding_and_AAS(self, inputs, targets, input_percentages, target_sizes, mask, transcript_prob=0.001):
+        """Validation pass of trainer_acoustic.py:203-245: CTC and WER / CER only (the adversarial entries read 0)."""
+        import random
+
+        from .utils import _get_variable_volatile
+        inputs = _get_variable_volatile(inputs)
+        N = inputs.size(0)
+        split_targets, offset = [], 0
+        for size in target_sizes:
+            split_targets.append(targets[offset:offset + int(size)])
+            offset += int(size)
+        enhanced = self.G(inputs)
+        prob = self.ASR(enhanced).transpose(0, 1)
+        T = prob.size(0)
+        sizes = input_percentages.clone().mul_(int(T)).int()
+        decoded_output, _ = self.decoder.decode(prob.detach(), sizes)
+        target_strings = self.decoder.convert_to_strings(split_targets)
+        we = ce = total_word = total_char = 0
+        for x in range(len(target_strings)):
+            decoding, reference = decoded_output[x][0], target_strings[x][0]
+            we += self.decoder.wer(decoding, reference); ce += self.decoder.cer(decoding, reference)
+            total_word += len(reference.split()); total_char += len(reference)
+            if random.uniform(0, 1) < transcript_prob:
+                print("reference = " + reference); print("decoding = " + decoding)
+        l_CTC = self.CTCLoss(prob, targets, sizes, target_sizes) / N
+        return l_CTC, 0.0, 1, we / max(total_word, 1), ce / max(total_word, 1), total_word, total_char
+
+
+class _NoNet(torch.nn.Module):
+    """Stand-in for the discriminator this trainer does not have (the shared checkpoint / device plumbing iterates G, D, ASR)."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("the acoustic_supervision trainer has no discriminator")

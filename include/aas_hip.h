@@ -98,6 +98,22 @@ int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K,
                  const float* bias, const float* addend, int64_t ldd, int accumulate,
                  int batch, int64_t strideA, int64_t strideB, int64_t strideC,
                  int kdivA, int64_t kouterA, int kdivB, int64_t kouterB);
+/* `n` (<= 4) products of EQUAL shape and mode in one launch, C_i (+)= op(A_i) op(B_i): the four weight-gradient products of a
+ * bidirectional recurrent layer (dW_ih, dW_hh per direction: model.py:73-74,94-95 backward) share d(gates) and fill the chip together
+ * where each alone needs split-K.  A / B / C: HOST arrays of n device pointers, K: host array of the n reduction extents (the
+ * recurrent products of a layer sum one time step less than the input products).  fp32 arithmetic on the LDS-DMA kernel when every
+ * operand takes 16-byte chunks, else n launches of aas_gemm_f32. */
+int aas_gemm_f32_multi(aasStream_t stream, int mode, int n, int M, int N, const int* K, const float* const* A, int64_t lda,
+                       const float* const* B, int64_t ldb, float* const* C, int64_t ldc, int accumulate);
+/* Kernel choice of aas_gemm_f32 in fp32 arithmetic: 0 (default) = the LDS-DMA kernel (128 x 128 x 32 tiles, operands by
+ * global_load_lds, split-K through partial slabs + a reduce launch) wherever both operands take 16-byte chunks; 1 = always the
+ * register-staged kernel (atomic split-K).  Results agree to fp32 summation order.  Environment: AAS_GEMM32=0 selects 1. */
+int aas_set_gemm_variant(int variant);
+/* Longest life of a workgroup of the LDS-DMA GEMM in k-steps of 32 (~2 us each); 0 = no cap (default; AAS_GEMM32_MAXSTEPS).  Deep
+ * products are split further along K (slabs + reduce launch) so that every workgroup hands its CU back within that time: the
+ * persistent recurrent launches of the training step (trainer_AAS.py:131-194 on this build's schedule) become resident only when
+ * enough CUs are free at once. */
+int aas_set_gemm_max_steps(int steps);
 /* C[M,N] (+)= sum_r kscale[r % knb] * A[r,M]^T B[r,N]   (fp32 mode): the TN product of aas_gemm_f32 with a per-reduction-row weight
  * applied while A is staged - the D-step weight gradients of a batched [enhanced; clean] discriminator pass carry the BEGAN factor
  * (-kt) on the enhanced utterances only (trainer_AAS.py:152-160); r = (t, n) time-major, knb = utterances per time step. */

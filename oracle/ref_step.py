@@ -7,6 +7,7 @@
                   ("intended": DCE term back-propagated; as_written=True keeps the
                   reference's behaviour where G only gets the adversarial gradient)
   am_step      <- AM_training/train.py:297-349
+  acoustic_step <- trainer_acoustic.py:120-142 (E + A, loss = CTC / N: no discriminator, no w_acoustic)
 
 Substitutions vs the reference source: .data[0] -> .item(); no
 .cuda(); bool mask; warpctc CTCLoss(prob, ...) -> F.ctc_loss(log_softmax(prob)),
@@ -103,6 +104,23 @@ def aas_step(G, D, A, opt_g, opt_d, opt_a, noisy, clean, cfg, kt, it):
     return kt, dict(l_adv_ny_G=l_adv_ny_G, l_adv_cl=l_adv_cl, l_ctc=l_ctc_v, g_adv=g_adv,
                     g_ctc_adv=g_ctc_adv, kt=kt, conv_measure=conv,
                     enhanced=enhanced.detach(), logits=prob.detach())
+
+
+def acoustic_step(G, A, opt_g, opt_a, noisy, cfg, it):
+    """One iteration of trainer_acoustic.py:120-142: enhanced = G(x); loss = CTC(A(enhanced)) / N; Adam on G, on A once
+    iter > allow_ASR_update_iter.  noisy = (inputs, targets, pct, target_sizes, ...)."""
+    inputs, targets, pct, target_sizes = noisy[0], noisy[1], noisy[2], noisy[3]
+    N = inputs.size(0)
+    enhanced = G(inputs)
+    prob = A(enhanced).transpose(0, 1)
+    sizes = frame_sizes(pct, prob.size(0))
+    loss = ctc_sum(prob, targets, sizes, target_sizes) / N
+    G.zero_grad(); A.zero_grad()
+    loss.backward()
+    opt_g.step()
+    if it > cfg.allow_ASR_update_iter:
+        opt_a.step()
+    return dict(l_ctc=loss.item(), enhanced=enhanced.detach(), logits=prob.detach())
 
 
 def dce_step(G, opt_g, batch):

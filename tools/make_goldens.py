@@ -618,15 +618,87 @@ def f9_rnn_kind():
     print("F9 keys", len(out))
 
 
+def acoustic_iteration(G, A, og, oa, ny, it, allow):
+    """trainer_acoustic.py:120-142, line by line, on reference modules (loss = CTC / N: no w_acoustic, no discriminator)."""
+    inputs, targets, pct, target_sizes = t(ny["inputs"]), t(ny["targets"]), t(ny["pct"]).clone(), t(ny["target_sizes"])
+    N = inputs.size(0)
+    enhanced = G(inputs)
+    prob = A(enhanced)
+    prob = prob.transpose(0, 1)
+    T = prob.size(0)
+    sizes = pct.mul_(int(T)).int()
+    loss = ctc_sum(prob, targets, sizes, target_sizes)
+    loss = loss / N
+    G.zero_grad(); A.zero_grad()
+    loss.backward()
+    grads = {}
+    for nm, m in (("G", G), ("A", A)):
+        for k, p in m.named_parameters():
+            grads[nm + "." + k] = p.grad.detach().clone().numpy()
+    og.step()
+    if it > allow:
+        oa.step()
+    return loss.item(), grads, enhanced.detach().numpy(), prob.detach().numpy()
+
+
+def f10_acoustic():
+    """F10: the acoustic_supervision trainer (trainer_acoustic.py:120-142): a tiny case with every tensor (3 iterations, ragged
+    lengths, A trainable from iteration 1) and config-2 size (N=30, T=200, E 4x500, A 2conv+5x1000 GRU), 2 iterations, sampled."""
+    out = {}
+    # ---- tiny
+    Fdim, H, HA, M, N, T, L = 8, 16, 12, 8, 4, 60, 3
+    G, _, A = build_aas(Fdim, H, HA, M, 3, seed=7100)
+    og, oa = adam(G, 1e-3), adam(A, 1e-3)
+    for k, v in G.state_dict().items():
+        out["tiny.G0." + k] = v.numpy().copy()
+    for k, v in A.state_dict().items():
+        out["tiny.A0." + k] = v.numpy().copy()
+    for it in range(3):
+        ny = make_batch(N, Fdim, [60, 52, 47, 33], seed=7200 + it, label_lens=[3, 2, 3, 1], lab_seed=7300 + it)
+        loss, grads, enh, prob = acoustic_iteration(G, A, og, oa, ny, it, allow=0)
+        p = "tiny.it%d." % it
+        for k, v in ny.items():
+            out[p + "ny." + k] = v
+        out[p + "loss"], out[p + "enhanced"], out[p + "logits"] = np.float64(loss), enh, prob
+        for k in ("G.rnn1.rnn.weight_hh_l0", "G.final_linear.weight", "A.conv.0.weight", "A.rnns.1.rnn.weight_ih_l0", "A.fc.0.module.1.weight"):
+            out[p + "grad." + k] = grads[k]
+    for k, v in G.state_dict().items():
+        out["tiny.G3." + k] = v.numpy().copy()
+    for k, v in A.state_dict().items():
+        out["tiny.A3." + k] = v.numpy().copy()
+    # ---- config-2 size (weights = F3's: seed 9000)
+    Fdim, H, HA, M, N, T, L = 80, 500, 1000, 128, 30, 200, 20
+    G, _, A = build_aas(Fdim, H, HA, M, 5, seed=9000)
+    og, oa = adam(G, 1e-5), adam(A, 1e-5)
+    out.update({"big.weight_seed": 9000, "big.lr": 1e-5, "big.N": N, "big.F": Fdim, "big.T": T, "big.L": L})
+    for it in range(2):
+        ny = dict(inputs=prng.uniform(123 + 1000 * it, (N, Fdim, T), 0.0, 6.0), mask=np.zeros((N, 1, T), np.uint8), pct=np.ones(N, np.float32),
+                  targets=prng.randint(125 + 1000 * it, (N * L,), 1, 28).astype(np.int32), target_sizes=np.full(N, L, np.int32))
+        loss, grads, enh, prob = acoustic_iteration(G, A, og, oa, ny, it, allow=0)
+        p = "big.it%d." % it
+        out[p + "loss"] = np.float64(loss)
+        ie, il = sample_idx(61 + it, enh.shape, 256), sample_idx(71 + it, prob.shape, 256)
+        out[p + "enh_idx"], out[p + "enh_samples"] = ie, enh.reshape(-1)[ie]
+        out[p + "logit_idx"], out[p + "logit_samples"] = il, prob.reshape(-1)[il]
+        for k in ("G.rnn1.rnn.weight_hh_l0", "G.rnn4.rnn.weight_ih_l0_reverse", "A.rnns.2.rnn.weight_hh_l0"):
+            g = grads[k]
+            ig = sample_idx(81, g.shape, 64)
+            out[p + "gradsample_idx." + k], out[p + "gradsample." + k] = ig, g.reshape(-1)[ig]
+            out[p + "gradnorm." + k] = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        print("F10 big it", it, loss, flush=True)
+    np.savez_compressed(os.path.join(OUT, "f10_acoustic.npz"), **out)
+    print("F10 keys", len(out))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip F3 (config 2, minutes of CPU)")
-    ap.add_argument("--only", default="", help="comma list of fixtures to (re)generate: f1,f2,f3,f4,f5,f6,f7,f8,f9")
+    ap.add_argument("--only", default="", help="comma list of fixtures to (re)generate: f1,...,f10")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     if a.only:
         table = dict(f1=f1_tiny, f2=f2_dce, f3=f3_config2, f4=f4_ops, f5=f5_fsegan_am, f6=f6_fsegan_config4,
-                     f7=f7_am_config5, f8=f8_host_side, f9=f9_rnn_kind)
+                     f7=f7_am_config5, f8=f8_host_side, f9=f9_rnn_kind, f10=f10_acoustic)
         for k in a.only.split(","):
             table[k]()
         sys.exit(0)
@@ -640,3 +712,4 @@ if __name__ == "__main__":
         f3_config2()
         f6_fsegan_config4()
         f7_am_config5()
+        f10_acoustic()
