@@ -344,6 +344,9 @@ float* workspace(hipStream_t s, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     Ws& w = g_ws[s];
     if (w.bytes < bytes) {
+        // a stream under hipGraph capture can neither be synchronised nor allocate: the caller runs the product without split-K
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
         // (the old block may still be read by a queued reduce launch: it is released when the stream has drained)
         if (w.p) {
             if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
@@ -501,9 +504,15 @@ int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A,
     if (sk > 1) {
         const size_t wsb = sizeof(float) * (size_t)sk * nz * M * N;
         p.ws = workspace(s, wsb);
-        AAS_CHECK(p.ws != nullptr, "aas_gemm_f32: could not allocate the split-K workspace (%zu bytes)", wsb);
-        p.splitk = sk;
-        grid.z = sk * nz;
+        if (p.ws != nullptr) {
+            p.splitk = sk;
+            grid.z = sk * nz;
+        } else {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(s, &cs);
+            AAS_CHECK(cs != hipStreamCaptureStatusNone, "aas_gemm_f32: could not allocate the split-K workspace (%zu bytes)", wsb);
+            sk = 1;     // (capturing, and no eager launch on this stream has sized the workspace yet: whole-K workgroups)
+        }
     }
     int rc;
     if (tmw == 64) {

@@ -539,7 +539,9 @@ int launch_rs(const RnnP& p, hipStream_t s) {
     if (p.P <= 8) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 2, -1, EX>), grid, block, 0, s, p);
     else if (p.P <= 16) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 4, -1, EX>), grid, block, 0, s, p);
     else if (p.P <= 32) {
-        if (!EX && MODE == GRU_BWD && U == 32 && (p.flags & 32768)) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 8, 1, false>), grid, block, 0, s, p);
+        // (LSTM layers wider than 512 units never get here with 32-unit slices: 128 gate rows x 1024 k of W^T do not fit the
+        //  register file of a 512-thread workgroup - that instance spilled 190-256 VGPRs - so run_bwd_rs gives them 16-unit slices)
+        if constexpr (MODE == LSTM_BWD && U == 32) return -1;
         else hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, U, 8, -1, EX>), grid, block, 0, s, p);
     }
     else if (U == 16 && p.P <= 64) hipLaunchKernelGGL((rnn_bwd_rs_kernel<MODE, 16, 16, -1, EX>), grid, block, 0, s, p);
@@ -557,7 +559,9 @@ int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
     p.tag = aas_rnn_launch_tag_value();
     // 32-unit slices (512-thread workgroups) halve the number of slices and with it the bytes every step moves
     // through the fabric; small layers keep 16-unit slices so that enough workgroups share the work
-    const int U = (p.H >= 256 && !(p.flags & 512)) ? 32 : 16;
+    // (LSTM layers of 512 < H <= 1024 units - legal: AM_training/train.py:46,203-204 - take 16-unit slices: 455 VGPRs in 256-thread
+    //  workgroups, no scratch)
+    const int U = (p.H >= 256 && !(p.flags & 512) && !(MODE == LSTM_BWD && p.H > 512)) ? 32 : 16;
     p.P = cdiv(p.H, U);
     if (X6 && !(MODE == LSTM_BWD && U == 32 && p.P > 8 && p.P <= 16)) return -1;   // (before anything is queued)
     if (p.P > (U == 16 ? 64 : 32)) return -1;              // one poll lane per producer, <= 8/16 tiles per wave

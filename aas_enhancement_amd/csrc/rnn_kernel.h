@@ -392,9 +392,8 @@ int launch_mt(const RnnP& p, int ks_need, bool vec, hipStream_t s) {
     if (ks_need <= 2) return launch_k<MODE, MT, 2, true>(p, s);
     if (ks_need <= 4) return launch_k<MODE, MT, 4, true>(p, s);
     if (ks_need <= 8) return launch_k<MODE, MT, 8, true>(p, s);
-    if constexpr (MODE == LSTM_FWD) return -1;  // H > 512 not instantiated for the LSTM forward slice width
-    else {
-        if (ks_need <= 16) return launch_k<MODE, MT, 16, true>(p, s);
+    {
+        if (ks_need <= 16) return launch_k<MODE, MT, 16, true>(p, s);      // (forward kernels: H <= 1024)
         if constexpr (FWD || MODE == RNN_BWD) return -1;
         else {
             if (ks_need <= 32) return launch_k<MODE, MT, 32, true>(p, s);

@@ -643,7 +643,9 @@ int launch_split_mt(const RnnP& p, int ks_need, hipStream_t s) {
         if constexpr (FWD || EX) return -1;
         else {
             if (ks_need <= 16) return launch_sk<MODE, MT, 16, EX>(p, s);
-            if (ks_need <= 24) return launch_sk<MODE, MT, 24, EX>(p, s);
+            if constexpr (MT == 1) {     // (two row tiles x 24 k-steps spilled registers: those shapes take the counter-based kernel)
+                if (ks_need <= 24) return launch_sk<MODE, MT, 24, EX>(p, s);
+            }
             return -1;
         }
     }

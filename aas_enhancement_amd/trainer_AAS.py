@@ -701,7 +701,11 @@ class Trainer(object):
             snap = [(f.flat_p.clone(), o.m.clone(), o.v.clone(), o.vmax.clone() if o.vmax is not None else None, o.step_count)
                     for f, o in pairs]
             bn_snap = {k: v.clone() for k, v in self.ASR.state_dict().items() if "running_" in k or "num_batches" in k}
-            ws = torch.cuda.Stream()
+            # (on the stream the capture will run on: per-stream scratch - the recurrent kernels' sync / exchange buffers, the
+            #  GEMM's split-K slabs - is then sized before the capture starts, where nothing may be allocated)
+            if getattr(self, "_cap_stream", None) is None:
+                self._cap_stream = torch.cuda.Stream()
+            ws = self._cap_stream
             ws.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(ws):
                 self._device_core(st["inputs"], st["cl"], nv_ny, nv_cl, st["meta"])

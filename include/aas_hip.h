@@ -43,7 +43,7 @@ int aas_device_cus(void);
  *     67108864 plain grid for the forward launches with more than 8 rows per group (default: XCD-aware grid, write-through),
  *   8388608 / 33554432 256x256 / 256x128 tiles for the wide products of aas_gemm_planes_tn (default 128x128),
  *   65536 / 131072 four waves per workgroup (one per SIMD) instead of eight in aas_gemm_planes_tn / the 128x128 aas_gemm_planes,
- *   32768 the 1000-unit GRU BPTT kernel with one (not two) k-steps of lo weight fragments in LDS (the older, spilling variant),
+ *   (32768: retired - it selected a register-spilling variant of the 1000-unit GRU BPTT kernel),
  *   134217728 fp32 mode on the counter-based kernels of round 1 instead of the data-is-the-flag ones, 268435456 fp32 mode: 16x16x4
  *     MFMA tiles also for row groups of <= 8 rows (default there: 4x4x1 blocks - same products, k summed in interleaved chains),
  *   536870912 mode 2: the exact (fp32-input MFMA) LSTM BPTT kernel instead of the six-product one,

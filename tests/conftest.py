@@ -9,11 +9,53 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# The library's default arithmetic is fp32 (aas_set_precision(0)).  Tests that do not take a `precision` fixture were written
-# against - and deliberately exercise - the split-bf16 fast mode's machinery (operand planes, plane-emitting BPTT, row-major
-# weight-gradient GEMM); the suite therefore defaults to that mode, and every parity test that matters runs in BOTH modes through
-# its `precision` fixture.  Child processes (multi-rank tests) inherit the variable.
-os.environ.setdefault("AAS_PRECISION", "1")
+# The suite runs in the LIBRARY'S DEFAULT arithmetic, fp32 (aas_set_precision(0); AAS_PRECISION in the environment moves the
+# default for a whole run and is inherited by the child processes of the multi-rank tests).  Parity tests that matter take the
+# `precision` fixture (fp32 / split-bf16 fast mode / fp32-equivalent) or `precision2` (fp32 / fast mode: the trainer-level schedule,
+# graph, data-parallel and validation tests); tests of the fast mode's own machinery (operand planes, plane-emitting BPTT, row-major
+# weight-gradient GEMM) pin mode 1 with `fast_mode`.  Every test leaves the process in the default mode (autouse fixture below).
+DEFAULT_PRECISION = int(os.environ.get("AAS_PRECISION", "0"))
+PRECISION_IDS = {0: "fp32", 1: "splitbf16", 2: "fp32eq"}
+
+
+def _ops():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from aas_enhancement_amd import ops
+    return ops
+
+
+@pytest.fixture(params=[0, 1, 2], ids=["fp32", "splitbf16", "fp32eq"])
+def precision(request):
+    _ops().set_precision(request.param)
+    return request.param
+
+
+@pytest.fixture(params=[0, 1], ids=["fp32", "splitbf16"])
+def precision2(request, monkeypatch):
+    _ops().set_precision(request.param)
+    monkeypatch.setenv("AAS_PRECISION", str(request.param))     # child processes (multi-rank tests) run the same mode
+    return request.param
+
+
+@pytest.fixture
+def fast_mode():
+    _ops().set_precision(1)
+    return 1
+
+
+@pytest.fixture(autouse=True)
+def _default_precision_after_every_test():
+    yield
+    try:
+        import torch
+        if torch.cuda.is_available():
+            from aas_enhancement_amd import ops
+            if ops.get_precision() != DEFAULT_PRECISION:
+                ops.set_precision(DEFAULT_PRECISION)
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def pytest_configure(config):

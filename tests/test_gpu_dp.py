@@ -83,7 +83,7 @@ def _mode_cfg(mode):
 
 
 @pytest.mark.parametrize("mode", ["sync", "async", "syncbn"])
-def test_trainer_dp_two_ranks_equals_single(mode):
+def test_trainer_dp_two_ranks_equals_single(mode, precision2):
     """sync: Trainer.train_step; async: the device-resident step bench.py times (global normalisers and kt inputs all-reduced
     on the device, bucketed gradient all-reduce); syncbn: + A's BatchNorm statistics all-reduced forward and backward, so
     even the acoustic branch (logits, CTC loss, the gradient it sends into E) equals the single-process global batch."""
@@ -156,7 +156,7 @@ def _am_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_am_trainer_dp_with_syncbn_equals_single():
+def test_am_trainer_dp_with_syncbn_equals_single(precision2):
     """AM pre-training step (config 5's per-GPU step) data parallel: global batch size as a device scalar, bucketed all-reduce of
     A's gradients, SyncBN - 2 ranks x 2 utterances == 1 rank x 4 utterances (loss and parameters after two Adam steps)."""
     if not torch.cuda.is_available():

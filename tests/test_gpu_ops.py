@@ -43,12 +43,6 @@ def test_native_library_loaded():
     assert L.aas_version() == 1 and L.aas_device_cus() >= 64
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["fp32", "splitbf16", "fp32eq"])
-def precision(request, ops):
-    ops.set_precision(request.param)
-    yield request.param
-    ops.set_precision(1)
-
 
 # relative tolerance of a K-deep product: exact fp32 MFMA vs split-bf16 (dropped lo*lo term ~2^-16)
 def gtol(precision, K):
@@ -240,9 +234,10 @@ def test_batchrnn_golden(ops, precision):
 
 
 @pytest.mark.parametrize("kind,T,N,H", [("lstm", 200, 30, 500), ("gru", 85, 30, 1000), ("lstm", 40, 60, 128), ("gru", 30, 70, 64),
-                                        ("lstm", 9, 3, 16), ("gru", 1, 2, 12)])
+                                        ("lstm", 9, 3, 16), ("gru", 1, 2, 12), ("lstm", 40, 30, 1000), ("lstm", 20, 8, 768)])
 def test_birnn_layer_vs_cpu_at_size(ops, precision, kind, T, N, H):
-    """config-2 layer shapes (E: T=200,N=30,H=500; A: T'=85,N=30,H=1000) and multi-group batches."""
+    """config-2 layer shapes (E: T=200,N=30,H=500; A: T'=85,N=30,H=1000), multi-group batches, and LSTM layers wider than 512
+    units (--rnn_type lstm --rnn_size 1000 is legal: AM_training/train.py:46,203-204)."""
     torch.manual_seed(0)
     ref = (nn.LSTM if kind == "lstm" else nn.GRU)(H, H, bidirectional=True, bias=False)
     x = R(T, N, H, seed=1) * 0.5
@@ -300,7 +295,7 @@ def test_bptt_kernel_variants_agree(ops, variant):
 
 
 @pytest.mark.parametrize("M,N,K", [(6000, 4000, 500), (300, 520, 96), (333, 77, 100), (1, 5, 32), (2000, 500, 6016), (129, 257, 1056)])
-def test_gemm_planes_vs_fp64(ops, M, N, K):
+def test_gemm_planes_vs_fp64(ops, M, N, K, fast_mode):
     """aas_gemm_planes (pre-split operands, LDS-DMA staging; 256x256, 128x128 and split-K paths) against fp64, with
     bias / addend / accumulate; the split is exact to 2^-18 per element."""
     A, B = R(M, K, seed=5).cuda(), R(N, K, seed=6).cuda()
@@ -320,7 +315,7 @@ def test_gemm_planes_vs_fp64(ops, M, N, K):
 
 
 @pytest.mark.parametrize("T,Nb,GH,I,H", [(37, 6, 104, 80, 24), (50, 60, 2000, 500, 500), (9, 3, 40, 72, 8)])
-def test_gemm_planes_tn_vs_fp64(ops, T, Nb, GH, I, H):
+def test_gemm_planes_tn_vs_fp64(ops, T, Nb, GH, I, H, fast_mode):
     """aas_gemm_planes_tn: the weight-gradient products from ROW-MAJOR planes (transposing LDS reads): both directions of
     dW_ih in one problem (result rows split over two tensors), dW_hh per direction with its time shift and a column base in
     the middle of a 32-column block, utterance classes with their own device-scalar alpha, K not a multiple of 32, poisoned
@@ -374,7 +369,7 @@ def test_gemm_planes_tn_vs_fp64(ops, T, Nb, GH, I, H):
     ops.lib().aas_set_debug_flags(0)
 
 
-def test_split_planes_transposed(ops):
+def test_split_planes_transposed(ops, fast_mode):
     """aas_split_planes_t: time-major [T*nb, C] -> planes[c][t*nbp + n] with per-utterance weights and zero pads; used as
     both operands of a weight-gradient product dW = (rs * dg)^T x."""
     T, nb, C1, C2 = 9, 30, 200, 72
@@ -459,7 +454,7 @@ def test_lmfb_vs_numpy(ops):
     assert rel_err(f40, lmfb_np.lmfb(wave[0, :1000], n_mels=40)[None]) < 1e-3
 
 
-def test_round2_plane_ops(ops):
+def test_round2_plane_ops(ops, fast_mode):
     """Entry points added for the plane-GEMM backward path, each against a float64 restatement: fused direction sum + planes,
     planes -> transposed planes (with per-utterance weights), block-strided transposed split, the multi-problem GEMM."""
     from aas_enhancement_amd._lib import check, lib, ptr, stream
@@ -504,7 +499,7 @@ def test_round2_plane_ops(ops):
 
 
 @pytest.mark.parametrize("kind,T,N,H", [("lstm", 40, 30, 64), ("gru", 35, 30, 100), ("lstm", 200, 30, 500)])
-def test_bptt_plane_output_equals_fp32_output(ops, kind, T, N, H):
+def test_bptt_plane_output_equals_fp32_output(ops, kind, T, N, H, fast_mode):
     """aas_lstm_bwd_planes / aas_gru_bwd_planes: d(gates) written straight as operand planes == split of the fp32 d(gates) the
     plain entry points write (same kernel, same arithmetic, other store form), pads zero."""
     from aas_enhancement_amd._lib import lib, ptr, stream
@@ -592,7 +587,7 @@ def test_batchnorm_split_entry_points_and_adam_tick(ops):
 
 @pytest.mark.parametrize("half_chip", [True, False])
 @pytest.mark.parametrize("kind,T,N,H", [("lstm", 60, 30, 500), ("lstm", 60, 60, 500), ("gru", 40, 30, 1000), ("lstm", 25, 30, 64)])
-def test_xcd_aware_recurrent_launches_are_bit_identical(ops, kind, T, N, H, half_chip):
+def test_xcd_aware_recurrent_launches_are_bit_identical(ops, kind, T, N, H, half_chip, fast_mode):
     """The XCD-aware persistent launches (exchange sets dealt to XCD classes; L2-resident publish stores once the XCC-id
     handshake has verified that a set - or a producer / consumer pair - shares an XCD) against the plain 3-D grid with
     write-through stores (debug bit 262144) and the XCD-aware grid with write-through stores (524288): same bits, no timeout.
@@ -638,7 +633,7 @@ def test_xcd_aware_recurrent_launches_are_bit_identical(ops, kind, T, N, H, half
 
 @pytest.mark.parametrize("kind,T,N,I,H,classes", [("lstm", 48, 30, 500, 500, 1), ("lstm", 40, 60, 500, 500, 2), ("gru", 36, 30, 672, 1000, 1),
                                                   ("lstm", 40, 30, 80, 500, 1)])
-def test_layer_weight_gradients_row_major_path_equals_transposed_path(ops, kind, T, N, I, H, classes):
+def test_layer_weight_gradients_row_major_path_equals_transposed_path(ops, kind, T, N, I, H, classes, fast_mode):
     """A recurrent layer's four weight gradients through aas_gemm_planes_tn (BPTT planes x forward input planes x the forward
     launch's exchange buffer, one launch per utterance class with its device-scalar weight) against the transposed-plane path
     (planes_t + split_rows_t + NT plane GEMM with the weights folded into the transposition) and against fp64."""

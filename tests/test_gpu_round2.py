@@ -25,13 +25,6 @@ def gpu():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[1, 0, 2], ids=["splitbf16", "fp32", "fp32eq"])
-def precision(request, gpu):
-    from aas_enhancement_amd import ops
-    ops.set_precision(request.param)
-    yield request.param
-    ops.set_precision(1)
-
 
 def _fill(m, seed, conv_std=None):
     from aas_enhancement_amd import prng
@@ -146,7 +139,7 @@ def test_am_config5_golden(gpu, precision):
             assert tot ** 0.5 == pytest.approx(float(z["it0.gradnorm_total"]), rel=3e-3)
 
 
-def test_alternating_async_and_sync_steps_match_sync_only(gpu):
+def test_alternating_async_and_sync_steps_match_sync_only(gpu, precision2):
     """FlatAdam's host and device step counters (and kt) must stay in step when train_step_async and train_step
     alternate (Trainer.train does exactly that on logging iterations): same trajectory as synchronous steps only."""
     from aas_enhancement_amd.trainer_AAS import Trainer
@@ -179,7 +172,7 @@ def test_alternating_async_and_sync_steps_match_sync_only(gpu):
         assert rel_err(res["mixed"][1][k], v) < 1e-3, k
 
 
-def test_two_lane_schedule_on_ragged_pair_matches_synchronous_step(gpu):
+def test_two_lane_schedule_on_ragged_pair_matches_synchronous_step(gpu, precision2):
     """Noisy and clean batches of different padded length (what real loaders deliver): train_step_async takes the two-lane
     schedule (E fwd || D(clean) fwd, D(enhanced) || A, E bwd || D(clean) bwd); same trajectory as the synchronous step's
     two-pass branch, which the F1 goldens pin."""
@@ -299,7 +292,7 @@ def test_device_greedy_decode_matches_host(gpu):
     assert a == b
 
 
-def test_validation_pass_matches_oracle(gpu):
+def test_validation_pass_matches_oracle(gpu, precision2):
     """greedy_decoding_and_AAS (trainer_AAS.py:301-351, cer = ce/total_word quirk kept) on the F1 batch vs the same
     quantities from the CPU oracle modules + the reference-pinned host decoder."""
     from aas_enhancement_amd.decoder import GreedyDecoder

@@ -36,7 +36,7 @@ def _free_port():
 
 
 # ------------------------------------------------------------------------------------------------ FSEGAN, device-resident
-def test_fsegan_async_config4_golden(gpu):
+def test_fsegan_async_config4_golden(gpu, precision2):
     """F6 (config 4 at size) through train_step_async + read_scalars: scalars, kt trajectory and enhanced samples of the
     reference-module step, two iterations (the second one sees the kt the device advanced)."""
     from aas_enhancement_amd import ops, prng
@@ -87,7 +87,7 @@ def _tiny_paired(seed, n=4, T=40, lens=None):
     return x, y, mask
 
 
-def test_fsegan_async_and_sync_steps_interchange(gpu):
+def test_fsegan_async_and_sync_steps_interchange(gpu, precision2):
     """async, async, sync, async == sync x 4 (host / device kt and the Adam step counters stay in step), ragged lengths."""
     ref, mix = _tiny_fsegan(), _tiny_fsegan()
     want, got = [], []
@@ -136,7 +136,7 @@ def test_flat_sgd_nesterov_vs_torch(gpu):
     assert opt2.lr == 0.05 and opt2.momentum == 0.9 and torch.equal(opt2.buf, opt.buf)
 
 
-def test_am_trainer_sgd_matches_oracle_step(gpu):
+def test_am_trainer_sgd_matches_oracle_step(gpu, precision2):
     """AMTrainer(optim='sgd') (train.py:172-174: SGD(momentum, nesterov=True)) against the CPU oracle model under torch.optim.SGD."""
     from aas_enhancement_amd import prng
     from aas_enhancement_amd.am_train import AMTrainer
@@ -213,7 +213,7 @@ def _pair_worker(rank, world, port, q, which):
 
 
 @pytest.mark.parametrize("which", ["dce", "fsegan_sync", "fsegan_async"])
-def test_dce_and_fsegan_trainers_dp_two_ranks_equal_single(gpu, which):
+def test_dce_and_fsegan_trainers_dp_two_ranks_equal_single(gpu, which, precision2):
     """2 ranks x 2 utterances (global nElement, SUM all-reduce of the flat gradient buffers, all-reduced kt inputs) == 1 rank x 4."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -299,7 +299,7 @@ def _train_worker(rank, world, port, tmp, q):
         dist.destroy_process_group()
 
 
-def test_train_loop_dp_with_sharding_loader_and_syncbn_across_save_iter(gpu, tmp_path):
+def test_train_loop_dp_with_sharding_loader_and_syncbn_across_save_iter(gpu, tmp_path, precision2):
     """rank 0 alone validates at a save_iter while A stays in train mode; with --sync_bn armed its BatchNorm
     would issue all-reduces no other rank matches.  Two ranks, a loader that shards before loading, sync_bn on, two save_iters
     inside four iterations: the run finishes, only rank 0 writes checkpoints, every rank ends with identical parameters, and
@@ -382,13 +382,6 @@ def test_exact_fp32_flag_kernels_vs_counter_kernels_and_xcd_variants(gpu, kind, 
 
 
 # ------------------------------------------------------------------------------------------------ vanilla `rnn` kind
-@pytest.fixture(params=[1, 0, 2], ids=["splitbf16", "fp32", "fp32eq"])
-def precision(request, gpu):
-    from aas_enhancement_amd import ops
-    ops.set_precision(request.param)
-    yield request.param
-    ops.set_precision(int(os.environ.get("AAS_PRECISION", "0")))
-
 
 @pytest.mark.parametrize("tag", ["s", "m", "l"])
 def test_brnn_vanilla_rnn_golden(gpu, precision, tag):

@@ -1,0 +1,164 @@
+"""GPU parity tests (-m gpu) added in round 4: the acoustic_supervision trainer (no discriminator) against F10 (the reference's
+stackedBRNN / DeepSpeech run through the restated trainer_acoustic.py:120-142 loop by tools/make_goldens.py), the LDS-DMA fp32 GEMM
+and its multi-problem weight-gradient launch against fp64, the hybrid forward schedule against the batched one.
+north_star tolerances: logits / enhanced within 1e-3 relative, losses within 1e-2 relative."""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from tests.helpers import LABELS, batch_from, grad_close, load, load_sd, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+
+REL_OUT, REL_LOSS = 1e-3, 1e-2
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def cfg(**kw):
+    c = types.SimpleNamespace(lr=1e-3, beta1=0.5, beta2=0.999, optimizer="adam", batch_size=4, expnum=0, lambda_k=0.001, gamma=0.5, gpu=0,
+                              load_path="", mode="train", write_log=False, w_adversarial=1.0, w_acoustic=1.0, allow_ASR_update_iter=0,
+                              schedule="fused", nFeat=8, rnn_size=16, rnn_layers=4, rnn_type="lstm")
+    c.__dict__.update(kw)
+    return c
+
+
+def _tiny_models(z):
+    from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
+    G = stackedBRNN(I=8, H=16, L=4)
+    A = DeepSpeech(nn.GRU, LABELS, 12, 3, True, 11, 2, 8, 2, nFreq=8)
+    load_sd(G, sub(z, "tiny.G0."))
+    load_sd(A, sub(z, "tiny.A0."))
+    return G, A
+
+
+@pytest.mark.parametrize("form", ["sync", "async"])
+def test_acoustic_supervision_tiny_golden(gpu, precision, form):
+    """trainer_acoustic.Trainer (E + A, loss = CTC / N, no discriminator anywhere) on F10's tiny ragged batches: iteration 0 at
+    north_star's tolerances incl. sampled gradients; the iterations behind Adam steps at the level its sign flips of
+    noise-level gradient elements allow."""
+    from aas_enhancement_amd.trainer_acoustic import Trainer
+    z = load("f10_acoustic.npz")
+    tr = Trainer(cfg(), None, models=_tiny_models(z))
+    assert not any(True for _ in tr.D.parameters())
+    for it in range(3):
+        ny = batch_from(z, "tiny.it%d.ny." % it)
+        if form == "sync":
+            r = tr.train_step(ny, it)
+            loss = r["l_ctc"]
+        else:
+            r = tr.train_step_async(ny, it)
+            loss = tr.read_scalars()["l_ctc"]
+        p = "tiny.it%d." % it
+        assert loss == pytest.approx(float(z[p + "loss"]), rel=REL_LOSS), it
+        tol = REL_OUT if it == 0 else 1e-2
+        assert rel_err(r["enhanced"], z[p + "enhanced"]) < tol and rel_err(r["prob"], z[p + "logits"]) < tol, it
+        if it == 0:
+            for nm, m in (("G", tr.G), ("A", tr.ASR)):
+                for k, v in m.named_parameters():
+                    if p + "grad.%s.%s" % (nm, k) in z.files:
+                        assert grad_close(v.grad, z[p + "grad.%s.%s" % (nm, k)], rtol=2e-3), (nm, k)
+    from aas_enhancement_amd import ops
+    assert not ops.rnn_timeout_flag()
+
+
+def test_acoustic_supervision_config2_golden(gpu, precision2):
+    """F10 at config-2 size (N=30, T=200, E 4x500 BiLSTM, A 2xconv + 5x1000 BiGRU, weights = F3's) through the device-resident
+    step: losses, sampled enhanced frames / logits, sampled weight gradients and their norms."""
+    from aas_enhancement_amd import prng
+    from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
+    from aas_enhancement_amd.trainer_acoustic import Trainer
+    z = load("f10_acoustic.npz")
+    N, F, T, L, seed = int(z["big.N"]), int(z["big.F"]), int(z["big.T"]), int(z["big.L"]), int(z["big.weight_seed"])
+    G = stackedBRNN(I=F, H=500, L=4)
+    A = DeepSpeech(nn.GRU, LABELS, 1000, 5, True, 11, 2, 128, 2, nFreq=F)
+    for m, s, cs in ((G, seed + 1, None), (A, seed + 3, 0.1)):
+        load_sd(m, {k: torch.from_numpy(v) for k, v in prng.fill_state_dict(m.state_dict(), s, conv_std=cs).items()}, strict=False)
+    tr = Trainer(cfg(lr=float(z["big.lr"]), nFeat=F, rnn_size=500, batch_size=N), None, models=(G, A))
+    for it in range(2):
+        ny = (torch.from_numpy(prng.uniform(123 + 1000 * it, (N, F, T), 0.0, 6.0)),
+              torch.from_numpy(prng.randint(125 + 1000 * it, (N * L,), 1, 28).astype(np.int32)),
+              torch.ones(N), torch.full((N,), L, dtype=torch.int32), torch.zeros(N, 1, T, dtype=torch.uint8))
+        r = tr.train_step_async(ny, it)
+        loss = tr.read_scalars()["l_ctc"]
+        p = "big.it%d." % it
+        assert loss == pytest.approx(float(z[p + "loss"]), rel=REL_LOSS), it
+        enh, prob = r["enhanced"].detach().reshape(-1), r["prob"].detach().reshape(-1)
+        e_ref, p_ref = z[p + "enh_samples"], z[p + "logit_samples"]
+        e_got = enh[torch.from_numpy(z[p + "enh_idx"]).cuda()].cpu().numpy()
+        p_got = prob[torch.from_numpy(z[p + "logit_idx"]).cuda()].cpu().numpy()
+        assert np.abs(e_got - e_ref).max() < REL_OUT * np.abs(e_ref).max(), it
+        assert np.abs(p_got - p_ref).max() < REL_OUT * np.abs(p_ref).max(), it
+        if it == 0:    # (A starts stepping at iteration 1: its gradients are formed from iteration 0 on, as in the reference)
+            for key in [k[len(p + "gradnorm."):] for k in z.files if k.startswith(p + "gradnorm.")]:
+                nm, k = key.split(".", 1)
+                g = dict((tr.G if nm == "G" else tr.ASR).named_parameters())[k].grad
+                got = g.reshape(-1)[torch.from_numpy(z[p + "gradsample_idx." + key]).cuda()].cpu().numpy()
+                want = z[p + "gradsample." + key]
+                gtol = 2e-3 if precision2 == 0 else 1.5e-2     # (the fast mode's 2^-17 products through nine recurrent layers)
+                assert np.abs(got - want).max() < gtol * np.abs(want).max() + 1e-9, key
+                assert float(g.double().pow(2).sum().sqrt()) == pytest.approx(float(z[p + "gradnorm." + key]), rel=gtol), key
+    from aas_enhancement_amd import ops
+    assert not ops.rnn_timeout_flag()
+
+
+@pytest.mark.parametrize("M,N,K", [(6000, 2000, 500), (2000, 500, 6000), (700, 512, 260), (130, 68, 100)])
+def test_lds_dma_gemm_against_register_staged_kernel_and_fp64(gpu, M, N, K):
+    """aas_gemm_f32 in fp32 arithmetic: the LDS-DMA kernel (aas_set_gemm_variant(0), the default) and the register-staged one
+    (variant 1) in all three modes with bias / addend / accumulate, both against fp64 at the fp32 chain's error level."""
+    from aas_enhancement_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(7)
+    a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    bias, add = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = a.double() @ b.double().t()
+    scale = float((a.abs().double() @ b.abs().double().t()).max())
+    A, B, Bt, At = a.cuda(), b.cuda(), b.t().contiguous().cuda(), a.t().contiguous().cuda()
+    try:
+        for variant in (0, 1):
+            L.aas_set_gemm_variant(variant)
+            c = torch.empty(M, N, device="cuda")
+            ops.gemm(ops.NT, M, N, K, A, K, B, K, c, N, bias=bias.cuda(), addend=add.cuda(), ldd=N)
+            assert float((c.double().cpu() - (ref + bias.double() + add.double())).abs().max()) < 4e-7 * scale, (variant, "nt")
+            ops.gemm(ops.NN, M, N, K, A, K, Bt, N, c, N)
+            assert float((c.double().cpu() - ref).abs().max()) < 4e-7 * scale, (variant, "nn")
+            c.fill_(1.0)
+            ops.gemm(ops.TN, M, N, K, At, M, Bt, N, c, N, accumulate=True)
+            assert float((c.double().cpu() - (ref + 1.0)).abs().max()) < 4e-7 * scale, (variant, "tn")
+    finally:
+        L.aas_set_gemm_variant(0)
+
+
+def test_multi_problem_weight_gradient_launch_equals_four_products(gpu):
+    """aas_gemm_f32_multi: the four weight-gradient products of a bidirectional layer (per-problem reduction extents, shared
+    d(gates)) in one launch == four aas_gemm_f32 launches, with and without the workgroup-lifetime cap (extra split-K slabs)."""
+    from aas_enhancement_amd import _lib, ops
+    L = _lib.lib()
+    T, Nb, H = 50, 30, 500
+    GH, R = 4 * H, T * Nb
+    g = torch.Generator().manual_seed(3)
+    dg = torch.randn(R, 2 * GH, generator=g).cuda()
+    x, h = torch.randn(R, H, generator=g).cuda(), torch.randn(2 * R, H, generator=g).cuda()
+    Rm = (T - 1) * Nb
+    want = [dg[:, :GH].double().t() @ x.double(), dg[:, GH:].double().t() @ x.double(),
+            dg[Nb:, :GH].double().t() @ h[:Rm].double(), dg[:Rm, GH:].double().t() @ h[R + Nb:].double()]
+    a0, b0, bh = dg.data_ptr(), x.data_ptr(), h.data_ptr()
+    As = [a0, a0 + 4 * GH, a0 + 4 * Nb * 2 * GH, a0 + 4 * GH]
+    Bs = [b0, b0, bh, bh + 4 * (R + Nb) * H]
+    try:
+        for cap in (0, 16):
+            L.aas_set_gemm_max_steps(cap)
+            outs = [torch.ones(GH, H, device="cuda") for _ in range(4)]
+            ops.gemm_multi(ops.TN, GH, H, [R, R, Rm, Rm], As, 2 * GH, Bs, H, [o.data_ptr() for o in outs], H, accumulate=True)
+            for o, w in zip(outs, want):
+                assert rel_err(o.double().cpu() - 1.0, w.cpu()) < 2e-5, cap
+    finally:
+        L.aas_set_gemm_max_steps(48)

@@ -42,13 +42,6 @@ def build_tiny(z):
     return G, D, A
 
 
-@pytest.fixture(params=[1, 0, 2], ids=["splitbf16", "fp32", "fp32eq"])
-def precision(request, gpu):
-    from aas_enhancement_amd import ops
-    ops.set_precision(request.param)
-    yield request.param
-    ops.set_precision(1)
-
 
 @pytest.mark.parametrize("schedule", ["fused", "as_executed"])
 def test_aas_step_tiny_golden(gpu, precision, schedule):
@@ -73,7 +66,7 @@ def test_aas_step_tiny_golden(gpu, precision, schedule):
             assert rel_err(v, z["final.%s.%s" % (nm, k)]) < 2e-3, (nm, k)
 
 
-def test_aas_step_graph_replay_tiny(gpu):
+def test_aas_step_graph_replay_tiny(gpu, precision2):
     """hipGraph path (frozen A): the fused iteration captured once and replayed must reproduce the eager fused
     trajectory - scalars, outputs and every parameter (kt, Adam bias corrections and losses live on the device
     between replays).  The eager fused step itself is pinned to the reference goldens above."""
@@ -96,7 +89,7 @@ def test_aas_step_graph_replay_tiny(gpu):
         assert rel_err(res["graph"][1][k], v) < 1e-3, k
 
 
-def test_graph_replay_matches_eager_config2(gpu):
+def test_graph_replay_matches_eager_config2(gpu, precision2):
     """Graph replay vs the eager fused step at BASELINE config-2 sizes, frozen A: identical scalars over 3 steps."""
     from aas_enhancement_amd import prng
     from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
@@ -120,7 +113,7 @@ def test_graph_replay_matches_eager_config2(gpu):
     assert np.allclose(res["eager"], res["graph"], rtol=1e-4), (res["eager"], res["graph"])
 
 
-def test_chain_schedules_agree_config2(gpu, monkeypatch):
+def test_chain_schedules_agree_config2(gpu, monkeypatch, precision2):
     """The three ways of queueing the discriminator and acoustic passes - one after the other on one stream, on two
     streams one chain after the other, and layer by layer in alternation with one combined backward - are the same
     computation: identical scalars, enhanced output and parameters over 2 steps at BASELINE config-2 sizes."""
@@ -154,7 +147,7 @@ def test_chain_schedules_agree_config2(gpu, monkeypatch):
     assert np.allclose(res["serial"], res["alternating"], rtol=2e-5), (res["serial"], res["alternating"])
 
 
-def test_async_steps_match_synchronous_steps(gpu):
+def test_async_steps_match_synchronous_steps(gpu, precision2):
     """Trainer.train_step_async (kt / losses device-resident, no read-back) == Trainer.train_step over 3 steps (tiny shapes)."""
     from aas_enhancement_amd.trainer_AAS import Trainer
     z = load("f1_aas_tiny.npz")
@@ -187,7 +180,7 @@ def test_forward_stages_equal_forward(gpu):
         assert torch.equal(last, m(x))
 
 
-def test_aas_grads_tiny_golden(gpu):
+def test_aas_grads_tiny_golden(gpu, precision2):
     """F1 iteration 0: every parameter gradient of E, D and A at optimiser-step time (as-executed schedule)."""
     from aas_enhancement_amd.ctc import CTCLoss
     from aas_enhancement_amd.model import L1Loss_mask
@@ -214,7 +207,7 @@ def test_aas_grads_tiny_golden(gpu):
             assert grad_close(p.grad, z["it0.grad.%s.%s" % (nm, k)], rtol=2e-3, atol=1e-5), (nm, k)
 
 
-def test_dce_config1_golden(gpu):
+def test_dce_config1_golden(gpu, precision2):
     """F2: BASELINE config 1 (N=4,F=80,T=200,H=128, 4 layers), 5 DCE steps."""
     from aas_enhancement_amd import prng
     from aas_enhancement_amd.model import stackedBRNN
@@ -269,7 +262,7 @@ def test_aas_config2_golden(gpu, precision):
     assert not ops.rnn_timeout_flag()
 
 
-def test_fsegan_golden(gpu):
+def test_fsegan_golden(gpu, precision2):
     from aas_enhancement_amd import prng
     from aas_enhancement_amd.model import stackedBRNN
     from aas_enhancement_amd.trainer_FSEGAN import Trainer
@@ -292,7 +285,7 @@ def test_fsegan_golden(gpu):
                 assert rel_err(v, z["fsegan_%s.final.%s.%s" % (variant, nm, k)]) < 2e-3, (variant, nm, k)
 
 
-def test_am_step_golden(gpu):
+def test_am_step_golden(gpu, precision2):
     """AM_training/train.py:297-349 (config 5's per-GPU step): A(x) -> CTC/N -> plain Adam."""
     from aas_enhancement_amd import prng
     from aas_enhancement_amd.ctc import CTCLoss
@@ -320,7 +313,7 @@ def test_am_step_golden(gpu):
         assert rel_err(v.double(), z["am.final." + k]) < 2e-3, k
 
 
-def test_am_trainer_class_golden(gpu):
+def test_am_trainer_class_golden(gpu, precision2):
     """aas_enhancement_amd.am_train.AMTrainer (flat buffers, fused Adam, side-stream wgrads) on the F5 AM vectors."""
     from aas_enhancement_amd import prng
     from aas_enhancement_amd.am_train import AMTrainer
@@ -340,7 +333,7 @@ def test_am_trainer_class_golden(gpu):
         assert rel_err(v.double(), z["am.final." + k]) < 2e-3, k
 
 
-def test_am_async_steps_equal_synchronous_steps_and_goldens(gpu):
+def test_am_async_steps_equal_synchronous_steps_and_goldens(gpu, precision2):
     """AMTrainer.train_step_async (no host read-back: device step counter, loss through a pinned ring, read one step late) on
     the F5 AM vectors - same losses, logits and final weights as the reference; interleaved with synchronous steps the Adam
     counters stay in step."""

@@ -142,6 +142,40 @@ def test_fsegan_and_am_steps():
         assert rel_err(v.double(), z["am.final." + k]) < 1e-5, k
 
 
+def test_acoustic_supervision_step_tiny_three_iterations():
+    """oracle.ref_step.acoustic_step (trainer_acoustic.py:120-142) vs F10: the reference's stackedBRNN / DeepSpeech run through the
+    restated loop by tools/make_goldens.py (ragged lengths, A stepping from iteration 1)."""
+    z = load("f10_acoustic.npz")
+    G = RM.RefStackedBRNN(8, 8, 16, 4)
+    A = RM.RefDeepSpeech(nn.GRU, LABELS, 12, 3, 11, 2, 8, 2, nFreq=8)
+    load_sd(G, sub(z, "tiny.G0."))
+    load_sd(A, sub(z, "tiny.A0."))
+    cfg = RS.StepConfig(lr=1e-3, allow_ASR_update_iter=0)
+    og, oa = RS.make_optim(G, cfg), RS.make_optim(A, cfg)
+    for it in range(3):
+        ny = batch_from(z, "tiny.it%d.ny." % it)
+        r = RS.acoustic_step(G, A, og, oa, ny, cfg, it)
+        p = "tiny.it%d." % it
+        # iteration 0 is the pure forward / backward: tight.  Later iterations sit behind Adam steps, which turn gradient elements
+        # at rounding-noise level (E only sees the CTC gradient here) into +-lr moves whose sign depends on the GEMM summation
+        # order, i.e. on the thread count of this run against the generator's: compared at that level.
+        tol = 1e-5 if it == 0 else 5e-3
+        assert r["l_ctc"] == pytest.approx(float(z[p + "loss"]), rel=tol)
+        assert rel_err(r["enhanced"], z[p + "enhanced"]) < tol and rel_err(r["logits"], z[p + "logits"]) < tol
+        for nm, m in (("G", G), ("A", A)):
+            for k, v in m.named_parameters():
+                if p + "grad.%s.%s" % (nm, k) in z.files:
+                    assert grad_close(v.grad, z[p + "grad.%s.%s" % (nm, k)], rtol=1e-4 if it == 0 else 2e-2), (it, nm, k)
+    for nm, m in (("G", G), ("A", A)):
+        for k, v in m.state_dict().items():
+            # (E's output bias is a per-feature constant in front of A's first conv + train-mode BatchNorm: its true gradient is
+            #  identically zero in this trainer, what Adam steps on is rounding noise - like A's conv biases)
+            if (nm == "A" and k in NOISE_PARAMS) or (nm == "G" and k == "final_linear.bias") or not v.dtype.is_floating_point:
+                continue
+            d = (v.double() - torch.from_numpy(np.asarray(z["tiny.%s3.%s" % (nm, k)])).double()).abs()
+            assert float(d.max()) <= 3 * 2.1e-3 and float((d > 2e-4).double().mean()) < 2e-2, (nm, k)     # (3 Adam steps of lr 1e-3)
+
+
 def test_ctc_numpy_vs_bruteforce_and_torch():
     rng = np.random.RandomState(0)
     for T, C, labels in [(4, 3, [1, 2]), (5, 3, [1, 1]), (3, 4, [2]), (4, 3, []), (5, 4, [1, 2, 1]), (2, 3, [1, 1])]:
