@@ -138,7 +138,7 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
     unsigned long long local = 0ull;    // bit c: consumer slice c shares this workgroup's XCD
     if (p.xcd) {
         unsigned* tab = p.xchg + (int64_t)4 * p.N * p.P * p.P * U;   // behind the ring, poisoned by the same memset
-        local = xcd_peer_mask(tab, xset, pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag);
+        local = xcd_peer_mask(tab, xset, pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag, p.sync + XSTAT_WORD + 4 * (MODE == LSTM_BWD ? 1 : 3));
         if (p.flags & 524288) local = 0ull;
     }
     // zero both A tiles once: pad rows / pad gate columns stay zero for the whole launch

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
     bool plain = false;   // plain (L2-resident) publish stores once the set is verified to share an XCD
     if (p.xcd) {
         unsigned* tab = xq + (int64_t)2 * T * N * KC * 32;
-        plain = xcd_set_colocated(tab, xset, pslice, p.P, err, p.tag, &xcd_flag) && !(p.flags & 524288) && p.xcd == 1;
+        plain = xcd_set_colocated(tab, xset, pslice, p.P, err, p.tag, &xcd_flag, p.sync + XSTAT_WORD + 4 * (MODE == LSTM_FWD ? 0 : 2)) && !(p.flags & 524288) && p.xcd == 1;
     }
 
     // gate-math role: one (row, unit) per thread

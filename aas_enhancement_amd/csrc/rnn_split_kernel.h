@@ -108,8 +108,12 @@ template <bool EX> __device__ __forceinline__ constexpr int elem_word(int k) { r
 constexpr int XCD_TAB_BYTES = 32 * 64 * 4;   // up to 32 sets x 64 slices
 
 // -> bit c set: slice c of this workgroup's set runs on the same XCD as this workgroup (0: unknown - table read timed out)
+// Placement statistics (diagnostics: tools/xcd_stats.py): per launch class four words behind the phase stamps of the sync buffer -
+// workgroups that looked, workgroups whose whole set shares their XCD, co-located peers, peers.
+constexpr int XSTAT_WORD = 1060;   // + 4 * class (0 LSTM forward, 1 LSTM BPTT, 2 GRU forward, 3 GRU BPTT)
+
 __device__ __forceinline__ unsigned long long xcd_peer_mask(unsigned* tab, int set, int pslice, int P, unsigned* err, int tag,
-                                                            unsigned long long* lds_word) {
+                                                            unsigned long long* lds_word, unsigned* stat = nullptr) {
     const int tid = threadIdx.x;
     if (tid < 64) {
         unsigned xcc;
@@ -133,6 +137,12 @@ __device__ __forceinline__ unsigned long long xcd_peer_mask(unsigned* tab, int s
         }
         const unsigned long long m = __ballot(tid < P && v == xcc);
         if (tid == 0) *lds_word = ok ? m : 0ull;
+        if (tid == 0 && stat) {
+            atomicAdd(stat + 0, 1u);
+            atomicAdd(stat + 1, (ok && m == (P >= 64 ? ~0ull : ((1ull << P) - 1ull))) ? 1u : 0u);
+            atomicAdd(stat + 2, ok ? (unsigned)__popcll(m) : 0u);
+            atomicAdd(stat + 3, (unsigned)P);
+        }
     }
     __syncthreads();
     const unsigned long long r = *lds_word;
@@ -140,9 +150,10 @@ __device__ __forceinline__ unsigned long long xcd_peer_mask(unsigned* tab, int s
     return r;
 }
 
-__device__ __forceinline__ bool xcd_set_colocated(unsigned* tab, int set, int pslice, int P, unsigned* err, int tag, unsigned long long* lds_word) {
+__device__ __forceinline__ bool xcd_set_colocated(unsigned* tab, int set, int pslice, int P, unsigned* err, int tag, unsigned long long* lds_word,
+                                                  unsigned* stat = nullptr) {
     const unsigned long long all = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
-    return xcd_peer_mask(tab, set, pslice, P, err, tag, lds_word) == all;
+    return xcd_peer_mask(tab, set, pslice, P, err, tag, lds_word, stat) == all;
 }
 
 // MODE, MT = 16-row batch tiles per workgroup, KS = 32-wide k chunks per wave
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     bool plain = false;   // plain (L2-resident) publish stores once the set is verified to share an XCD (xcd_set_colocated)
     if (FWD && p.xcd) {
         unsigned* tab = p.xchg + xrows * KC * 32;          // behind the exchange rows, poisoned by the same memset
-        plain = xcd_set_colocated(tab, xset, pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag) && !(p.flags & 524288);
+        plain = xcd_set_colocated(tab, xset, pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag, p.sync + XSTAT_WORD + 4 * (LSTM ? 0 : 2)) && !(p.flags & 524288);
     }
     for (int s = 0; s < T; ++s) {
         unsigned long long st0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull, st1 = st0, st2 = st0, st3 = st0;

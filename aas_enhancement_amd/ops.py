@@ -151,6 +151,41 @@ _wgrad_streams = {}
 _chain_streams = {}
 
 
+_lane_streams = {}
+_hip_rt = [None]
+
+
+def lane_stream(half, dev=None):
+    """A HIP stream whose kernels run on ONE HALF of the CUs only (hipExtStreamCreateWithCUMask): bits 0..127 of the mask select 16
+    CUs on each of the 8 XCDs, bits 128..255 the other 16 (tools/probe/cumask.cpp), so round-robin workgroup placement over the XCDs
+    - what the XCD-aware recurrent launches count on - is unchanged.  Two chains of persistent recurrent launches on the two lanes
+    cannot take each other's CUs: a persistent launch becomes resident only when all its workgroups find a CU, and an unmasked GEMM of
+    the OTHER chain, dealt over every free CU, made it wait for that GEMM's end (the 1000-unit GRU forward launches of the acoustic
+    chain: 1.10 ms beside the discriminator's projections, 0.78 alone).  half: 0 = low CU half, 1 = high."""
+    import ctypes
+    if dev is None:
+        dev = torch.cuda.current_device()
+    dev = torch.device("cuda", dev) if isinstance(dev, int) else dev
+    key = (dev, int(half))
+    st = _lane_streams.get(key)
+    if st is None:
+        if _hip_rt[0] is None:
+            _hip_rt[0] = ctypes.CDLL("libamdhip64.so")
+        words = (device_cus() + 31) // 32
+        lo = words // 2
+        mask = (ctypes.c_uint32 * words)(*[(0xFFFFFFFF if ((i < lo) == (half == 0)) else 0) for i in range(words)])
+        h = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = _hip_rt[0].hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+        if rc != 0 or not h.value:
+            raise RuntimeError("hipExtStreamCreateWithCUMask failed (rc=%d)" % rc)
+        st = _lane_streams[key] = torch.cuda.ExternalStream(h.value, device=dev)
+    return st
+
+
+CHAIN_LANES = [os.environ.get("AAS_CHAIN_LANES", "0") == "1"]   # the two chains of the AAS step on CU-masked lane streams
+
+
 def chain_stream(dev=None):
     """THE second stream for a chain of persistent recurrent launches, one per device and process: every trainer shares it.
     (Streams are multiplexed onto four hardware queues; a second trainer with a side stream of its own made five busy streams
@@ -158,6 +193,8 @@ def chain_stream(dev=None):
     if dev is None:
         dev = torch.cuda.current_device()
     dev = torch.device("cuda", dev) if isinstance(dev, int) else dev
+    if CHAIN_LANES[0]:
+        return lane_stream(1, dev)
     s = _chain_streams.get(dev)
     if s is None:
         prio = 0
@@ -172,6 +209,19 @@ def chain_stream(dev=None):
 
 def wgrad_stream(dev):
     s = _wgrad_streams.get(dev)
+    if s is None and os.environ.get("AAS_WGRAD_LANE", "") in ("0", "1"):
+        # (experiment: the weight-gradient products confined to one CU half - a masked stream of its own)
+        import ctypes
+        if _hip_rt[0] is None:
+            _hip_rt[0] = ctypes.CDLL("libamdhip64.so")
+        half = int(os.environ["AAS_WGRAD_LANE"])
+        words = (device_cus() + 31) // 32
+        mask = (ctypes.c_uint32 * words)(*[(0xFFFFFFFF if ((i < words // 2) == (half == 0)) else 0) for i in range(words)])
+        h = ctypes.c_void_p()
+        rc = _hip_rt[0].hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+        if rc != 0:
+            raise RuntimeError("hipExtStreamCreateWithCUMask failed (rc=%d)" % rc)
+        s = _wgrad_streams[dev] = torch.cuda.ExternalStream(h.value, device=dev)
     if s is None:
         # lowest priority: when a persistent recurrent launch and queued weight-gradient blocks compete for CUs, the
         # recurrent grid (which must become fully resident) is dispatched first

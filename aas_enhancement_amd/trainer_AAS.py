@@ -767,38 +767,55 @@ class Trainer(object):
         losses lets the engine pop backward nodes in reverse creation order, i.e. alternating between the chains, each
         on the stream its forward ran on.  Returns (l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a)."""
         c = self.config
-        main = torch.cuda.current_stream()
+        caller = torch.cuda.current_stream()
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = ops.chain_stream()
         side = self._side = self._side_stream
-        side.wait_stream(main)
+        side.wait_stream(caller)
+        # CU-masked lanes (ops.lane_stream): the discriminator chain on the low CU half, the acoustic chain (side) on the high half
+        main = ops.lane_stream(0, leaf.device) if ops.CHAIN_LANES[0] else caller
+        if main is not caller:
+            main.wait_stream(caller)
         Nn = leaf.size(0)
         leaf_a = enhanced.detach().requires_grad_(True)
         enhanced.record_stream(side)
-        gD = self.D.forward_stages(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
+        with torch.cuda.stream(main):
+            if main is not caller:
+                for t_ in (enhanced, leaf, cl_inputs, rs):
+                    t_.record_stream(main)
+            gD = self.D.forward_stages(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
         gA = self.ASR.forward_stages(leaf_a)
         ae = out_a = None
         while ae is None or out_a is None:
             if ae is None:
-                ae = next(gD)
+                with torch.cuda.stream(main):
+                    ae = next(gD)
             if out_a is None:
                 with torch.cuda.stream(side):
                     out_a = next(gA)
-        if mask is not None:   # eager path: masked-L1 modules (host-side n_valid)
-            l_adv_ny_G, _ = self.diffLoss(ae[:Nn], leaf, mask)
-            l_adv_cl, _ = self.diffLoss(ae[Nn:], cl_inputs, cl_mask)
-            l_adv_ny_G = l_adv_ny_G * c.w_adversarial
-            l_adv_cl = c.w_adversarial * l_adv_cl
-        else:   # device path: (weight / normaliser) per loss as python floats or device scalars (data parallel)
-            l_adv_ny_G = ops.l1_sum(ae[:Nn], leaf) * scales[0]
-            l_adv_cl = ops.l1_sum(ae[Nn:], cl_inputs) * scales[1]
+        with torch.cuda.stream(main):
+            if mask is not None:   # eager path: masked-L1 modules (host-side n_valid)
+                l_adv_ny_G, _ = self.diffLoss(ae[:Nn], leaf, mask)
+                l_adv_cl, _ = self.diffLoss(ae[Nn:], cl_inputs, cl_mask)
+                l_adv_ny_G = l_adv_ny_G * c.w_adversarial
+                l_adv_cl = c.w_adversarial * l_adv_cl
+            else:   # device path: (weight / normaliser) per loss as python floats or device scalars (data parallel)
+                l_adv_ny_G = ops.l1_sum(ae[:Nn], leaf) * scales[0]
+                l_adv_cl = ops.l1_sum(ae[Nn:], cl_inputs) * scales[1]
+            l_pair = l_adv_ny_G + l_adv_cl
         with torch.cuda.stream(side):
             prob = out_a.transpose(0, 1)
             if targets is None:
                 l_CTC = ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) * scales[2]
             else:
                 l_CTC = c.w_acoustic * self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / N_glob
-        self._backward_pair(l_adv_ny_G + l_adv_cl, l_CTC, main, side)
+        with torch.cuda.stream(main):
+            self._backward_pair(l_pair, l_CTC, main, side)
+        if main is not caller:
+            caller.wait_stream(main)
+            for t_ in (leaf.grad, l_adv_ny_G, l_adv_cl, ae):
+                if t_ is not None:
+                    t_.record_stream(caller)
         return l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a
 
     def _backward_pair(self, loss_main, loss_side, main, side):
