@@ -29,36 +29,37 @@ def collect(d, counter):
     return per
 
 
-# launch classes of bench.py's roofline object (ops.Profiler names) -> kernel-name prefixes of either arithmetic mode
-# (persistent grids: P x Q x 2 x threads; the same kernel at two batch sizes has the same grid here, so one entry serves both)
+# launch classes of bench.py's roofline object (ops.Profiler names) -> kernel-name prefixes, per arithmetic mode and kernel
+# generation.  A class takes EVERY kernel one of its prefixes matches (template variants of one kernel: tile heights, wave
+# counts); the first prefix group that matches anything wins (newer kernels first).  bytes per launch = dispatch-weighted mean.
 CLASS_PATTERNS = {
-    "lstm_bwd[N=60,H=500]": "rnn_bwd_rs_kernel<1, ", "lstm_bwd[N=30,H=500]": ("rnn_bwd_rs_kernel<1, 32, 4, -1, true, true>", "rnn_bwd_rs_kernel<1, "), "gru_bwd[N=30,H=1000]": "rnn_bwd_rs_kernel<3, ",
-    "lstm_fwd[N=60,H=500]": "rnn_fwd32_kernel<0, ", "lstm_fwd[N=30,H=500]": "rnn_split_kernel<0, ", "gru_fwd[N=30,H=1000]": "rnn_fwd32_kernel<2, ",
-    "gemm_planes_wgrad": "gemm_planes_tn_kernel<", "gemm_planes": "gemm_planes_kernel<256, 256",
-    "gemm_tn": "gemm_f32_kernel<false, false", "gemm_nn": "gemm_f32_kernel<true, false", "gemm_nt": "gemm_f32_kernel<true, true"}
+    "lstm_bwd[N=60,H=500]": (("rnn_bwd_rs_kernel<1, 32, 4, -1, true, false,", "rnn_bwd_rs_kernel<1, 32, 4, -1, false, false, true"), ("rnn_bwd_rs_kernel<1, ",)),
+    "lstm_bwd[N=30,H=500]": (("rnn_bwd_rs_kernel<1, 32, 4, -1, true, true,",), ("rnn_bwd_rs_kernel<1, ",)),
+    "gru_bwd[N=30,H=1000]": (("rnn_bwd_rs_kernel<3, ",),),
+    "lstm_fwd[N=60,H=500]": (("rnn_fwd32_kernel<0, ",),), "lstm_fwd[N=30,H=500]": (("rnn_split_kernel<0, ",),), "gru_fwd[N=30,H=1000]": (("rnn_fwd32_kernel<2, ",),),
+    "gemm_planes_wgrad": (("gemm_planes_tn_kernel<",),), "gemm_planes": (("gemm_planes_kernel<256, 256",),),
+    "gemm_tn": (("gemm32_kernel<false, false",), ("gemm_f32_kernel<false, false",)),
+    "gemm_nn": (("gemm32_kernel<true, false",), ("gemm_f32_kernel<true, false",)),
+    "gemm_nt": (("gemm32_kernel<true, true",), ("gemm_f32_kernel<true, true",)),
+    "gemm_splitk_reduce": (("gemm32_reduce_kernel",),)}
 
 
 def classes_of(kernels):
     by_class = {}
-    for cname, pats in CLASS_PATTERNS.items():
-        hit = []
-        for pat in ((pats,) if isinstance(pats, str) else pats):      # (a tuple: the first pattern that matches anything wins)
-            hit = [(k, v) for k, v in kernels.items() if k.startswith(pat)]
+    for cname, groups in CLASS_PATTERNS.items():
+        for pats in groups:
+            hit = [(k, v) for k, v in kernels.items() if any(k.startswith(p_) for p_ in pats)]
             if hit:
+                n = sum(v["dispatches"] for _, v in hit)
+                mean = lambda key: sum(v[key] * v["dispatches"] for _, v in hit) / max(n, 1)
+                by_class[cname] = {"FETCH_SIZE_KiB_avg": mean("FETCH_SIZE_KiB_avg"), "WRITE_SIZE_KiB_avg": mean("WRITE_SIZE_KiB_avg"), "dispatches": n,
+                                   "hbm_bytes_per_launch": mean("hbm_bytes_per_launch"), "kernels": sorted(k for k, _ in hit)}
                 break
-        if hit:
-            k, v = max(hit, key=lambda kv: kv[1]["dispatches"])
-            by_class[cname] = dict(v, kernel=k)
     return by_class
 
 
-def main():
-    if sys.argv[1] == "--rebuild":      # recompute by_class of an existing summary (kernel names changed, same raw numbers)
-        j = json.load(open(sys.argv[2]))
-        j["by_class"] = classes_of(j["kernels"])
-        json.dump(j, open(sys.argv[2], "w"), indent=1)
-        return
-    fdir, wdir, out, cmd = sys.argv[1:5]
+def summarise(fdir, wdir, cmd, steps=0):
+    """-> the summary dict of one FETCH_SIZE and one WRITE_SIZE pass (directories of rocprofv3 csv output)."""
     fe, wr = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
     kernels = {}
     for name in sorted(set(fe) | set(wr)):
@@ -68,13 +69,23 @@ def main():
         wa = sum(w) / len(w) if w else 0.0
         kernels[name] = {"FETCH_SIZE_KiB_avg": fa, "WRITE_SIZE_KiB_avg": wa, "dispatches": max(len(f), len(w)),
                          "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
-    by_class = classes_of(kernels)
     total = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in kernels.values())
-    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-    json.dump({"total_hbm_bytes": total, "steps_in_run": steps, "hbm_bytes_per_step": (total / steps) if steps else None, "by_class": by_class, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `%s`" % cmd,
-               "units": "KiB per dispatch; fetched bytes = 2 x FETCH_SIZE x 1024 (gfx950 wide-read correction), written bytes = WRITE_SIZE x 1024",
-               "kernels": kernels}, open(out, "w"), indent=1)
-    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
+    return {"total_hbm_bytes": total, "steps_in_run": steps, "hbm_bytes_per_step": (total / steps) if steps else None, "by_class": classes_of(kernels),
+            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `%s`" % cmd,
+            "units": "KiB per dispatch; fetched bytes = 2 x FETCH_SIZE x 1024 (gfx950 wide-read correction), written bytes = WRITE_SIZE x 1024",
+            "kernels": kernels}
+
+
+def main():
+    if sys.argv[1] == "--rebuild":      # recompute by_class of an existing summary (kernel names changed, same raw numbers)
+        j = json.load(open(sys.argv[2]))
+        j["by_class"] = classes_of(j["kernels"])
+        json.dump(j, open(sys.argv[2], "w"), indent=1)
+        return
+    fdir, wdir, out, cmd = sys.argv[1:5]
+    j = summarise(fdir, wdir, cmd, int(sys.argv[5]) if len(sys.argv) > 5 else 0)
+    json.dump(j, open(out, "w"), indent=1)
+    for k, v in sorted(j["kernels"].items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
         print("%-60s x%-4d %8.1f MB / launch" % (k[:60], v["dispatches"], v["hbm_bytes_per_launch"] / 1e6))
 
 
