@@ -43,6 +43,7 @@ def _bwd_cus():
 
 class AMTrainer(object):
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), dp=None, labels=None, sync_bn=False, optim="adam", momentum=0.9):
+        self.precision = ops.get_precision()   # the arithmetic this trainer runs in (ops.precision)
         self.model = model
         self.criterion = CTCLoss()
         ops.name_layers(model, "A")
@@ -61,6 +62,7 @@ class AMTrainer(object):
         self.losses = AverageMeter()
 
     # ---- one step (:297-349) -----------------------------------------------------------------------------------
+    @ops.with_trainer_precision
     def train_step(self, data_list):
         inputs, targets, input_percentages, target_sizes = data_list[0], data_list[1], data_list[2], data_list[3]
         inputs = _get_variable_nograd(inputs)
@@ -101,6 +103,7 @@ class AMTrainer(object):
         return dict(loss=0.0 if is_inf else loss_value, is_inf=is_inf, logits=out)
 
     # ---- the same step without a host synchronisation -----------------------------------------------------------
+    @ops.with_trainer_precision
     def train_step_async(self, data_list):
         """train_step queued WITHOUT reading the loss back: the Adam bias corrections come from a device step counter
         (`FlatAdam.step_dev`) and the (all-reduced) loss goes to a pinned host buffer asynchronously.  `read_loss(handle)`
@@ -163,6 +166,7 @@ class AMTrainer(object):
 
     # ---- validation (:357-399) ---------------------------------------------------------------------------------
     @torch.no_grad()
+    @ops.with_trainer_precision
     def validate(self, batches, transcript_prob=0.0):
         """Greedy-decode WER / CER in percent, averaged over utterances (each utterance's edit distance divided by its own
         reference length, as the reference does); the model runs in eval mode (running-statistics BatchNorm, softmax)."""

@@ -127,6 +127,36 @@ class DPContext(object):
             return _Done()
         return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
+    def broadcast_(self, tensor, src=0):
+        """In-place broadcast from rank `src` (module buffers that only one rank advanced: A's BatchNorm running statistics behind
+        a rank-0-only validation pass)."""
+        if not self.active or self.world == 1:
+            return tensor
+        if self._staged(tensor):
+            host = tensor.detach().cpu()
+            dist.broadcast(host, src=src, group=self.group)
+            tensor.copy_(host)
+        else:
+            dist.broadcast(tensor, src=src, group=self.group)
+        return tensor
+
+    def broadcast_buffers(self, module, src=0):
+        """Every registered buffer of `module` from rank `src`: one flat float broadcast + one for the integer counters."""
+        if not self.active or self.world == 1:
+            return
+        fl = [b for b in module.buffers() if b.dtype.is_floating_point]
+        it = [b for b in module.buffers() if not b.dtype.is_floating_point]
+        for group in (fl, it):
+            if not group:
+                continue
+            flat = torch.cat([b.detach().reshape(-1).to(group[0].dtype) for b in group])
+            self.broadcast_(flat, src)
+            off = 0
+            for b in group:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view_as(b))
+                off += n
+
     def reduce_scalars(self, tensor):
         if self.active:
             if self._staged(tensor):

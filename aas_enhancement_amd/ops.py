@@ -122,6 +122,38 @@ def get_precision():
     return _precision[0]
 
 
+class precision(object):
+    """`with ops.precision(mode):` - the arithmetic mode of everything queued inside the block, the previous mode back on exit (the
+    library reads the mode when a launch is queued).  The trainers wrap their step / validation entry points in it with the mode they
+    were built for (`Trainer.precision`), so two trainers of different modes in one process, or a caller that flips the process-wide
+    setting in between, cannot run a step in the wrong arithmetic.  mode None: leave the current setting alone."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _precision[0]
+        if self.mode is not None and int(self.mode) != self.prev:
+            set_precision(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        if _precision[0] != self.prev:
+            set_precision(self.prev)
+        return False
+
+
+def with_trainer_precision(fn):
+    """Decorator for trainer methods: run under `ops.precision(self.precision)`."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with precision(getattr(self, "precision", None)):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 def set_rnn_cu_limit(cus):
     """Cap the CUs of every persistent recurrent launch queued from now on (0 = whole device)."""
     check(lib().aas_set_rnn_cu_limit(int(cus)), "aas_set_rnn_cu_limit")

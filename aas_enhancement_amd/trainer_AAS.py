@@ -87,10 +87,22 @@ class Trainer(object):
         self._opts = None
         self._flat = None
         self.dp = None
+        # the arithmetic this trainer runs in: the library's setting when it is built (config.precision / AAS_PRECISION / fp32);
+        # every step and validation entry point runs under ops.precision(self.precision); set_precision() switches it
+        self.precision = ops.get_precision()
         # a parameter of D is used from two streams when the step switches schedules: autograd synchronises the accumulation
         # correctly and says so once per process; the notice is not actionable here
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
+    def set_precision(self, mode):
+        """Switch this trainer to another arithmetic mode (0 fp32 / 1 split-bf16 / 2 fp32-equivalent) and bring the cached weight
+        operand planes of its networks up to date for it, off the critical path."""
+        self.precision = int(mode)
+        with ops.precision(self.precision):
+            for net in (self.G, self.D, self.ASR):
+                if any(True for _ in net.parameters()):
+                    ops.refresh_weight_planes(net)
 
     def build_model(self):
         print("initialize enhancement & discriminator model")
@@ -173,6 +185,7 @@ class Trainer(object):
             attach_n_valid(mask)
         return (_get_variable_nograd(inputs), targets, pct, target_sizes, _get_variable_nograd(mask))
 
+    @ops.with_trainer_precision
     def train_step(self, data_list, data_list_cl, iter, log_norms=True):
         """One iteration of :131-194.  Returns the host scalars the reference logs.
         Data parallel (world > 1): `data_list*` are this rank's shards; losses are normalised by the
@@ -587,6 +600,7 @@ class Trainer(object):
             self._kt_dev.fill_(float(self.kt))
             self._kt_dev_live = False   # the host copy is the current one until a device-resident step has run
 
+    @ops.with_trainer_precision
     def train_step_async(self, data_list, data_list_cl, iter):
         """The fused iteration queued WITHOUT any host synchronisation: kt, the Adam bias corrections and the loss scalars
         stay on the device (`_device_core`, the same launch sequence the graph path captures), the CTC metadata goes up
@@ -659,6 +673,7 @@ class Trainer(object):
         bal = self.gamma * l_adv_cl - l_adv_ny_G
         return dict(l_adv_ny_G=l_adv_ny_G, l_adv_cl=l_adv_cl, l_ctc=l_ctc, kt=kt, conv_measure=l_adv_cl + abs(bal))
 
+    @ops.with_trainer_precision
     def train_step_graph(self, data_list, data_list_cl, iter):
         """Graph-replayed fused iteration (single GPU, no gradient-norm logging).  Falls back to train_step when the
         configuration needs host decisions inside the step."""
@@ -948,8 +963,12 @@ class Trainer(object):
                         ops.SYNC_BN[0] = armed
                 if self.dp.active:
                     self.dp.barrier()   # host-side (gloo side group): no pending RCCL work while rank 0 validates, however long
+                    # A stays in train mode during validation (as in the reference), so rank 0's BatchNorm running statistics moved
+                    # while the other ranks' did not: hand every rank rank 0's buffers - the ranks are replicas again, buffers included
+                    self.dp.broadcast_buffers(self.ASR, src=0)
 
     # ---- validation + checkpoint lifecycle (:215-297) -----------------------------------------
+    @ops.with_trainer_precision
     def validate_and_checkpoint(self, iter):
         c = self.config
         self.G.eval()
@@ -987,6 +1006,7 @@ class Trainer(object):
                 copyfile(cur, "{}/{}_valmin_{}.pth".format(self.model_dir, tag, iter))
             self.valmin_iter = iter
 
+    @ops.with_trainer_precision
     def greedy_decoding_and_AAS(self, inputs, targets, input_percentages, target_sizes, mask, transcript_prob=0.001):
         """:301-351 (keeps the reference's ``cer = ce/total_word`` quirk at :338)."""
         inputs = _get_variable_volatile(inputs)

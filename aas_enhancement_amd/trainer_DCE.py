@@ -10,6 +10,7 @@ from .utils import AverageMeter, _get_variable_nograd, attach_n_valid
 
 class Trainer(object):
     def __init__(self, config, data_loader=None, models=None):
+        self.precision = ops.get_precision()   # the arithmetic this trainer runs in (ops.precision)
         self.config, self.data_loader = config, data_loader
         self.lr, self.beta1, self.beta2 = config.lr, config.beta1, config.beta2
         self.diffLoss = L1Loss_mask()
@@ -46,6 +47,7 @@ class Trainer(object):
         self._reducer = BucketReducer(self.dp, [self._flat]) if self.dp.active else None
         return self._opt
 
+    @ops.with_trainer_precision
     def train_step(self, data_list, iter=0):
         """:116-127; data_list = (inputs, cleans, mask, ...) (_collate_fn_paired order).  Data parallel: `data_list` is this
         rank's shard, the loss is normalised by the GLOBAL nElement and the flat gradient buffer is SUM-all-reduced bucket by

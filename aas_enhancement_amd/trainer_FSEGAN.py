@@ -17,6 +17,7 @@ from .utils import AverageMeter, _get_variable_nograd, attach_n_valid
 
 class Trainer(object):
     def __init__(self, config, data_loader=None, models=None):
+        self.precision = ops.get_precision()   # the arithmetic this trainer runs in (ops.precision)
         self.config, self.data_loader = config, data_loader
         self.lr, self.beta1, self.beta2 = config.lr, config.beta1, config.beta2
         self.diffLoss = L1Loss_mask()
@@ -106,6 +107,7 @@ class Trainer(object):
         enhanced.backward(leaf.grad)
         return enhanced, l_adv_ny_G, l_adv_cl, dce
 
+    @ops.with_trainer_precision
     def train_step(self, data_list, iter=0):
         """:128-182 (intended semantics), host-synchronous: returns the scalars of the log lines (and the gradient
         norm of G).  Data parallel: `data_list` is this rank's shard; the losses are normalised by the GLOBAL nElement, so the
@@ -153,6 +155,7 @@ class Trainer(object):
                     conv_measure=l_adv_cl_data + abs(g_d_balance), g_norm=g_norm, enhanced=enhanced)
 
     # ---- the same step without a host synchronisation (what train() queues on iterations that print nothing) -----------
+    @ops.with_trainer_precision
     def train_step_async(self, data_list, iter=0):
         """train_step queued WITHOUT reading anything back: kt, the Adam bias corrections, the loss scalars and the running DCE
         average of the log line stay on the device (`aas_began_step`, `FlatAdam.step_dev`), so the host queues step i+1 while

@@ -82,6 +82,7 @@ class Trainer(_AASTrainer):
             ops.WGRAD_HOOK[0] = None
         return enhanced, prob, l_CTC, asr_steps
 
+    @ops.with_trainer_precision
     def train_step(self, data_list, iter):
         """Synchronous form: returns the host scalars the reference logs (:139-147)."""
         if self._opts is None:
@@ -105,6 +106,7 @@ class Trainer(_AASTrainer):
         self.ctc_tr_local.update(l_ctc, n_glob)
         return dict(l_ctc=l_ctc, enhanced=enhanced, prob=prob)
 
+    @ops.with_trainer_precision
     def train_step_async(self, data_list, iter):
         """The same iteration without a host synchronisation: the loss and the running CTC average stay on the device;
         `read_scalars()` fetches them when a log line needs them."""
@@ -187,7 +189,9 @@ class Trainer(_AASTrainer):
                         ops.SYNC_BN[0] = armed
                 if self.dp.active:
                     self.dp.barrier()
+                    self.dp.broadcast_buffers(self.ASR, src=0)      # (rank 0's validation moved A's BatchNorm running statistics)
 
+    @ops.with_trainer_precision
     def greedy_decoding_and_AAS(self, inputs, targets, input_percentages, target_sizes, mask, transcript_prob=0.001):
         """Validation pass of trainer_acoustic.py:203-245: CTC and WER / CER only (the adversarial entries read 0)."""
         import random

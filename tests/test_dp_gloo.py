@@ -247,3 +247,70 @@ def test_main_initialises_process_group_and_shards(tmp_path):
     for x, pct in ((x0, res[0][3]), (x1, res[1][3])):
         for row, pc in zip(x, pct):
             assert int(round(float(pc) * t_glob)) == lens[int(row[0, 0])]
+
+
+def _buffers_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
+    try:
+        import torch.nn as nn
+        from aas_enhancement_amd.dist import DPContext
+        from aas_enhancement_amd.model import DeepSpeech
+        from tests.helpers import LABELS
+        dp = DPContext.from_env()
+        A = DeepSpeech(nn.GRU, LABELS, 12, 3, True, 11, 2, 8, 2, nFreq=8)      # parameter / buffer containers only: no kernel runs here
+        # what a rank-0-only validation pass leaves behind: rank 0's BatchNorm running statistics (and batch counters) have moved
+        g = torch.Generator().manual_seed(5)
+        for b in A.buffers():
+            if rank == 0:
+                b.copy_((torch.rand(b.shape, generator=g) * 3).to(b.dtype) if b.dtype.is_floating_point else torch.full_like(b, 7))
+        before = [b.clone() for b in A.buffers()]
+        dp.broadcast_buffers(A, src=0)
+        q.put((rank, [b.numpy().copy() for b in A.buffers()], [b.numpy().copy() for b in before]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_buffers_makes_ranks_replicas_again_after_rank0_only_validation():
+    """A stays in train mode while rank 0 alone validates, so its BatchNorm running statistics move on rank 0
+    only.  DPContext.broadcast_buffers (called by the trainers behind the post-validation barrier) hands every rank rank 0's
+    buffers, floating point and integer ones, bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_buffers_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, after0, before0), (_, after1, before1) = res
+    assert len(after0) >= 9
+    assert any(not np.array_equal(a, b) for a, b in zip(before0, before1))      # the ranks really had diverged
+    for a0, a1, b0 in zip(after0, after1, before0):
+        assert np.array_equal(a0, b0) and np.array_equal(a1, b0) and a0.dtype == b0.dtype
+
+
+def test_precision_context_restores_the_previous_mode():
+    """ops.precision(mode): the mode inside the block, the previous one back on exit - also when the block raises."""
+    from aas_enhancement_amd import ops
+    base = ops.get_precision()
+    try:
+        with ops.precision(2):
+            assert ops.get_precision() == 2
+            with ops.precision(1):
+                assert ops.get_precision() == 1
+            assert ops.get_precision() == 2
+            with ops.precision(None):
+                assert ops.get_precision() == 2
+        assert ops.get_precision() == base
+        with pytest.raises(ValueError):
+            with ops.precision(1):
+                raise ValueError("x")
+        assert ops.get_precision() == base
+    finally:
+        ops.set_precision(base)
