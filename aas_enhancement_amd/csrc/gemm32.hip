@@ -371,11 +371,15 @@ const float* zero_block() {
 
 template <bool AKC, bool BKC, int TMW>
 int launch32(G32& p, dim3 grid, hipStream_t s) {
-    constexpr int LDS = NSTAGE * (2 * TMW * 128 + OPB);
+    constexpr int LDS0 = NSTAGE * (2 * TMW * 128 + OPB);
+    // experiment (AAS_GEMM32_WHOLE_CU=1): ask for more than half of a CU's LDS, so a workgroup has its CU to itself and hands the
+    // WHOLE CU back when it retires - a persistent recurrent launch waiting for residency needs whole CUs
+    static const bool whole = getenv("AAS_GEMM32_WHOLE_CU") && atoi(getenv("AAS_GEMM32_WHOLE_CU")) != 0;
+    const int LDS = whole ? 84 * 1024 : LDS0;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm32_kernel<AKC, BKC, TMW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS) != hipSuccess)
+                                84 * 1024) != hipSuccess)
             return -1;
         attr_done = true;
     }
@@ -392,44 +396,53 @@ int launch32(G32& p, dim3 grid, hipStream_t s) {
 // Tile height and split-K factor.  A launch runs in rounds of (CUs x workgroups per CU) workgroups that start and finish
 // together; the last round costs a whole round however few workgroups it holds.  Model: time ~ rounds x (work of the workgroups a
 // CU holds in a round) + the slab traffic of a split; pick the cheapest of 128- / 64-row tiles x split factors.
-void choose(int M, int N, int K, int nz, bool can_split, int& tmw, int& sk) {
+double cost_us(int M, int N, int K, int nz, int bm, int s, int* slabs = nullptr) {
+    const int cus = aas_device_cus() > 0 ? aas_device_cus() : 256;
+    const int ktiles = (K + TK - 1) / TK;
+    const int per_cu = bm == 128 ? 2 : 3;
+    const int64_t tiles = (int64_t)cdiv(N, TN_) * cdiv(M, bm) * nz;
+    const int per = (ktiles + s - 1) / s;
+    const int se = (ktiles + per - 1) / per;            // slabs that are not empty
+    if (slabs) *slabs = se;
+    const int64_t wgs = tiles * se;
+    const int64_t slots = (int64_t)cus * per_cu;
+    const int64_t rounds = (wgs + slots - 1) / slots;
+    // workgroups the busiest CU holds over the launch (full rounds: per_cu each; the last round: dealt round-robin)
+    const int64_t last = wgs - (rounds - 1) * slots;
+    const int64_t on_cu = (rounds - 1) * per_cu + (last + cus - 1) / cus;
+    // one k-step of a 128-row tile holds the CU's matrix pipes for ~2.05 us (4096 cycles at the ~2.0-2.1 GHz the chip holds
+    // under fp32 MFMA load); a workgroup alone on its CU covers fewer of its own LDS / barrier waits (measured 0.93 of that
+    // rate for 128-row tiles, 0.82 for 64-row ones; 0.97 / 0.90-0.95 with co-resident workgroups); + ~3 us of prologue /
+    // epilogue per workgroup; a split adds the slab stores and the reduce launch
+    const int co = (int)((wgs + cus - 1) / cus) < per_cu ? (int)((wgs + cus - 1) / cus) : per_cu;
+    const double eff = bm == 128 ? (co >= 2 ? 0.97 : 0.93) : (co >= 3 ? 0.95 : co == 2 ? 0.90 : 0.82);
+    const double wg_us = per * 2.05 * (bm / 128.0) / eff + 3.0;
+    double t = on_cu * wg_us;
+    if (se > 1) t += (double)(se + 1) * M * N * 4 / 4.0e6 + 3.0;
+    return t;
+}
+
+double choose(int M, int N, int K, int nz, bool can_split, int& tmw, int& sk) {
     static const int f_bm = getenv("AAS_GEMM32_BM") ? atoi(getenv("AAS_GEMM32_BM")) : 0;
     static const int f_sk = getenv("AAS_GEMM32_SK") ? atoi(getenv("AAS_GEMM32_SK")) : 0;
     // longest life of a workgroup in k-steps (~2 us each): a persistent recurrent launch of the training step becomes resident only
     // when enough CUs are free AT ONCE, so a GEMM beside it must hand its CUs back soon (0 = no cap)
     const int max_steps = aas_gemm_max_steps_value();
-    const int cus = aas_device_cus() > 0 ? aas_device_cus() : 256;
     const int ktiles = (K + TK - 1) / TK;
     double best = 1e30;
     tmw = 64; sk = 1;
     for (int bm = 128; bm >= 64; bm -= 64) {
         if (f_bm && bm != f_bm) continue;
-        const int per_cu = bm == 128 ? 2 : 3;
-        const int64_t tiles = (int64_t)cdiv(N, TN_) * cdiv(M, bm) * nz;
         for (int s = 1; s <= 16; ++s) {
             if (s > 1 && (!can_split || ktiles / s < 16)) break;
             if (f_sk && s != f_sk && can_split) continue;
             if (max_steps > 0 && can_split && (ktiles + s - 1) / s > max_steps && s < 16 && ktiles / (s + 1) >= 16) continue;
-            const int per = (ktiles + s - 1) / s;
-            const int se = (ktiles + per - 1) / per;            // slabs that are not empty
-            const int64_t wgs = tiles * se;
-            const int64_t slots = (int64_t)cus * per_cu;
-            const int64_t rounds = (wgs + slots - 1) / slots;
-            // workgroups the busiest CU holds over the launch (full rounds: per_cu each; the last round: dealt round-robin)
-            const int64_t last = wgs - (rounds - 1) * slots;
-            const int64_t on_cu = (rounds - 1) * per_cu + (last + cus - 1) / cus;
-            // one k-step of a 128-row tile holds the CU's matrix pipes for ~2.05 us (4096 cycles at the ~2.0-2.1 GHz the chip holds
-            // under fp32 MFMA load); a workgroup alone on its CU covers fewer of its own LDS / barrier waits (measured 0.93 of that
-            // rate for 128-row tiles, 0.82 for 64-row ones; 0.97 / 0.90-0.95 with co-resident workgroups); + ~3 us of prologue /
-            // epilogue per workgroup; a split adds the slab stores and the reduce launch
-            const int co = (int)((wgs + cus - 1) / cus) < per_cu ? (int)((wgs + cus - 1) / cus) : per_cu;
-            const double eff = bm == 128 ? (co >= 2 ? 0.97 : 0.93) : (co >= 3 ? 0.95 : co == 2 ? 0.90 : 0.82);
-            const double wg_us = per * 2.05 * (bm / 128.0) / eff + 3.0;
-            double t = on_cu * wg_us;
-            if (se > 1) t += (double)(se + 1) * M * N * 4 / 4.0e6 + 3.0;
+            int se;
+            const double t = cost_us(M, N, K, nz, bm, s, &se);
             if (t < best) { best = t; tmw = bm / 2; sk = se; }
         }
     }
+    return best;
 }
 
 int g_max_steps = -1;
@@ -497,40 +510,53 @@ int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A,
     AAS_CHECK(p.zero != nullptr, "aas_gemm_f32: zero block symbol not found");
     p.multi = nmulti > 0 ? nmulti : 0;
     for (int i = 0; i < p.multi; ++i) { p.Am[i] = Am[i]; p.Bm[i] = Bm[i]; p.Cm[i] = Cm[i]; p.Km[i] = Km ? Km[i] : K; }
-    int tmw, sk;
     const int nz = nmulti > 0 ? nmulti : batch;
-    choose(M, N, K, nz, batch == 1, tmw, sk);
-    dim3 grid(cdiv(N, TN_), cdiv(M, 2 * tmw), nz);
-    if (sk > 1) {
-        const size_t wsb = sizeof(float) * (size_t)sk * nz * M * N;
-        p.ws = workspace(s, wsb);
-        if (p.ws != nullptr) {
-            p.splitk = sk;
-            grid.z = sk * nz;
-        } else {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(s, &cs);
-            AAS_CHECK(cs != hipStreamCaptureStatusNone, "aas_gemm_f32: could not allocate the split-K workspace (%zu bytes)", wsb);
-            sk = 1;     // (capturing, and no eager launch on this stream has sized the workspace yet: whole-K workgroups)
+    const int m_first = M;     // (a two-launch split of the rows - whole rounds of 128-row tiles, then 64-row tiles - was measured: no gain,
+                               //  the hardware already deals a partial round one workgroup per CU)
+    for (int part = 0; part < (m_first < M ? 2 : 1); ++part) {
+        const int mo = part == 0 ? 0 : m_first, Mp = part == 0 ? m_first : M - m_first;
+        G32 q = p;
+        q.M = Mp;
+        if (mo) {
+            q.A = akc ? A + (int64_t)mo * lda : A + mo;
+            q.C = C + (int64_t)mo * ldc;
+            if (addend) q.addend = addend + (int64_t)mo * ldd;
         }
-    }
-    int rc;
-    if (tmw == 64) {
-        if (akc && bkc) rc = launch32<true, true, 64>(p, grid, s);
-        else if (akc) rc = launch32<true, false, 64>(p, grid, s);
-        else rc = launch32<false, false, 64>(p, grid, s);
-    } else {
-        if (akc && bkc) rc = launch32<true, true, 32>(p, grid, s);
-        else if (akc) rc = launch32<true, false, 32>(p, grid, s);
-        else rc = launch32<false, false, 32>(p, grid, s);
-    }
-    AAS_CHECK(rc == 0, "aas_gemm_f32: could not raise the dynamic LDS limit");
-    if (p.splitk > 1) {
-        const int64_t q4 = (int64_t)M * (N / 4);
-        R4 cs;
-        for (int i = 0; i < 4; ++i) cs.C[i] = p.multi > 0 ? p.Cm[i < p.multi ? i : 0] : C;
-        hipLaunchKernelGGL(gemm32_reduce_kernel, dim3((unsigned)((q4 + 255) / 256), p.multi > 0 ? p.multi : 1), dim3(256), 0, s, p.ws,
-                           p.splitk, M, N, cs, ldc, bias, addend, ldd, accumulate);
+        int tmw, sk;
+        if (m_first < M) { tmw = part == 0 ? 64 : 32; sk = 1; }
+        else choose(Mp, N, K, nz, batch == 1, tmw, sk);
+        dim3 grid(cdiv(N, TN_), cdiv(Mp, 2 * tmw), nz);
+        if (sk > 1) {
+            const size_t wsb = sizeof(float) * (size_t)sk * nz * Mp * N;
+            q.ws = workspace(s, wsb);
+            if (q.ws != nullptr) {
+                q.splitk = sk;
+                grid.z = sk * nz;
+            } else {
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing(s, &cs);
+                AAS_CHECK(cs != hipStreamCaptureStatusNone, "aas_gemm_f32: could not allocate the split-K workspace (%zu bytes)", wsb);
+                sk = 1;     // (capturing, and no eager launch on this stream has sized the workspace yet: whole-K workgroups)
+            }
+        }
+        int rc;
+        if (tmw == 64) {
+            if (akc && bkc) rc = launch32<true, true, 64>(q, grid, s);
+            else if (akc) rc = launch32<true, false, 64>(q, grid, s);
+            else rc = launch32<false, false, 64>(q, grid, s);
+        } else {
+            if (akc && bkc) rc = launch32<true, true, 32>(q, grid, s);
+            else if (akc) rc = launch32<true, false, 32>(q, grid, s);
+            else rc = launch32<false, false, 32>(q, grid, s);
+        }
+        AAS_CHECK(rc == 0, "aas_gemm_f32: could not raise the dynamic LDS limit");
+        if (q.splitk > 1) {
+            const int64_t q4 = (int64_t)Mp * (N / 4);
+            R4 cs;
+            for (int i = 0; i < 4; ++i) cs.C[i] = q.multi > 0 ? q.Cm[i < q.multi ? i : 0] : q.C;
+            hipLaunchKernelGGL(gemm32_reduce_kernel, dim3((unsigned)((q4 + 255) / 256), q.multi > 0 ? q.multi : 1), dim3(256), 0, s, q.ws,
+                               q.splitk, Mp, N, cs, ldc, bias, q.addend, ldd, accumulate);
+        }
     }
     AAS_LAUNCH_CHECK("aas_gemm_f32");
     return 0;
