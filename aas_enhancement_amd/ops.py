@@ -109,11 +109,15 @@ _precision = [int(__import__('os').environ.get('AAS_PRECISION', '0'))]
 
 
 def set_precision(mode):
-    """0 (library default) = fp32 operands on fp32-input MFMA, the reference's arithmetic; 1 = split-bf16 fast mode (operands as
-    bf16 hi/lo, 3 MFMAs per product, ~2^-17 per product: narrower than fp32, inside the parity budget); 2 = fp32-EQUIVALENT: fp32
-    recurrent products and small GEMMs as in mode 0, the large GEMMs as six bf16 products of three-term operands (all 24 operand
-    bits, dropped cross terms <= 2^-25: `gemm_planes6`).  `--precision` of main.py /
-    am_train.py and the AAS_PRECISION environment variable select it for a whole run."""
+    """0 (library default) = fp32 operands on fp32-input MFMA with fp32 accumulation in every GEMM and recurrent product - the
+    arithmetic class of the reference's cuDNN / cuBLAS fp32 path, not bit-identical to it: summation orders differ as between any two
+    GEMM tilings, and the reduce-scatter BPTT exchanges its partial sums as fp32 words whose two low mantissa bits carry the step tag
+    (rounded to nearest there: a 22-bit exchange, |error| <= 2 ulp per partial; the guarantee is the fp64-error tests, not "exact");
+    1 = split-bf16 fast mode (operands as bf16 hi/lo, 3 MFMAs per product, ~2^-17 per product: narrower than fp32, inside the parity
+    budget); 2 = fp32-EQUIVALENT: small GEMMs and recurrent products as in mode 0, EXCEPT the 500-unit LSTM's BPTT, which runs the
+    six-product bf16 kernel; the large GEMMs as six bf16 products of three-term operands (all 24 operand bits, dropped cross terms
+    <= 2^-25: `gemm_planes6`).  `--precision` of main.py / am_train.py and the AAS_PRECISION environment variable select it for a whole
+    run; a trainer keeps the mode it was built in (`Trainer.precision`, `ops.precision`)."""
     check(lib().aas_set_precision(int(mode)), "aas_set_precision")
     _precision[0] = int(mode)
 
