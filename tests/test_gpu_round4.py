@@ -162,3 +162,77 @@ def test_multi_problem_weight_gradient_launch_equals_four_products(gpu):
                 assert rel_err(o.double().cpu() - 1.0, w.cpu()) < 2e-5, cap
     finally:
         L.aas_set_gemm_max_steps(48)
+
+
+# ------------------------------------------------------------------------------------------------ acoustic trainer, data parallel
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _acoustic_models(seed=40):
+    from aas_enhancement_amd import prng
+    from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
+    G = stackedBRNN(I=8, H=16, L=2)
+    A = DeepSpeech(nn.GRU, LABELS, 12, 2, True, 11, 2, 8, 2, nFreq=8)
+    for m, s, cs in ((G, seed + 1, None), (A, seed + 3, 0.1)):
+        load_sd(m, {k: torch.from_numpy(v) for k, v in prng.fill_state_dict(m.state_dict(), s, conv_std=cs).items()}, strict=False)
+    return G, A
+
+
+def _acoustic_batch(it):
+    from tests.tools_shim import make_batch
+    b = make_batch(4, 8, [60, 60, 60, 60], 510 + it, [3, 3, 2, 2], 520 + it)
+    return (torch.from_numpy(b["inputs"]), torch.from_numpy(b["targets"]), torch.from_numpy(b["pct"]), torch.from_numpy(b["target_sizes"]),
+            torch.from_numpy(b["mask"]))
+
+
+def _acoustic_worker(rank, world, port, q, form):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=180))
+    try:
+        torch.cuda.set_device(0)
+        from aas_enhancement_amd.trainer_acoustic import Trainer
+        tr = Trainer(cfg(sync_bn=True), None, models=_acoustic_models())
+        tr.make_optimizers()
+        assert tr.dp.active
+        out = []
+        for it in range(3):
+            b = tr.dp.shard_collated(_acoustic_batch(it))
+            if form == "sync":
+                out.append(tr.train_step(b, it)["l_ctc"])
+            else:
+                tr.train_step_async(b, it)
+                out.append(tr.read_scalars()["l_ctc"])
+        q.put((rank, np.asarray(out), tr._flat["G"].flat_p.detach().cpu().numpy(), tr._flat["A"].flat_p.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("form", ["sync", "async"])
+def test_acoustic_trainer_dp_two_ranks_equal_single(gpu, form, precision2):
+    """trainer_acoustic data parallel: 2 ranks x 2 utterances (global N as the loss normaliser, bucketed all-reduce of E's and A's flat
+    gradient buffers, SyncBN in A) == 1 rank x 4 utterances: losses, and E's / A's parameters after three Adam steps."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_acoustic_worker, args=(r, 2, port, q, form)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from aas_enhancement_amd.trainer_acoustic import Trainer
+    tr = Trainer(cfg(), None, models=_acoustic_models())
+    ref = np.asarray([tr.train_step(_acoustic_batch(it), it)["l_ctc"] for it in range(3)])
+    for rank, out, gp, ap in res:
+        assert np.allclose(out, ref, rtol=3e-4), (rank, out, ref)
+        for got, want in ((gp, tr._flat["G"].flat_p), (ap, tr._flat["A"].flat_p)):
+            d_ = np.abs(got - want.detach().cpu().numpy())
+            assert float((d_ > 2e-4).mean()) < 5e-3 and float(d_.max()) < 6.1e-3, rank      # (Adam sign flips of noise-level gradients)
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
