@@ -8,6 +8,8 @@ The step is one serial chain - E forward, A forward, CTC, A backward, E backward
 takes the whole chip; the weight-gradient products run on the side stream as in the AAS trainer.  `train_step_async` keeps
 the loss and the running CTC average of the log line on the device (no host synchronisation per step).
 """
+import os
+
 import torch
 
 from . import ops
@@ -72,7 +74,10 @@ class Trainer(_AASTrainer):
                 l_CTC = ops.ctc_sum(prob, None, None, None, self.CTCLoss.blank, ctc_meta) * scale
             else:
                 l_CTC = self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / n_glob
+            # (AAS_AC_BWD_CUS: CU cap of the BPTT launches, leaving CUs to the weight-gradient products beside them; 0 = whole chip)
+            ops.set_rnn_cu_limit(int(os.environ.get("AAS_AC_BWD_CUS", "0")))
             l_CTC.backward()
+            ops.set_rnn_cu_limit(0)
             ops.sync_wgrad()
             if self._reducer is not None:
                 for f in self._flat.values():
