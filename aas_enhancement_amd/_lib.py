@@ -28,7 +28,7 @@ SIGNATURES = {
     "aas_set_rnn_cu_limit": [c_int],
     "aas_gemm_f32": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                      c_int, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_i64],
-    "aas_gemm_f32_multi": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int],
+    "aas_gemm_f32_multi": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_i64, c_i64, c_vp],
     "aas_set_gemm_variant": [c_int],
     "aas_set_gemm_max_steps": [c_int],
     "aas_gemm_tn_rowscaled_f32": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_int],

@@ -21,7 +21,7 @@ int aas_rnn_launch_tag_value();  // >= 1: what a timed-out persistent launch lea
 int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                    int64_t ldc, const float* bias, const float* addend, int64_t ldd, int accumulate, int batch, int64_t strideA,
                    int64_t strideB, int64_t strideC, int kdivA, int64_t kouterA, int kdivB, int64_t kouterB, int nmulti,
-                   const float* const* Am, const float* const* Bm, float* const* Cm, const int* Km);
+                   const float* const* Am, const float* const* Bm, float* const* Cm, const int* Km, const float* d_alpha);
 int aas_rnn_cus();  // aas_device_cus() capped by aas_set_rnn_cu_limit()
 
 #define AAS_CHECK(cond, ...)            \

@@ -474,7 +474,7 @@ static int gemm_f32_impl(aasStream_t stream, int mode, int M, int N, int K, cons
     if (aas_precision_value() != 1 && kscale == nullptr) {
         // fp32 arithmetic: the LDS-DMA kernel (gemm32.hip) wherever both operands take 16-byte chunks
         const int rc32 = aas_gemm32_try(s, mode, M, N, K, A, lda, B, ldb, C, ldc, bias, addend, ldd, accumulate, batch, strideA, strideB,
-                                        strideC, kdivA, kouterA, kdivB, kouterB, 0, nullptr, nullptr, nullptr, nullptr);
+                                        strideC, kdivA, kouterA, kdivB, kouterB, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
         if (rc32 >= 0) return rc32;
     }
     GemmP p;
@@ -547,9 +547,12 @@ extern "C" int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K, c
 }
 
 extern "C" int aas_gemm_f32_multi(aasStream_t stream, int mode, int n, int M, int N, const int* K, const float* const* A, int64_t lda,
-                                  const float* const* B, int64_t ldb, float* const* C, int64_t ldc, int accumulate) {
+                                  const float* const* B, int64_t ldb, float* const* C, int64_t ldc, int accumulate, int kdiv, int64_t kouterA,
+                                  int64_t kouterB, const float* d_alpha) {
     AAS_CHECK(mode >= 0 && mode <= 2 && n >= 1 && n <= 4, "aas_gemm_f32_multi: bad mode %d / problem count %d", mode, n);
     AAS_CHECK(M >= 0 && N >= 0 && K && A && B && C, "aas_gemm_f32_multi: bad sizes M=%d N=%d or null arrays", M, N);
+    AAS_CHECK(kdiv >= 0 && (kdiv == 0 || mode == AAS_GEMM_TN), "aas_gemm_f32_multi: two-level reduction rows (kdiv=%d) are a TN feature", kdiv);
+    AAS_CHECK(!(d_alpha && aas_precision_value() == 1), "aas_gemm_f32_multi: alpha is not supported in the split-bf16 mode (the plane GEMMs carry it)");
     int kmax = 0;
     for (int i = 0; i < n; ++i) {
         AAS_CHECK(K[i] >= 0 && A[i] && B[i] && C[i], "aas_gemm_f32_multi: problem %d: K=%d or a null operand", i, K[i]);
@@ -558,12 +561,13 @@ extern "C" int aas_gemm_f32_multi(aasStream_t stream, int mode, int n, int M, in
     if (M == 0 || N == 0) return 0;
     if (aas_precision_value() != 1) {
         const int rc32 = aas_gemm32_try((hipStream_t)stream, mode, M, N, kmax, nullptr, lda, nullptr, ldb, nullptr, ldc, nullptr, nullptr, 0,
-                                        accumulate, 1, 0, 0, 0, 0, 0, 0, 0, n, A, B, C, K);
+                                        accumulate, 1, 0, 0, 0, kdiv, kouterA, kdiv, kouterB, n, A, B, C, K, d_alpha);
         if (rc32 >= 0) return rc32;
     }
     for (int i = 0; i < n; ++i) {   // operands that do not take 16-byte chunks (or the fast mode): one general launch per problem
-        const int rc = gemm_f32_impl(stream, mode, M, N, K[i], A[i], lda, B[i], ldb, C[i], ldc, nullptr, nullptr, 0, accumulate, 1, 0, 0, 0, 0,
-                                     0, 0, 0, nullptr, 0);
+        // (alpha rides on the reduction rows of A there: kscale with one entry)
+        const int rc = gemm_f32_impl(stream, mode, M, N, K[i], A[i], lda, B[i], ldb, C[i], ldc, nullptr, nullptr, 0, accumulate, 1, 0, 0, 0, kdiv,
+                                     kouterA, kdiv, kouterB, d_alpha, d_alpha ? 1 : 0);
         if (rc) return rc;
     }
     return 0;

@@ -59,6 +59,7 @@ struct G32 {
     const float* Bm[4];
     float* Cm[4];
     int Km[4];            // multi: reduction extent per problem (<= K)
+    const float* alpha;   // device scalar: the product is multiplied by it before bias / addend / accumulate (null: 1)
 };
 
 // LDS-DMA as inline assembly: hipcc does not then know that the instruction writes LDS.  With the builtin it orders every LDS
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256, TMW == 64 ? 2 : 3) void gemm32_kernel(G32 p) {
         } else {
             s.p += TK * ld;
             s.rem += TK;
-            if (s.rem >= kdiv) { s.rem -= kdiv; s.p += wrap; }
+            while (s.rem >= kdiv) { s.rem -= kdiv; s.p += wrap; }      // (kdiv >= 8: at most four turns)
         }
     };
     auto stage = [&](int st) {   // the next k-step of both operands into stage st
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(256, TMW == 64 ? 2 : 3) void gemm32_kernel(G32 p) {
     if (n < p.N) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (!part && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+        const float al = (!part && p.alpha) ? *p.alpha : 1.0f;
 #pragma unroll 4
         for (int rr = 0; rr < TMW; rr += 4) {
             const int row = rr + rq, m = m0 + wm * TMW + row;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256, TMW == 64 ? 2 : 3) void gemm32_kernel(G32 p) {
             f32x4 v = *reinterpret_cast<const f32x4*>(ew + row * 256 + c4 * 4);
             float* cp = Cw + (int64_t)m * ldc + n;
             if (!part) {
-                v += bv;
+                v = v * al + bv;
                 if (addend) v += *reinterpret_cast<const f32x4*>(addend + (int64_t)m * p.ldd + n);
                 if (p.accumulate) v += *reinterpret_cast<const f32x4*>(cp);
             }
@@ -311,7 +313,7 @@ struct R4 {
 };
 __global__ __launch_bounds__(256) void gemm32_reduce_kernel(const float* __restrict__ ws, int ns, int M, int N, R4 cs,
                                                             int64_t ldc, const float* __restrict__ bias, const float* __restrict__ addend,
-                                                            int64_t ldd, int accumulate) {
+                                                            int64_t ldd, int accumulate, const float* __restrict__ alpha) {
     const int64_t q4 = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one float4 of the [M][N] slab
     const int n4 = N >> 2;
     if (q4 >= (int64_t)M * n4) return;
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(256) void gemm32_reduce_kernel(const float* __restr
     ws += (int64_t)blockIdx.y * ns * slab;
     f32x4 s = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * N + n);
     for (int z = 1; z < ns; ++z) s += *reinterpret_cast<const f32x4*>(ws + z * slab + (int64_t)m * N + n);
+    if (alpha) s = s * alpha[0];
     if (bias) { s.x += bias[n]; s.y += bias[n + 1]; s.z += bias[n + 2]; s.w += bias[n + 3]; }
     float* cp = C + (int64_t)m * ldc + n;
     if (addend) {
@@ -474,7 +477,7 @@ int aas_gemm_variant_value() {
 int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                    int64_t ldc, const float* bias, const float* addend, int64_t ldd, int accumulate, int batch, int64_t strideA,
                    int64_t strideB, int64_t strideC, int kdivA, int64_t kouterA, int kdivB, int64_t kouterB, int nmulti,
-                   const float* const* Am, const float* const* Bm, float* const* Cm, const int* Km) {
+                   const float* const* Am, const float* const* Bm, float* const* Cm, const int* Km, const float* d_alpha) {
     if (aas_gemm_variant_value() == 1) return -1;
     if (M < 64 || N < 64 || K < 64) return -1;   // thin products: the general kernel's tile edge handling is as good
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -496,7 +499,7 @@ int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A,
     // the 16-byte epilogue: whole float4 columns, 16-byte aligned rows of C / addend / bias; two-level k rows step without a division
     ok = ok && N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && (!bias || al16(bias)) && (!addend || (al16(addend) && ldd % 4 == 0));
     for (int i = 0; i < np; ++i) ok = ok && al16(nmulti > 0 ? Cm[i] : C);
-    ok = ok && (kdivA == 0 || kdivA >= TK) && (kdivB == 0 || kdivB >= TK);
+    ok = ok && (kdivA == 0 || kdivA >= 8) && (kdivB == 0 || kdivB >= 8);
     if (!ok) return -1;
     G32 p;
     memset(&p, 0, sizeof(p));
@@ -508,6 +511,7 @@ int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A,
     p.flags = aas_debug_flags_value();
     p.zero = zero_block();
     AAS_CHECK(p.zero != nullptr, "aas_gemm_f32: zero block symbol not found");
+    p.alpha = d_alpha;
     p.multi = nmulti > 0 ? nmulti : 0;
     for (int i = 0; i < p.multi; ++i) { p.Am[i] = Am[i]; p.Bm[i] = Bm[i]; p.Cm[i] = Cm[i]; p.Km[i] = Km ? Km[i] : K; }
     const int nz = nmulti > 0 ? nmulti : batch;
@@ -555,7 +559,7 @@ int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A,
             R4 cs;
             for (int i = 0; i < 4; ++i) cs.C[i] = q.multi > 0 ? q.Cm[i < q.multi ? i : 0] : q.C;
             hipLaunchKernelGGL(gemm32_reduce_kernel, dim3((unsigned)((q4 + 255) / 256), q.multi > 0 ? q.multi : 1), dim3(256), 0, s, q.ws,
-                               q.splitk, Mp, N, cs, ldc, bias, q.addend, ldd, accumulate);
+                               q.splitk, Mp, N, cs, ldc, bias, q.addend, ldd, accumulate, q.alpha);
         }
     }
     AAS_LAUNCH_CHECK("aas_gemm_f32");

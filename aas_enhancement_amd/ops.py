@@ -355,15 +355,16 @@ def _gemm_raw(mode, M, N, K, A, lda, B, ldb, C, ldc, bias, addend, ldd, accumula
                              batch, sA, sB, sC, kdivA, kouterA, kdivB, kouterB), "aas_gemm_f32")
 
 
-def gemm_multi(mode, M, N, Ks, As, lda, Bs, ldb, Cs, ldc, accumulate=False):
+def gemm_multi(mode, M, N, Ks, As, lda, Bs, ldb, Cs, ldc, accumulate=False, kdiv=0, kouterA=0, kouterB=0, alpha=None):
     """<= 4 products of equal shape in ONE launch (include/aas_hip.h: aas_gemm_f32_multi): As / Bs / Cs are device byte addresses,
-    Ks the reduction extent of each problem."""
+    Ks the reduction extent of each problem; kdiv / kouter*: two-level reduction rows of both operands (TN); alpha: device scalar."""
     import ctypes
     n = len(Ks)
     vp = lambda xs: (ctypes.c_void_p * n)(*[int(x) for x in xs])
     ks = (ctypes.c_int * n)(*[int(k) for k in Ks])
     with _timed("gemm", "gemm_%s" % ("nt", "nn", "tn")[mode], sum(2.0 * M * N * k for k in Ks)):
-        check(lib().aas_gemm_f32_multi(stream(), mode, n, M, N, ks, vp(As), lda, vp(Bs), ldb, vp(Cs), ldc, int(accumulate)), "aas_gemm_f32_multi")
+        check(lib().aas_gemm_f32_multi(stream(), mode, n, M, N, ks, vp(As), lda, vp(Bs), ldb, vp(Cs), ldc, int(accumulate), int(kdiv), int(kouterA),
+                                       int(kouterB), ptr(alpha)), "aas_gemm_f32_multi")
 
 
 # ---- pre-split operand planes (split-bf16 GEMM with the fp32 -> hi/lo split hoisted out of the k-loop) ----------
@@ -862,6 +863,7 @@ _GATES = {"lstm": 4, "gru": 3, "rnn": 1}
 # behind the BPTT launch and take CUs from the input-gradient GEMM on the critical path, and the per-row weight lengthens the TN
 # kernel's prefetch - so it is off by default.
 _TN_FOLD = os.environ.get("AAS_TN_FOLD", "0") == "1"
+CLASS_WGRAD = [os.environ.get("AAS_CLASS_WGRAD", "1") == "1"]   # ... per utterance class with alpha (no scaled copies of x / h)
 MULTI_WGRAD = [os.environ.get("AAS_MULTI_WGRAD", "1") == "1"]   # fp32 arithmetic: a layer's four weight-gradient products as one aas_gemm_f32_multi launch
 TN_WGRAD = [os.environ.get("AAS_TN_WGRAD", "1") == "1"]   # weight-gradient products from row-major planes (aas_gemm_planes_tn)
 
@@ -1143,7 +1145,9 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
             return wgrads_planes(out)
         tn = lambda *a_, **k_: gemm(TN, *a_, **k_)
         xw, hw = x2, hout
-        if rs is not None:  # per-utterance weights on the parameter gradients only (dx used the unscaled d(gates))
+        multi_ok = MULTI_WGRAD[0] and _precision[0] != 1 and not (rs is not None and _precision[0] == 0 and _TN_FOLD) and all(o.is_contiguous() for o in out)
+        by_class = multi_ok and rs is not None and CLASS_WGRAD[0] and bool(getattr(rs, "_aas_classes", None))
+        if rs is not None and not by_class:  # per-utterance weights on the parameter gradients only (dx used the unscaled d(gates))
             if _precision[0] == 0 and _TN_FOLD and all(o.is_contiguous() for o in out):
                 # fp32 mode, optional: the weight rides on the reduction rows while the GEMM stages them (no pass at all)
                 def tn(M_, N_, K_, A_, lda_, B_, ldb_, C_, ldc_, a_off=0, b_off=0, accumulate=False):
@@ -1156,9 +1160,37 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
                 xw = scale_rows(x2, rs, N)
                 if T > 1:
                     hw = scale_rows(hout.view(2 * R, H), rs, N)
-        if MULTI_WGRAD[0] and _precision[0] != 1 and not (rs is not None and _precision[0] == 0 and _TN_FOLD) and all(o.is_contiguous() for o in out):
+        if multi_ok:
             # the four products of the layer (both directions' dW_ih and dW_hh) share d(gates): ONE launch of 4 x (GH/128 x I/128)
-            # tiles fills the chip without split-K (two launches when the input and hidden widths differ)
+            # tiles fills the chip without split-K (two launches when the input and hidden widths differ).  Per-utterance weights
+            # (the batched discriminator pass): one launch per utterance CLASS over that class's reduction rows - two-level row
+            # addressing, rows (t, n0 .. n0+ns) of every time step - with the class's weight as the product's alpha: no scaled
+            # copies of x / h (10 scale_rows launches, 1 ms of HBM-bound stream time per step before)
+            classes = [(0, N, None)] if rs is None else getattr(rs, "_aas_classes", None)
+            if classes and (rs is None or by_class):
+                a0, ah, b0, bh = dgx.data_ptr(), dgh.data_ptr(), x2.data_ptr(), hout.data_ptr()
+                first = True
+                for n0, ns, alpha in classes:
+                    two = ns != N
+                    kw = dict(kdiv=ns, kouterA=N * 2 * GH, kouterB=N * I, alpha=alpha) if two else dict(alpha=alpha)
+                    kwh = dict(kw, kouterB=N * H) if two else kw
+                    oa, ox, oh = 4 * n0 * 2 * GH, 4 * n0 * I, 4 * n0 * H          # byte offsets of the class's first row
+                    ih = ([a0 + oa, a0 + oa + 4 * GH], [b0 + ox, b0 + ox], [out[0].data_ptr(), out[2].data_ptr()], [T * ns, T * ns])
+                    Rm = (T - 1) * ns
+                    hh = ([ah + oa + 4 * N * 2 * GH, ah + oa + 4 * GH], [bh + oh, bh + oh + 4 * (T * N * H + N * H)],
+                          [out[1].data_ptr(), out[3].data_ptr()], [Rm, Rm])
+                    a_ = acc or not first
+                    if T > 1 and I == H:
+                        gemm_multi(TN, GH, I, ih[3] + hh[3], ih[0] + hh[0], 2 * GH, ih[1] + hh[1], I, ih[2] + hh[2], I, accumulate=a_, **kw)
+                    else:
+                        gemm_multi(TN, GH, I, ih[3], ih[0], 2 * GH, ih[1], I, ih[2], I, accumulate=a_, **kw)
+                        if T > 1:
+                            gemm_multi(TN, GH, H, hh[3], hh[0], 2 * GH, hh[1], H, hh[2], H, accumulate=a_, **kwh)
+                        elif not a_:
+                            out[1].zero_()
+                            out[3].zero_()
+                    first = False
+                return
             a0, ah, b0, bh = dgx.data_ptr(), dgh.data_ptr(), xw.data_ptr(), hw.data_ptr()
             ih = ([a0, a0 + 4 * GH], [b0, b0], [out[0].data_ptr(), out[2].data_ptr()], [R, R])
             Rm = (T - 1) * N

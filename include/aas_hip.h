@@ -101,10 +101,15 @@ int aas_gemm_f32(aasStream_t stream, int mode, int M, int N, int K,
 /* `n` (<= 4) products of EQUAL shape and mode in one launch, C_i (+)= op(A_i) op(B_i): the four weight-gradient products of a
  * bidirectional recurrent layer (dW_ih, dW_hh per direction: model.py:73-74,94-95 backward) share d(gates) and fill the chip together
  * where each alone needs split-K.  A / B / C: HOST arrays of n device pointers, K: host array of the n reduction extents (the
- * recurrent products of a layer sum one time step less than the input products).  fp32 arithmetic on the LDS-DMA kernel when every
- * operand takes 16-byte chunks, else n launches of aas_gemm_f32. */
+ * recurrent products of a layer sum one time step less than the input products).  TN only: kdiv > 0 addresses the reduction rows
+ * of BOTH operands two-level, row(r) = (r / kdiv) * kouter + (r % kdiv) * ld - the rows of ONE utterance class of a time-major
+ * [T, N, ...] tensor are kdiv = class size, kouter = N * ld, from the class's first row; d_alpha (device scalar or null) multiplies
+ * the products: the D-step weight gradients of the batched [enhanced; clean] discriminator pass carry the BEGAN factor (-kt) on the
+ * enhanced class only (trainer_AAS.py:152-160) - two launches, no scaled copies of x / h.  fp32 arithmetic on the LDS-DMA kernel when
+ * every operand takes 16-byte chunks, else n launches of the general kernel. */
 int aas_gemm_f32_multi(aasStream_t stream, int mode, int n, int M, int N, const int* K, const float* const* A, int64_t lda,
-                       const float* const* B, int64_t ldb, float* const* C, int64_t ldc, int accumulate);
+                       const float* const* B, int64_t ldb, float* const* C, int64_t ldc, int accumulate, int kdiv, int64_t kouterA,
+                       int64_t kouterB, const float* d_alpha);
 /* Kernel choice of aas_gemm_f32 in fp32 arithmetic: 0 (default) = the LDS-DMA kernel (128 x 128 x 32 tiles, operands by
  * global_load_lds, split-K through partial slabs + a reduce launch) wherever both operands take 16-byte chunks; 1 = always the
  * register-staged kernel (atomic split-K).  Results agree to fp32 summation order.  Environment: AAS_GEMM32=0 selects 1. */

@@ -164,6 +164,35 @@ def test_multi_problem_weight_gradient_launch_equals_four_products(gpu):
         L.aas_set_gemm_max_steps(48)
 
 
+@pytest.mark.parametrize("T,Nb,H", [(50, 60, 500), (7, 6, 16)])
+def test_weight_gradients_per_utterance_class_with_alpha_equal_scaled_products(gpu, T, Nb, H):
+    """The batched [enhanced; clean] discriminator pass: weight gradients as one multi-problem launch per utterance CLASS - two-level
+    reduction rows (the class's rows of every time step), the class weight as a device-scalar alpha - against fp64 products of
+    explicitly scaled operands; at the discriminator's size (LDS-DMA kernel, kdiv = 30 < one k-step) and at a tiny size (general
+    kernel, alpha on its reduction rows)."""
+    from aas_enhancement_amd import ops
+    GH, R, ns = 4 * H, T * Nb, Nb // 2
+    g = torch.Generator().manual_seed(11)
+    dg = torch.randn(T, Nb, 2 * GH, generator=g).cuda()
+    x, h = torch.randn(T, Nb, H, generator=g).cuda(), torch.randn(2, T, Nb, H, generator=g).cuda()
+    kt = torch.tensor([-0.37], device="cuda")
+    w = torch.ones(Nb, dtype=torch.float64)
+    w[:ns] = -0.37
+    dgd, xd, hd = dg.double().cpu(), x.double().cpu() * w[None, :, None], h.double().cpu() * w[None, None, :, None]
+    want = [torch.einsum("tng,tni->gi", dgd[..., :GH], xd), torch.einsum("tng,tni->gi", dgd[..., GH:], xd),
+            torch.einsum("tng,tni->gi", dgd[1:, :, :GH], hd[0, :-1]), torch.einsum("tng,tni->gi", dgd[:-1, :, GH:], hd[1, 1:])]
+    outs = [torch.zeros(GH, H, device="cuda") for _ in range(4)]
+    a0, b0, bh = dg.data_ptr(), x.data_ptr(), h.data_ptr()
+    for n0, alpha in ((0, kt), (ns, None)):
+        oa, ox = 4 * n0 * 2 * GH, 4 * n0 * H
+        As = [a0 + oa, a0 + oa + 4 * GH, a0 + oa + 4 * Nb * 2 * GH, a0 + oa + 4 * GH]
+        Bs = [b0 + ox, b0 + ox, bh + ox, bh + ox + 4 * (T * Nb * H + Nb * H)]
+        ops.gemm_multi(ops.TN, GH, H, [T * ns, T * ns, (T - 1) * ns, (T - 1) * ns], As, 2 * GH, Bs, H, [o.data_ptr() for o in outs], H,
+                       accumulate=True, kdiv=ns, kouterA=Nb * 2 * GH, kouterB=Nb * H, alpha=alpha)
+    for o, wv in zip(outs, want):
+        assert rel_err(o, wv) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------------ acoustic trainer, data parallel
 def _free_port():
     import socket

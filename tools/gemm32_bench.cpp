@@ -206,7 +206,7 @@ static void time_wgrad(int R, int GH, int I, int iters) {
         for (int multi = 0; multi < 2; ++multi) {
             auto go = [&]() {
                 if (multi) {
-                    if (aas_gemm_f32_multi(nullptr, 2, 4, GH, I, Km, Am, 2 * GH, Bm, I, out, I, 1)) { fprintf(stderr, "%s\n", aas_last_error()); exit(3); }
+                    if (aas_gemm_f32_multi(nullptr, 2, 4, GH, I, Km, Am, 2 * GH, Bm, I, out, I, 1, 0, 0, 0, nullptr)) { fprintf(stderr, "%s\n", aas_last_error()); exit(3); }
                 } else {
                     for (int i = 0; i < 4; ++i)
                         if (aas_gemm_f32(nullptr, 2, GH, I, R, Am[i], 2 * GH, Bm[i], I, out[i], I, nullptr, nullptr, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0)) {
@@ -251,7 +251,7 @@ static int check_multi(int R, int GH, int I) {
     const float* Bm[4] = {x, x, h, h + (size_t)R * I + 30 * I};
     const int Km[4] = {R, R, R - 30, R - 30};
     aas_set_gemm_variant(0);
-    if (aas_gemm_f32_multi(nullptr, 2, 4, GH, I, Km, Am, 2 * GH, Bm, I, o0, I, 1)) { fprintf(stderr, "%s\n", aas_last_error()); exit(3); }
+    if (aas_gemm_f32_multi(nullptr, 2, 4, GH, I, Km, Am, 2 * GH, Bm, I, o0, I, 1, 0, 0, 0, nullptr)) { fprintf(stderr, "%s\n", aas_last_error()); exit(3); }
     aas_set_gemm_variant(1);
     for (int i = 0; i < 4; ++i)
         if (aas_gemm_f32(nullptr, 2, GH, I, Km[i], Am[i], 2 * GH, Bm[i], I, o1[i], I, nullptr, nullptr, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0)) exit(3);
