@@ -43,7 +43,8 @@ int aas_device_cus(void);
  *     67108864 plain grid for the forward launches with more than 8 rows per group (default: XCD-aware grid, write-through),
  *   8388608 / 33554432 256x256 / 256x128 tiles for the wide products of aas_gemm_planes_tn (default 128x128),
  *   65536 / 131072 four waves per workgroup (one per SIMD) instead of eight in aas_gemm_planes_tn / the 128x128 aas_gemm_planes,
- *   (32768: retired - it selected a register-spilling variant of the 1000-unit GRU BPTT kernel),
+ *   32768 BatchNorm on the column-per-thread kernels with fp64 atomics (default where C % 4 == 0: 16-byte loads, per-block partial
+ *     sums in a workspace, no atomics - same statistics on every run),
  *   134217728 fp32 mode on the counter-based kernels of round 1 instead of the data-is-the-flag ones, 268435456 fp32 mode: 16x16x4
  *     MFMA tiles also for row groups of <= 8 rows (default there: 4x4x1 blocks - same products, k summed in interleaved chains),
  *   536870912 mode 2: the exact (fp32-input MFMA) LSTM BPTT kernel instead of the six-product one,
@@ -268,7 +269,8 @@ int aas_gru_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const 
  * x,y [R,C] (ld = C).  stats [4,C] fp32: mean, invstd, (bwd) sum_dy, sum_dy_xhat.
  * slope != 1 fuses LeakyReLU(negative_slope = slope) after the affine (model.py:291,299: slope=map).
  * running_mean/var (may be NULL) are updated with `momentum` and the unbiased variance.
- * wsd: >= 2*C doubles of scratch. */
+ * wsd: >= 2*C doubles of scratch (used by the general kernels only: with C % 4 == 0 and 16-byte aligned tensors the per-block
+ * partial sums go to a per-stream workspace the library owns - two launches, no zero-fill, no atomics). */
 int aas_bn_fwd(aasStream_t stream, const float* x, float* y, int64_t R, int C,
                const float* gamma, const float* beta, float eps, float slope,
                float* stats, float* running_mean, float* running_var, float momentum, double* wsd);

