@@ -65,10 +65,10 @@ SIGNATURES = {
     "aas_gru_bwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "aas_rnn_fwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "aas_rnn_bwd": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
-    "aas_bn_fwd": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp],
+    "aas_bn_fwd": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp],
     "aas_bn_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_vp],
     "aas_bn_stats": [c_vp, c_vp, c_i64, c_int, c_vp],
-    "aas_bn_apply": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp],
+    "aas_bn_apply": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp],
     "aas_bn_bwd_reduce": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_vp, c_vp],
     "aas_bn_bwd_apply": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp],
     "aas_bn_eval": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32],

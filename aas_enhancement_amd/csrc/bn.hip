@@ -41,9 +41,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        float* __restrict__ stats, float* __restrict__ rmean,
                                                        float* __restrict__ rvar, float momentum,
                                                        const double* __restrict__ wsd, const double* __restrict__ rs_dev,
-                                                       int64_t Rs_host) {
+                                                       int64_t Rs_host, long long* __restrict__ nbt) {
     const int cl = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
+    if (nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbt[0] += 1;   // num_batches_tracked
     if (c >= C) return;
     // rows behind the statistics: this launch's R, or the all-reduced row count under SyncBN (device or host value)
     const double Rs = rs_dev ? rs_dev[0] : (double)Rs_host;
@@ -218,11 +219,12 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         float slope, float* __restrict__ stats, float* __restrict__ rmean,
                                                         float* __restrict__ rvar, float momentum, const double* __restrict__ part, int RB,
-                                                        const double* __restrict__ rs_dev, int64_t Rs_host) {
+                                                        const double* __restrict__ rs_dev, int64_t Rs_host, long long* __restrict__ nbt) {
     __shared__ double tot[2][64];
     bn_totals(part, RB, C, tot);
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + cq * 4;
+    if (nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbt[0] += 1;   // num_batches_tracked
     if (c >= C) return;
     const double Rs = rs_dev ? rs_dev[0] : (double)Rs_host;
     f32x4 g, b;
@@ -395,19 +397,19 @@ extern "C" int aas_bn_stats(aasStream_t stream, const float* x, int64_t R, int C
 
 extern "C" int aas_bn_apply(aasStream_t stream, const float* x, float* y, int64_t R, int C, const float* gamma,
                             const float* beta, float eps, float slope, float* stats, float* running_mean,
-                            float* running_var, float momentum, const double* wsd, const double* d_rows) {
+                            float* running_var, float momentum, const double* wsd, const double* d_rows, long long* num_batches_tracked) {
     AAS_CHECK(x && y && gamma && beta && stats && wsd && R > 0 && C > 0, "aas_bn_apply: bad args");
     AAS_CHECK((running_mean == nullptr) == (running_var == nullptr), "aas_bn_apply: running stats must both be set or both NULL");
     if (part_ws((hipStream_t)stream, R, C, x, y, nullptr, nullptr)) {   // (the totals are the caller's: one "partial" row)
         const Geom4 g = geom4(R);
         hipLaunchKernelGGL(bn_apply4_kernel, dim3(cdiv(C, 64), g.RB), dim3(256), 0, (hipStream_t)stream, x, y, R, C, g.RPB, gamma, beta,
-                           eps, slope, stats, running_mean, running_var, momentum, wsd, 1, d_rows, R);
+                           eps, slope, stats, running_mean, running_var, momentum, wsd, 1, d_rows, R, num_batches_tracked);
         AAS_LAUNCH_CHECK("aas_bn_apply");
         return 0;
     }
     dim3 grid(cdiv(C, 64), cdiv(R, RPB));
     hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, R, C, gamma, beta, eps, slope, stats,
-                       running_mean, running_var, momentum, wsd, d_rows, R);
+                       running_mean, running_var, momentum, wsd, d_rows, R, num_batches_tracked);
     AAS_LAUNCH_CHECK("aas_bn_apply");
     return 0;
 }
@@ -470,7 +472,7 @@ extern "C" int aas_softmax_rows(aasStream_t stream, const float* x, float* y, in
 
 extern "C" int aas_bn_fwd(aasStream_t stream, const float* x, float* y, int64_t R, int C, const float* gamma,
                           const float* beta, float eps, float slope, float* stats, float* running_mean,
-                          float* running_var, float momentum, double* wsd) {
+                          float* running_var, float momentum, double* wsd, long long* num_batches_tracked) {
     AAS_CHECK(x && y && gamma && beta && stats && wsd && R > 0 && C > 0, "aas_bn_fwd: bad args");
     AAS_CHECK((running_mean == nullptr) == (running_var == nullptr), "aas_bn_fwd: running stats must both be set or both NULL");
     hipStream_t s = (hipStream_t)stream;
@@ -480,7 +482,7 @@ extern "C" int aas_bn_fwd(aasStream_t stream, const float* x, float* y, int64_t 
         hipLaunchKernelGGL(bn_part4_kernel<false>, grid, dim3(256), 0, s, x, (const float*)nullptr, R, C, g.RPB, (const float*)nullptr,
                            (const float*)nullptr, 1.f, (const float*)nullptr, part);
         hipLaunchKernelGGL(bn_apply4_kernel, grid, dim3(256), 0, s, x, y, R, C, g.RPB, gamma, beta, eps, slope, stats, running_mean,
-                           running_var, momentum, (const double*)part, g.RB, (const double*)nullptr, R);
+                           running_var, momentum, (const double*)part, g.RB, (const double*)nullptr, R, num_batches_tracked);
         AAS_LAUNCH_CHECK("aas_bn_fwd");
         return 0;
     }
@@ -488,7 +490,7 @@ extern "C" int aas_bn_fwd(aasStream_t stream, const float* x, float* y, int64_t 
     dim3 grid(cdiv(C, 64), cdiv(R, RPB));
     hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, x, R, C, wsd);
     hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, x, y, R, C, gamma, beta, eps, slope, stats, running_mean,
-                       running_var, momentum, wsd, (const double*)nullptr, R);
+                       running_var, momentum, wsd, (const double*)nullptr, R, num_batches_tracked);
     AAS_LAUNCH_CHECK("aas_bn_fwd");
     return 0;
 }

@@ -83,10 +83,8 @@ class _BNParams(nn.Module):
     def forward(self, x, slope=1.0):
         if not self.training:   # model.eval(): running statistics (AM_training/train.py:357 validation; the AAS trainers
             return ops.batchnorm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, slope)  # never do)
-        y = ops.batchnorm_rows(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                               self.momentum, slope)
-        self.num_batches_tracked += 1
-        return y
+        return ops.batchnorm_rows(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                  self.momentum, slope, self.num_batches_tracked)   # (the counter: += 1 inside the apply launch)
 
 
 class SequenceWise(nn.Module):

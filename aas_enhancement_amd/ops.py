@@ -1311,7 +1311,7 @@ class _BatchNormRows(torch.autograd.Function):
     statistics pass and the apply pass, forward and backward, so the result equals the single-process global batch."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope, nbt=None):
         require_cuda(x, gamma)
         x = _c(x)
         C = x.shape[-1]
@@ -1323,7 +1323,7 @@ class _BatchNormRows(torch.autograd.Function):
         if dp is None:
             wsd = _wsd(x.device, 2 * C)
             check(lib().aas_bn_fwd(stream(), ptr(x), ptr(y), R, C, ptr(gamma), ptr(beta), float(eps), float(slope),
-                                   ptr(stats), ptr(running_mean), ptr(running_var), float(momentum), ptr(wsd)), "aas_bn_fwd")
+                                   ptr(stats), ptr(running_mean), ptr(running_var), float(momentum), ptr(wsd), ptr(nbt)), "aas_bn_fwd")
         else:
             red = torch.empty(2 * C + 1, device=x.device, dtype=torch.float64)   # [sum, sumsq, rows]: ONE collective
             check(lib().aas_bn_stats(stream(), ptr(x), R, C, ptr(red)), "aas_bn_stats")
@@ -1331,7 +1331,7 @@ class _BatchNormRows(torch.autograd.Function):
             dp.reduce_scalars(red)
             ctx.rows = red[2 * C:]
             check(lib().aas_bn_apply(stream(), ptr(x), ptr(y), R, C, ptr(gamma), ptr(beta), float(eps), float(slope), ptr(stats),
-                                     ptr(running_mean), ptr(running_var), float(momentum), ptr(red), ptr(ctx.rows)), "aas_bn_apply")
+                                     ptr(running_mean), ptr(running_var), float(momentum), ptr(red), ptr(ctx.rows), ptr(nbt)), "aas_bn_apply")
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.slope = slope
         return y
@@ -1357,7 +1357,7 @@ class _BatchNormRows(torch.autograd.Function):
             ctx.dp.reduce_scalars(glob)
             check(lib().aas_bn_bwd_apply(stream(), ptr(x), ptr(dy), ptr(dx), R, C, ptr(gamma), ptr(beta), float(ctx.slope),
                                          ptr(stats), ptr(dgamma), ptr(dbeta), 0, ptr(glob), ptr(loc), ptr(ctx.rows)), "aas_bn_bwd_apply")
-        return dx, (dgamma if ctx.needs_input_grad[1] else None), (dbeta if ctx.needs_input_grad[2] else None), None, None, None, None, None
+        return dx, (dgamma if ctx.needs_input_grad[1] else None), (dbeta if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
 
 
 def batchnorm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, slope=1.0):
@@ -1381,8 +1381,11 @@ def softmax_rows(x):
     return y
 
 
-def batchnorm_rows(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, slope=1.0):
-    return _BatchNormRows.apply(x, gamma, beta, running_mean, running_var, eps, momentum, slope)
+def batchnorm_rows(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, slope=1.0, num_batches_tracked=None):
+    """num_batches_tracked: the module's int64 counter on the device - incremented by the apply launch itself."""
+    if num_batches_tracked is not None:
+        assert num_batches_tracked.dtype == torch.int64 and num_batches_tracked.is_cuda
+    return _BatchNormRows.apply(x, gamma, beta, running_mean, running_var, eps, momentum, slope, num_batches_tracked)
 
 
 # --------------------------------------------------------------------------------------- conv1d (k>1)

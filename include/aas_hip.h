@@ -268,12 +268,14 @@ int aas_gru_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const 
  * via SequenceWise :44-49, :290,298, :316; the reference never calls ASR.eval()).
  * x,y [R,C] (ld = C).  stats [4,C] fp32: mean, invstd, (bwd) sum_dy, sum_dy_xhat.
  * slope != 1 fuses LeakyReLU(negative_slope = slope) after the affine (model.py:291,299: slope=map).
- * running_mean/var (may be NULL) are updated with `momentum` and the unbiased variance.
+ * running_mean/var (may be NULL) are updated with `momentum` and the unbiased variance; num_batches_tracked (device int64, may be
+ * NULL) is incremented by the apply launch (nn.BatchNorm1d's counter - no separate launch on the chain).
  * wsd: >= 2*C doubles of scratch (used by the general kernels only: with C % 4 == 0 and 16-byte aligned tensors the per-block
  * partial sums go to a per-stream workspace the library owns - two launches, no zero-fill, no atomics). */
 int aas_bn_fwd(aasStream_t stream, const float* x, float* y, int64_t R, int C,
                const float* gamma, const float* beta, float eps, float slope,
-               float* stats, float* running_mean, float* running_var, float momentum, double* wsd);
+               float* stats, float* running_mean, float* running_var, float momentum, double* wsd,
+               long long* num_batches_tracked);
 int aas_bn_bwd(aasStream_t stream, const float* x, const float* dy, float* dx, int64_t R, int C,
                const float* gamma, const float* beta, float slope, float* stats,
                float* dgamma, float* dbeta, int accumulate, double* wsd);
@@ -287,7 +289,7 @@ int aas_bn_bwd(aasStream_t stream, const float* x, const float* dy, float* dx, i
 int aas_bn_stats(aasStream_t stream, const float* x, int64_t R, int C, double* wsd);
 int aas_bn_apply(aasStream_t stream, const float* x, float* y, int64_t R, int C, const float* gamma, const float* beta,
                  float eps, float slope, float* stats, float* running_mean, float* running_var, float momentum,
-                 const double* wsd, const double* d_rows);
+                 const double* wsd, const double* d_rows, long long* num_batches_tracked);
 int aas_bn_bwd_reduce(aasStream_t stream, const float* x, const float* dy, int64_t R, int C, const float* gamma,
                       const float* beta, float slope, const float* stats, double* wsd);
 int aas_bn_bwd_apply(aasStream_t stream, const float* x, const float* dy, float* dx, int64_t R, int C, const float* gamma,

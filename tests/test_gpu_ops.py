@@ -554,12 +554,12 @@ def test_batchnorm_split_entry_points_and_adam_tick(ops):
     stats = torch.empty(4, C, device="cuda")
     y2 = torch.empty_like(x)
     check(L.aas_bn_stats(stream(), ptr(x), Rr, C, ptr(red)))
-    check(L.aas_bn_apply(stream(), ptr(x), ptr(y2), Rr, C, ptr(g), ptr(b), 1e-5, 128.0, ptr(stats), None, None, 0.1, ptr(red), None))
+    check(L.aas_bn_apply(stream(), ptr(x), ptr(y2), Rr, C, ptr(g), ptr(b), 1e-5, 128.0, ptr(stats), None, None, 0.1, ptr(red), None, None))
     assert torch.equal(y2, y.detach())
     red[:2 * C] *= 2.0
     red[2 * C] = 2.0 * Rr
     y3 = torch.empty_like(x)
-    check(L.aas_bn_apply(stream(), ptr(x), ptr(y3), Rr, C, ptr(g), ptr(b), 1e-5, 128.0, ptr(stats), None, None, 0.1, ptr(red), ptr(red[2 * C:])))
+    check(L.aas_bn_apply(stream(), ptr(x), ptr(y3), Rr, C, ptr(g), ptr(b), 1e-5, 128.0, ptr(stats), None, None, 0.1, ptr(red), ptr(red[2 * C:]), None))
     xx = torch.cat([x, x], 0).cpu()
     ref = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(xx, None, None, g.cpu(), b.cpu(), True, 0.1, 1e-5), 128.0)[:Rr]
     assert rel_err(y3, ref) < 1e-5

@@ -316,6 +316,15 @@ def test_batchnorm_partial_sum_path_vs_fp64_and_atomic_path(gpu, R_, C, slope):
     assert rel_err(red[:C], x.double().sum(0)) < 1e-6 and rel_err(red[C:], (x.double() ** 2).sum(0)) < 1e-6
     y2, st = torch.empty_like(x), torch.empty((4, C), device=gpu)
     rm, rv = torch.zeros(C, device=gpu), torch.ones(C, device=gpu)
+    nbt = torch.full((1,), 41, device=gpu, dtype=torch.int64)     # nn.BatchNorm1d's num_batches_tracked: += 1 inside the apply launch
     check(lib().aas_bn_apply(stream(), ptr(x), ptr(y2), R_, C, ptr(gamma), ptr(beta), 1e-5, float(slope), ptr(st), ptr(rm), ptr(rv), 0.1,
-                             ptr(red), None), "aas_bn_apply")
+                             ptr(red), None, ptr(nbt)), "aas_bn_apply")
     assert rel_err(y2, new[0]) < 1e-6 and rel_err(rm, new[4]) < 1e-6 and rel_err(rv, new[5]) < 1e-6
+    assert int(nbt.item()) == 42
+    for fl in (0, 32768):
+        lib().aas_set_debug_flags(fl)
+        try:
+            ops.batchnorm_rows(x, gamma, beta, rm, rv, 1e-5, 0.1, slope, nbt)
+        finally:
+            lib().aas_set_debug_flags(0)
+    assert int(nbt.item()) == 44
