@@ -406,9 +406,16 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                         // four independent accumulation chains (k mod 4): back-to-back issue without waiting on the previous result
                         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
                         if (!(p.flags & 2)) {
+                            // (the tile reads run AHEAD of the MFMAs that use them: eight 16-byte reads in flight)
+                            constexpr int AH = 8;
+                            f32x4 dq[AH];
+#pragma unroll
+                            for (int i = 0; i < AH; ++i) dq[i] = *reinterpret_cast<const f32x4*>(arow + i * 4);
 #pragma unroll
                             for (int k4 = 0; k4 < KT / 4; ++k4) {
-                                const f32x4 dv = *reinterpret_cast<const f32x4*>(arow + k4 * 4);
+                                const f32x4 dv = dq[k4 % AH];
+                                if (k4 + AH < KT / 4) dq[k4 % AH] = *reinterpret_cast<const f32x4*>(arow + (k4 + AH) * 4);
+                                __builtin_amdgcn_sched_barrier(0);   // (keep the read ahead: the scheduler would sink it to its use)
                                 c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[cg][k4 * 4 + 0], dv[0], c0, 0, 0, 0);
                                 c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[cg][k4 * 4 + 1], dv[1], c1, 0, 0, 0);
                                 c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[cg][k4 * 4 + 2], dv[2], c2, 0, 0, 0);
