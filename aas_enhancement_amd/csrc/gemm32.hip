@@ -324,14 +324,12 @@ __global__ __launch_bounds__(256) void gemm32_reduce_kernel(const float* __restr
     f32x4 s = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * N + n);
     for (int z = 1; z < ns; ++z) s += *reinterpret_cast<const f32x4*>(ws + z * slab + (int64_t)m * N + n);
     if (alpha) s = s * alpha[0];
-    if (bias) { s.x += bias[n]; s.y += bias[n + 1]; s.z += bias[n + 2]; s.w += bias[n + 3]; }
+    // (16-byte accesses: aas_gemm32_try only takes products whose C / addend / bias rows are 16-byte aligned)
+    if (bias) s += *reinterpret_cast<const f32x4*>(bias + n);
     float* cp = C + (int64_t)m * ldc + n;
-    if (addend) {
-        const float* dp = addend + (int64_t)m * ldd + n;
-        s.x += dp[0]; s.y += dp[1]; s.z += dp[2]; s.w += dp[3];
-    }
-    if (accumulate) { s.x += cp[0]; s.y += cp[1]; s.z += cp[2]; s.w += cp[3]; }
-    cp[0] = s.x; cp[1] = s.y; cp[2] = s.z; cp[3] = s.w;
+    if (addend) s += *reinterpret_cast<const f32x4*>(addend + (int64_t)m * ldd + n);
+    if (accumulate) s += *reinterpret_cast<const f32x4*>(cp);
+    *reinterpret_cast<f32x4*>(cp) = s;
 }
 
 __device__ float g_zero_block[64];   // zero-initialised: where out-of-range lanes of an LDS-DMA fetch from
