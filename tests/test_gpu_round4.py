@@ -328,3 +328,63 @@ def test_batchnorm_partial_sum_path_vs_fp64_and_atomic_path(gpu, R_, C, slope):
         finally:
             lib().aas_set_debug_flags(0)
     assert int(nbt.item()) == 44
+
+
+@pytest.mark.parametrize("T,N,H,cus", [(40, 30, 500, 128), (40, 60, 500, 128), (25, 26, 500, 128), (25, 60, 500, 0), (30, 13, 320, 64),
+                                      (3, 30, 500, 128), (1, 30, 500, 128), (12, 70, 500, 128), (16, 30, 264, 128)])
+def test_lstm_bptt_fp32_vs_fp64_recurrence_on_capped_grids(gpu, T, N, H, cus):
+    """fp32 LSTM BPTT (nn.LSTM backward under model.py:94-95,101-105) against the recurrence in fp64 on the host, on the grids the
+    training step uses (CU budgets of 128 / 64 and the whole chip): row groups of 4 / 8 rows on the 4 x 4 x 1 block kernels (tile
+    reads running ahead of the MFMAs), 16 rows on the 16 x 16 x 4 tile kernels (debug bit 268435456 forces them everywhere), ragged
+    last groups, row chunks over several launches (N = 70), T = 1 and T = 3; run-to-run identical; no timeout."""
+    import os
+    from aas_enhancement_amd import _lib, ops
+    L = _lib.lib()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(11)
+    R = lambda *shape, scale=1.0: (torch.randn(*shape, generator=g) * scale).to(dev)
+    ops.set_precision(0)
+    L.aas_set_rnn_cu_limit(cus)
+    try:
+        w = [R(4 * H, H, scale=1.0 / H ** 0.5) for _ in range(2)]
+        pre, dy = R(T, N, 2, 4 * H), R(T, N, H)
+        sync, xc = ops._sync_buf(torch.device(dev, 0)), ops._xchg_buf(torch.device(dev, 0), T, N, H, 4)
+        s, p = _lib.stream(), _lib.ptr
+        hout, gact = torch.zeros(2, T, N, H, device=dev), torch.zeros(2, T, N, H, 4, device=dev)
+        cst = torch.zeros(2, T, N, H, device=dev)
+        ops.check(L.aas_lstm_fwd(s, T, N, H, p(pre), p(w[0]), p(w[1]), p(hout), p(gact), p(cst), p(sync), p(xc)), "fwd")
+        res = {}
+        for fl in (268435456, 0, 0):
+            L.aas_set_debug_flags(fl)
+            dgx = torch.zeros(T, N, 2, 4 * H, device=dev)
+            ops.check(L.aas_lstm_bwd(s, T, N, H, p(dy), p(w[0]), p(w[1]), p(gact), p(cst), p(dgx), p(sync), p(xc)), "bwd")
+            torch.cuda.synchronize()
+            assert not ops.rnn_timeout_flag()
+            res.setdefault(fl, []).append(dgx.clone())
+        assert torch.equal(res[0][0], res[0][1])                       # run to run
+        a, b = res[0][0], res[268435456][0]
+        assert torch.isfinite(a).all() and a.abs().max() > 0
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7
+        gd, cd = gact.double().cpu(), cst.double().cpu()
+        want = torch.zeros(T, N, 2, 4 * H, dtype=torch.float64)
+        for d_ in range(2):
+            W = w[d_].double().cpu()
+            dh_rec = torch.zeros(N, H, dtype=torch.float64)
+            dc_next = torch.zeros(N, H, dtype=torch.float64)
+            for t in (range(T - 1, -1, -1) if d_ == 0 else range(T)):
+                tq = t - 1 if d_ == 0 else t + 1
+                ig, fg, gg, og = gd[d_, t, :, :, 0], gd[d_, t, :, :, 1], gd[d_, t, :, :, 2], gd[d_, t, :, :, 3]
+                c_t = cd[d_, t]
+                cp = cd[d_, tq] if 0 <= tq < T else torch.zeros_like(c_t)
+                dh = dy[t].double().cpu() + dh_rec
+                tc = torch.tanh(c_t)
+                dc = dh * og * (1 - tc * tc) + dc_next
+                dc_next = dc * fg
+                dg = torch.cat([dc * gg * ig * (1 - ig), dc * cp * fg * (1 - fg), dc * ig * (1 - gg * gg), dh * tc * og * (1 - og)], dim=1)
+                want[t, :, d_] = dg
+                dh_rec = dg @ W
+        assert rel_err(a, want) < 2e-5 and rel_err(b, want) < 2e-5
+    finally:
+        L.aas_set_debug_flags(0)
+        L.aas_set_rnn_cu_limit(0)
+        ops.set_precision(int(os.environ.get("AAS_PRECISION", "0")))
