@@ -23,6 +23,7 @@ SIGNATURES = {
     "aas_last_error": [],
     "aas_device_cus": [],
     "aas_set_debug_flags": [c_int],
+    "aas_get_debug_flags": [],
     "aas_set_precision": [c_int],
     "aas_set_rnn_launch_tag": [c_int],
     "aas_set_rnn_cu_limit": [c_int],
@@ -105,15 +106,16 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, c_int)
-        if os.environ.get("AAS_WGRAD_WGS"):               # grid cap of the row-major weight-gradient GEMM (0 = none)
-            L.aas_set_wgrad_wg_cap(int(os.environ["AAS_WGRAD_WGS"]))
-        if os.environ.get("AAS_DEBUG_FLAGS"):             # A/B kernel-selection bits of aas_set_debug_flags (include/aas_hip.h)
-            L.aas_set_debug_flags(int(os.environ["AAS_DEBUG_FLAGS"]))
+        from . import knobs                               # ablation switches: defaults unless AAS_ABLATION=1 (knobs.py)
+        if knobs.get("WGRAD_WGS"):                        # grid cap of the row-major weight-gradient GEMM (0 = none)
+            L.aas_set_wgrad_wg_cap(int(knobs.get("WGRAD_WGS")))
+        if knobs.get("DEBUG_FLAGS"):                      # A/B kernel-selection bits of aas_set_debug_flags (include/aas_hip.h)
+            L.aas_set_debug_flags(int(knobs.get("DEBUG_FLAGS")))
         # The host side above this binding is the TRAINING STEP: its GEMMs run beside persistent recurrent launches that become
         # resident only when enough CUs are free at once, so a GEMM workgroup lives at most 48 k-steps (~0.1 ms) here - deeper
         # products are split further along K.  Same box, config-2 fp32 step: no cap 28.6 ms, 48: 27.55, 24: 27.7.  (The C library's
         # own default is no cap: the best choice for a product alone on the chip.)
-        L.aas_set_gemm_max_steps(int(os.environ.get("AAS_GEMM32_MAXSTEPS", "48")))
+        L.aas_set_gemm_max_steps(int(knobs.get("GEMM32_MAXSTEPS")))
         if os.environ.get("AAS_PRECISION") in ("0", "1", "2"):  # 0 = fp32 MFMA (library default), 1 = split-bf16 fast mode
             L.aas_set_precision(int(os.environ["AAS_PRECISION"]))
         _lib = L

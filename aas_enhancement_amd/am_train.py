@@ -19,7 +19,7 @@ import time
 import numpy as np
 import torch
 
-from . import ops
+from . import knobs, ops
 from .ctc import CTCLoss
 from .decoder import GreedyDecoder
 from .dist import BucketReducer, DeviceCounts, DPContext, FlatBuffers
@@ -32,12 +32,12 @@ from .utils import AverageMeter, _get_variable_nograd
 # fp32-class modes - with 15 rows per workgroup instead of 8 the MFMA-bound BPTT launch issues the same 16-row tiles, and the
 # weight-gradient GEMMs get the other half (config 5: 14.4 -> 13.5 ms); the latency-bound split-bf16 mode keeps the whole device
 # (7.2 vs 8.1 ms).
-_FWD_CUS = int(os.environ.get("AAS_AM_FWD_CUS", "0"))
+_fwd_cus = lambda: int(knobs.get("AM_FWD_CUS"))
 
 
 def _bwd_cus():
-    if os.environ.get("AAS_AM_BWD_CUS") is not None:
-        return int(os.environ["AAS_AM_BWD_CUS"])
+    if knobs.get("AM_BWD_CUS") is not None:
+        return int(knobs.get("AM_BWD_CUS"))
     return 0 if ops._precision[0] == 1 else ops.device_cus() // 2
 
 
@@ -127,7 +127,7 @@ class AMTrainer(object):
             self._reducer.begin()
             ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
         try:
-            ops.set_rnn_cu_limit(_FWD_CUS)
+            ops.set_rnn_cu_limit(_fwd_cus())
             out = self.model(inputs).transpose(0, 1)
             loss = self.criterion(out, targets, sizes, target_sizes, prepared=meta)
             loss = loss * (1.0 / counts.get(0)).float() if self.dp.active else loss / N

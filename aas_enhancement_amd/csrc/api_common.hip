@@ -1,4 +1,5 @@
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -29,6 +30,12 @@ int aas_debug_flags_value() { return g_debug_flags; }
 extern "C" int aas_set_debug_flags(int flags) {
     g_debug_flags = flags;
     return 0;
+}
+extern "C" int aas_get_debug_flags(void) { return g_debug_flags; }
+
+const char* aas_ablation_env(const char* name) {
+    static const bool on = getenv("AAS_ABLATION") && atoi(getenv("AAS_ABLATION")) == 1;
+    return on ? getenv(name) : nullptr;
 }
 
 // 0 (default) = fp32-input MFMA everywhere, the reference's arithmetic; 1 = split-bf16 (hi/lo, 3 MFMAs) fast mode

@@ -13,6 +13,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 void aas_set_error(const char* fmt, ...);
 int aas_debug_flags_value();
+// Experiment switches of the kernels are read from the environment only when AAS_ABLATION=1 is exported with them (the
+// host side's aas_enhancement_amd/knobs.py applies the same rule): a stray AAS_* variable cannot change a product run.
+const char* aas_ablation_env(const char* name);
 int aas_precision_value();
 int aas_wgrad_wg_cap();                       // 0 = no cap on the grid of aas_gemm_planes_tn
 void aas_note_fwd_h_planes(int pitch_bytes);  // what the last forward recurrent launch left in its exchange buffer (0: nothing usable)

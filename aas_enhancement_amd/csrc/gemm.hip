@@ -449,7 +449,7 @@ void launch(const GemmP& p, bool va, bool vb, dim3 grid, hipStream_t s) {
     // eight waves per workgroup whenever both operands take 16-byte loads (debug bit 1073741824: always four; AAS_GEMM_W8_MAX=n: only
     // for grids below n workgroups).  Same box, config-2 step: four waves 31.7-31.8 ms, eight waves below 512 workgroups 30.9-31.1,
     // always 30.8; alone on the chip the 2000 x 500 x 6000 weight-gradient product 0.176 -> 0.149 ms, the GRU's 0.255 -> 0.204.
-    static const int64_t w8_max = getenv("AAS_GEMM_W8_MAX") ? atoll(getenv("AAS_GEMM_W8_MAX")) : (int64_t)1 << 40;
+    static const int64_t w8_max = aas_ablation_env("AAS_GEMM_W8_MAX") ? atoll(aas_ablation_env("AAS_GEMM_W8_MAX")) : (int64_t)1 << 40;
     const bool w8 = va && vb && (int64_t)grid.x * grid.y * grid.z < w8_max && !(p.flags & 1073741824);
     if (w8) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, true, true>), grid, dim3(512), 0, s, p);
     else if (va && vb) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, true>), grid, dim3(256), 0, s, p);
@@ -493,7 +493,7 @@ static int gemm_f32_impl(aasStream_t stream, int mode, int M, int N, int K, cons
     // epilogue traffic (splitk x MxN x 4 B at ~1.3 TB/s) stays far below the time saved
     // fp32 kernel (eight light waves per workgroup, up to four workgroups per CU): two workgroups per CU for every mode
     // (config-2 step, same box: target 256: 30.9 ms, 384: 30.7-30.9, 512: 30.55-30.6, 640: 30.65-30.7, 1024: 31.2, 128: 32.6-33.1)
-    static const int sk_target = getenv("AAS_GEMM_SK_TARGET") ? atoi(getenv("AAS_GEMM_SK_TARGET")) : 0;   // experiment switch
+    static const int sk_target = aas_ablation_env("AAS_GEMM_SK_TARGET") ? atoi(aas_ablation_env("AAS_GEMM_SK_TARGET")) : 0;   // experiment switch
     const int target = sk_target > 0 ? sk_target : (!split_prec || mode == AAS_GEMM_TN) ? 512 : 256;
     if (batch == 1 && blocks < (target * 3) / 4 && K >= 1024) {
         int want = (target + blocks - 1) / blocks;

@@ -375,7 +375,7 @@ int launch32(G32& p, dim3 grid, hipStream_t s) {
     constexpr int LDS0 = NSTAGE * (2 * TMW * 128 + OPB);
     // experiment (AAS_GEMM32_WHOLE_CU=1): ask for more than half of a CU's LDS, so a workgroup has its CU to itself and hands the
     // WHOLE CU back when it retires - a persistent recurrent launch waiting for residency needs whole CUs
-    static const bool whole = getenv("AAS_GEMM32_WHOLE_CU") && atoi(getenv("AAS_GEMM32_WHOLE_CU")) != 0;
+    static const bool whole = aas_ablation_env("AAS_GEMM32_WHOLE_CU") && atoi(aas_ablation_env("AAS_GEMM32_WHOLE_CU")) != 0;
     const int LDS = whole ? 84 * 1024 : LDS0;
     static bool attr_done = false;
     if (!attr_done) {
@@ -424,8 +424,8 @@ double cost_us(int M, int N, int K, int nz, int bm, int s, int* slabs = nullptr)
 }
 
 double choose(int M, int N, int K, int nz, bool can_split, int& tmw, int& sk) {
-    static const int f_bm = getenv("AAS_GEMM32_BM") ? atoi(getenv("AAS_GEMM32_BM")) : 0;
-    static const int f_sk = getenv("AAS_GEMM32_SK") ? atoi(getenv("AAS_GEMM32_SK")) : 0;
+    static const int f_bm = aas_ablation_env("AAS_GEMM32_BM") ? atoi(aas_ablation_env("AAS_GEMM32_BM")) : 0;
+    static const int f_sk = aas_ablation_env("AAS_GEMM32_SK") ? atoi(aas_ablation_env("AAS_GEMM32_SK")) : 0;
     // longest life of a workgroup in k-steps (~2 us each): a persistent recurrent launch of the training step becomes resident only
     // when enough CUs are free AT ONCE, so a GEMM beside it must hand its CUs back soon (0 = no cap)
     const int max_steps = aas_gemm_max_steps_value();
@@ -462,12 +462,12 @@ extern "C" int aas_set_gemm_variant(int v) {
 }
 
 int aas_gemm_max_steps_value() {
-    if (g_max_steps < 0) g_max_steps = getenv("AAS_GEMM32_MAXSTEPS") ? atoi(getenv("AAS_GEMM32_MAXSTEPS")) : 0;
+    if (g_max_steps < 0) g_max_steps = aas_ablation_env("AAS_GEMM32_MAXSTEPS") ? atoi(aas_ablation_env("AAS_GEMM32_MAXSTEPS")) : 0;
     return g_max_steps;
 }
 
 int aas_gemm_variant_value() {
-    if (g_variant < 0) g_variant = (getenv("AAS_GEMM32") && atoi(getenv("AAS_GEMM32")) == 0) ? 1 : 0;
+    if (g_variant < 0) g_variant = (aas_ablation_env("AAS_GEMM32") && atoi(aas_ablation_env("AAS_GEMM32")) == 0) ? 1 : 0;
     return g_variant;
 }
 

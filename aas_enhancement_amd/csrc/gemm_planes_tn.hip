@@ -297,7 +297,7 @@ int launch_tn(PTN& p, const int* h_M, const int* h_N, int count, hipStream_t s) 
     // Two shares bring the fp32-equivalent mode's weight-gradient error from 1.2-1.5x the fp32 mode's down to it (shorter
     // accumulation chains, as the fp32 GEMM's split-K has), but every launch then pays ~40 us of atomics: config-2 step
     // 23.6 -> 25.5 ms (four shares 28.6), fast mode 16.0 -> 17.2 - so it stays an option.
-    static const int ks_env = getenv("AAS_TN_KSPLIT") ? atoi(getenv("AAS_TN_KSPLIT")) : 1;
+    static const int ks_env = aas_ablation_env("AAS_TN_KSPLIT") ? atoi(aas_ablation_env("AAS_TN_KSPLIT")) : 1;
     int ksplit = ks_env;
     if (ksplit > 8) ksplit = 8;
     if (!p.accumulate || ksplit < 1) ksplit = 1;

@@ -1,0 +1,125 @@
+"""Schedule / kernel-selection switches of the hot path - the ONE place they live.
+
+The shipped configuration is the table of defaults below.  In normal operation nothing here is read from the environment:
+a switch that changes results or timing (`SKIP_WGRAD` drops the weight-gradient products altogether) must not be flippable
+by a stray `AAS_*` variable in a product path.  Who may turn them:
+
+  * tests and the A/B tooling, through this API: `knobs.override(NAME=value)` (context manager) / `knobs.set(NAME, value)`;
+  * a developer shell, by exporting `AAS_ABLATION=1` TOGETHER with `AAS_<NAME>=...` (tools/ab.sh does) - without
+    `AAS_ABLATION=1` such variables are ignored and named once on stderr.
+
+`active()` returns every switch that differs from its default; `bench.py` refuses to print a headline value while it is
+non-empty (or while the library's debug flags are non-zero) unless `--allow-ablation` labels the line as an ablation run.
+`AAS_PRECISION` (the documented arithmetic-mode selector of a whole run), `AAS_DP_FORCE`, `AAS_NO_PIN` and
+`AAS_BENCH_FORCE_SPAWN` are run configuration, not ablation switches, and are not handled here.
+"""
+import contextlib
+import os
+import sys
+
+# name -> (default, parser)
+_b = lambda s: str(s).strip().lower() in ("1", "true", "yes", "on")
+_i = int
+_s = str
+_opt_i = lambda s: None if s in ("", "None", "auto") else int(s)
+
+_TABLE = {
+    # ---- results-changing (timing experiments only; never in a product run)
+    "SKIP_WGRAD": (False, _b),        # drop every weight-gradient product: "how much of the step do they hold"
+    "DEBUG_FLAGS": (0, _i),           # aas_set_debug_flags bits (include/aas_hip.h): A/B kernel selection
+    # ---- schedule of the AAS step (trainer_AAS.py)
+    "OVERLAP_ASR": (True, _b),        # acoustic chain on a second stream beside the discriminator chain
+    "INTERLEAVE": (True, _b),         # the two chains queued layer by layer in alternation
+    "TWO_LANES": ("auto", _s),        # auto | 1 | 0: two-lane schedule (ragged noisy / clean pairs) vs batched D
+    "PAIR_BWD": ("auto", _s),         # auto | 0 | 1: one autograd call over both chains' losses
+    "NEUTRAL_BWD": (True, _b),
+    "BWD_FROM": ("neutral", _s),
+    "ASR_EXACT": (False, _b),         # acoustic model pinned to fp32 in the fast modes
+    "EARLY_ADAM": (True, _b),         # D's Adam step on the weight-gradient stream, beside E's backward
+    "DEFER_WGRAD": (False, _b),
+    "DEFER_D_LAYERS": (None, _opt_i),  # None = 2 (0 in the fp32-equivalent mode): D's top layers' products held back until E's backward
+    "DEFER_A_LAYERS": (0, _i),
+    "EBWD_CUS": (128, _i),            # CU budget of E's BPTT launches (the rest runs E's weight-gradient products)
+    "LANE_CUS": (0, _i),
+    "AC_BWD_CUS": (0, _i),            # trainer_acoustic
+    "AM_FWD_CUS": (0, _i),            # am_train
+    "AM_BWD_CUS": (None, _opt_i),
+    # ---- streams
+    "CHAIN_LANES": (False, _b),       # CU-masked lane streams (measured slower)
+    "CHAIN_PRIO": (False, _b),
+    "WGRAD_LANE": ("", _s),
+    "WGRAD_PRIO": (True, _b),
+    "WGRAD_EARLY": (True, _b),
+    "WGRAD_WGS": (0, _i),             # grid cap of the row-major weight-gradient GEMM
+    # ---- kernel-path selection (ops.py)
+    "LINEAR_DIRECT": (True, _b),
+    "PLANES_PRE": (True, _b),
+    "PLANES_BWD": (True, _b),
+    "PLANES_EMIT": (True, _b),
+    "TN_FOLD": (False, _b),
+    "CLASS_WGRAD": (True, _b),
+    "MULTI_WGRAD": (True, _b),
+    "TN_WGRAD": (True, _b),
+    "FUSED_GLUE": (True, _b),         # step prologue / epilogue launches instead of torch eager glue
+    "GEMM32_MAXSTEPS": (48, _i),      # lifetime cap (k-steps) of a GEMM workgroup inside the training step
+}
+
+_values = {k: v[0] for k, v in _TABLE.items()}
+_listeners = []     # callables(name, value): module-level mirrors (ops.PLANES_PRE[0] ...) and library setters
+_warned = [False]
+
+
+def _load_env():
+    names = [k for k in _TABLE if ("AAS_" + k) in os.environ]
+    if not names:
+        return
+    if os.environ.get("AAS_ABLATION", "0") != "1":
+        if not _warned[0]:
+            _warned[0] = True
+            sys.stderr.write("[aas] ignoring %s: ablation switches are read from the environment only with AAS_ABLATION=1 "
+                             "(aas_enhancement_amd/knobs.py)\n" % ", ".join("AAS_" + n for n in names))
+        return
+    for n in names:
+        _values[n] = _TABLE[n][1](os.environ["AAS_" + n])
+
+
+_load_env()
+
+
+def get(name):
+    return _values[name]
+
+
+def set(name, value):   # noqa: A001  (module-level API: knobs.set)
+    """Test / A-B API: turn one switch for the rest of the process (or until set back)."""
+    if name not in _TABLE:
+        raise KeyError("unknown knob %r" % (name,))
+    _values[name] = value
+    for fn in _listeners:
+        fn(name, value)
+
+
+def on_change(fn):
+    _listeners.append(fn)
+
+
+@contextlib.contextmanager
+def override(**kw):
+    """`with knobs.override(TWO_LANES="1", EBWD_CUS=96): ...` - previous values back on exit."""
+    prev = {k: _values[k] for k in kw}
+    try:
+        for k, v in kw.items():
+            set(k, v)
+        yield
+    finally:
+        for k, v in prev.items():
+            set(k, v)
+
+
+def active():
+    """{name: value} of every switch that is not at its shipped default."""
+    return {k: v for k, v in _values.items() if v != _TABLE[k][0]}
+
+
+def defaults():
+    return {k: v[0] for k, v in _TABLE.items()}

@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, knobs
 from ._lib import check, lib, ptr, require_cuda, stream
 
 NT, NN, TN = 0, 1, 2
@@ -178,9 +178,9 @@ def device_cus():
 # (autograd gets None for those inputs): they are only needed at the optimiser step, so they overlap the next
 # layer's persistent BPTT launch instead of sitting on the backward critical path.  sync_wgrad() joins.
 DIRECT_WGRAD = [True]    # kill switch; the path is taken only for parameters re-homed by dist.FlatBuffers (_aas_flat_grad)
-LINEAR_DIRECT = [os.environ.get("AAS_LINEAR_DIRECT", "1") == "1"]   # pointwise linear layers take the same side-stream path
+LINEAR_DIRECT = [knobs.get("LINEAR_DIRECT")]   # pointwise linear layers take the same side-stream path
 WGRAD_HOOK = [None]      # callable(list of .grad views) run on the side stream after a layer's products are queued
-_SKIP_WGRAD = bool(int(__import__('os').environ.get('AAS_SKIP_WGRAD', '0')))
+_SKIP_WGRAD = [knobs.get("SKIP_WGRAD")]   # timing experiment only (knobs.py): never set in a product run
 _wgrad_streams = {}
 
 
@@ -219,7 +219,7 @@ def lane_stream(half, dev=None):
     return st
 
 
-CHAIN_LANES = [os.environ.get("AAS_CHAIN_LANES", "0") == "1"]   # the two chains of the AAS step on CU-masked lane streams
+CHAIN_LANES = [knobs.get("CHAIN_LANES")]   # the two chains of the AAS step on CU-masked lane streams
 
 
 def chain_stream(dev=None):
@@ -234,7 +234,7 @@ def chain_stream(dev=None):
     s = _chain_streams.get(dev)
     if s is None:
         prio = 0
-        if os.environ.get("AAS_CHAIN_PRIO", "0") == "1":
+        if knobs.get("CHAIN_PRIO"):
             try:
                 prio = min(torch.cuda.Stream.priority_range())
             except Exception:  # noqa: BLE001
@@ -245,12 +245,12 @@ def chain_stream(dev=None):
 
 def wgrad_stream(dev):
     s = _wgrad_streams.get(dev)
-    if s is None and os.environ.get("AAS_WGRAD_LANE", "") in ("0", "1"):
+    if s is None and knobs.get("WGRAD_LANE") in ("0", "1"):
         # (experiment: the weight-gradient products confined to one CU half - a masked stream of its own)
         import ctypes
         if _hip_rt[0] is None:
             _hip_rt[0] = ctypes.CDLL("libamdhip64.so")
-        half = int(os.environ["AAS_WGRAD_LANE"])
+        half = int(knobs.get("WGRAD_LANE"))
         words = (device_cus() + 31) // 32
         mask = (ctypes.c_uint32 * words)(*[(0xFFFFFFFF if ((i < words // 2) == (half == 0)) else 0) for i in range(words)])
         h = ctypes.c_void_p()
@@ -262,7 +262,7 @@ def wgrad_stream(dev):
         # lowest priority: when a persistent recurrent launch and queued weight-gradient blocks compete for CUs, the
         # recurrent grid (which must become fully resident) is dispatched first
         prio = 0
-        if os.environ.get("AAS_WGRAD_PRIO", "1") == "1":
+        if knobs.get("WGRAD_PRIO"):
             try:
                 prio = max(torch.cuda.Stream.priority_range())
             except Exception:  # noqa: BLE001
@@ -708,9 +708,9 @@ def linear_rows(x, W, b=None, rs=None):
 
 
 # --------------------------------------------------------------------------------------- RNN layers
-PLANES_PRE = [os.environ.get("AAS_PLANES_PRE", "1") == "1"]   # input projections of the recurrent layers on the plane GEMM
-PLANES_BWD = [os.environ.get("AAS_PLANES_BWD", "1") == "1"]   # their input-gradient and weight-gradient products too
-PLANES_EMIT = [os.environ.get("AAS_PLANES_EMIT", "1") == "1"]  # the BPTT kernels write d(gates) as operand planes (no fp32, no split)
+PLANES_PRE = [knobs.get("PLANES_PRE")]   # input projections of the recurrent layers on the plane GEMM
+PLANES_BWD = [knobs.get("PLANES_BWD")]   # their input-gradient and weight-gradient products too
+PLANES_EMIT = [knobs.get("PLANES_EMIT")]  # the BPTT kernels write d(gates) as operand planes (no fp32, no split)
 
 
 def _plane_sig(w_ih, w_ih_r, GH, I, tag):
@@ -857,15 +857,34 @@ def _wih_t_planes(w_ih, w_ih_r, GH, I):
     return wt
 
 
+def _knob_changed(name, value):
+    """knobs.set / knobs.override -> the module-level mirrors the hot path reads, and the library's own setters."""
+    global _TN_FOLD
+    mirrors = dict(LINEAR_DIRECT=LINEAR_DIRECT, SKIP_WGRAD=_SKIP_WGRAD, CHAIN_LANES=CHAIN_LANES, PLANES_PRE=PLANES_PRE, PLANES_BWD=PLANES_BWD,
+                   PLANES_EMIT=PLANES_EMIT, CLASS_WGRAD=CLASS_WGRAD, MULTI_WGRAD=MULTI_WGRAD, TN_WGRAD=TN_WGRAD)
+    if name in mirrors:
+        mirrors[name][0] = value
+    elif name == "TN_FOLD":
+        _TN_FOLD = value
+    elif name == "DEBUG_FLAGS":
+        lib().aas_set_debug_flags(int(value))
+    elif name == "WGRAD_WGS":
+        lib().aas_set_wgrad_wg_cap(int(value))
+    elif name == "GEMM32_MAXSTEPS":
+        lib().aas_set_gemm_max_steps(int(value))
+
+
+knobs.on_change(_knob_changed)
+
 _GATES = {"lstm": 4, "gru": 3, "rnn": 1}
 # fp32 mode: per-utterance weights folded into the weight-gradient GEMM (aas_gemm_tn_rowscaled_f32) instead of a scaling pass over
 # d(gates).  Measured on one box (tools/ab.sh): 32.5-32.6 ms / step with the fold against 31.8 without - the products then start right
 # behind the BPTT launch and take CUs from the input-gradient GEMM on the critical path, and the per-row weight lengthens the TN
 # kernel's prefetch - so it is off by default.
-_TN_FOLD = os.environ.get("AAS_TN_FOLD", "0") == "1"
-CLASS_WGRAD = [os.environ.get("AAS_CLASS_WGRAD", "1") == "1"]   # ... per utterance class with alpha (no scaled copies of x / h)
-MULTI_WGRAD = [os.environ.get("AAS_MULTI_WGRAD", "1") == "1"]   # fp32 arithmetic: a layer's four weight-gradient products as one aas_gemm_f32_multi launch
-TN_WGRAD = [os.environ.get("AAS_TN_WGRAD", "1") == "1"]   # weight-gradient products from row-major planes (aas_gemm_planes_tn)
+_TN_FOLD = knobs.get("TN_FOLD")
+CLASS_WGRAD = [knobs.get("CLASS_WGRAD")]   # ... per utterance class with alpha (no scaled copies of x / h)
+MULTI_WGRAD = [knobs.get("MULTI_WGRAD")]   # fp32 arithmetic: a layer's four weight-gradient products as one aas_gemm_f32_multi launch
+TN_WGRAD = [knobs.get("TN_WGRAD")]   # weight-gradient products from row-major planes (aas_gemm_planes_tn)
 
 
 def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None):
@@ -1132,7 +1151,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         return True
 
     def wgrads(out, acc):
-        if _SKIP_WGRAD:  # timing experiment only (AAS_SKIP_WGRAD=1): how much of the step the weight-gradient products hold
+        if _SKIP_WGRAD[0]:  # timing experiment only (knobs.SKIP_WGRAD): how much of the step the weight-gradient products hold
             return
         nonlocal dgx, dgh
         if use_planes6 and acc and T > 1 and wgrads_tn6(out):
@@ -1228,7 +1247,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         # the critical path (32.5 vs 31.8 ms)
         fold_ok = _precision[0] == 0 and _TN_FOLD and all(o.is_contiguous() for o in direct)
         no_mutation = use_planes or use_planes6 or rs is None or fold_ok
-        ev = ev_bptt if (no_mutation and T > 1 and os.environ.get("AAS_WGRAD_EARLY", "1") == "1") else torch.cuda.Event()
+        ev = ev_bptt if (no_mutation and T > 1 and knobs.get("WGRAD_EARLY")) else torch.cuda.Event()
         if ev is not ev_bptt:
             ev.record(main)
         hook = WGRAD_HOOK[0]

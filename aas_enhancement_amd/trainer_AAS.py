@@ -18,7 +18,7 @@ from shutil import copyfile
 
 import torch
 
-from . import ops
+from . import knobs, ops
 from .ctc import CTCLoss
 from .decoder import GreedyDecoder
 from .model import DeepSpeech, L1Loss_mask, stackedBRNN, supported_rnns
@@ -308,7 +308,7 @@ class Trainer(object):
             leaf_a.grad.record_stream(torch.cuda.current_stream())
             # (on logging iterations the adversarial part was already back-propagated for g_adv)
             gsum = ops.add3(leaf.grad, leaf_a.grad) if leaf.grad is not None else leaf_a.grad
-            ops.set_rnn_cu_limit(int(os.environ.get("AAS_EBWD_CUS", "128")))  # leave CUs to E's weight-gradient GEMMs
+            ops.set_rnn_cu_limit(knobs.get("EBWD_CUS"))  # leave CUs to E's weight-gradient GEMMs
             enhanced.backward(gsum)
             ops.set_rnn_cu_limit(0)
             if log_norms:
@@ -455,7 +455,7 @@ class Trainer(object):
         if self._interleave_ok():
             # the discriminator's weight-gradient products are held back while the two BPTT chains run (they slow the chains'
             # cross-CU exchange) and released into E's backward phase, where half of the chip has little else to do
-            ops.DEFER_WGRAD[0] = os.environ.get("AAS_DEFER_WGRAD", "0") == "1"   # (measured: no gain, 19.0 vs 19.2 ms - kept as a switch)
+            ops.DEFER_WGRAD[0] = knobs.get("DEFER_WGRAD")   # (measured: no gain, 19.0 vs 19.2 ms - kept as a switch)
             # The weight-gradient products of the layers that are back-propagated FIRST (D's - and a trainable A's - top layers)
             # are held back until E's backward: beside the two BPTT chains every CU is taken and the products only slow the chains
             # down, beside E's backward half of the chip is free.  Not all of them: E's backward phase has room for about two D
@@ -465,8 +465,9 @@ class Trainer(object):
             #  with the eight-wave fp32 GEMM; with the four-wave one the weight-gradient stream was saturated and 0 was best)
             # (fp32-equivalent mode, with the six-product BPTT: 0 / 1 / 2 = 23.9-24.2 / 24.1-24.2 / 24.5-24.6 ms - its weight-gradient
             #  products are cheap enough to run beside the chains)
-            for net, env, dflt in ((self.D, "AAS_DEFER_D_LAYERS", 0 if ops._precision[0] == 2 else 2), (self.ASR, "AAS_DEFER_A_LAYERS", 0)):
-                ndef = int(os.environ.get(env, str(dflt)))
+            for net, knob, dflt in ((self.D, "DEFER_D_LAYERS", 0 if ops._precision[0] == 2 else 2), (self.ASR, "DEFER_A_LAYERS", 0)):
+                ndef = knobs.get(knob)
+                ndef = dflt if ndef is None else int(ndef)
                 if ndef > 0:
                     lids = [m._aas_layer_id for m in net.modules() if getattr(m, "_aas_layer_id", None) is not None]
                     ops.DEFER_LIDS.update(lids[-ndef:])
@@ -489,15 +490,17 @@ class Trainer(object):
         torch.cuda.current_stream().wait_stream(self._side)
         # E's BPTT launches are capped too: the CUs they leave free run E's weight-gradient GEMMs (side stream), which would
         # otherwise wait for each fully-resident 512-thread launch to retire
-        ops.set_rnn_cu_limit(int(os.environ.get("AAS_EBWD_CUS", "128")))
+        ops.set_rnn_cu_limit(knobs.get("EBWD_CUS"))
         leaf_a.grad.record_stream(torch.cuda.current_stream())
         gsum = ops.add3(leaf.grad, leaf_a.grad)
+        if getattr(self, "keep_enh_grads", False):   # parity gates / tests: the two gradients arriving at `enhanced` (:148, :170)
+            self._enh_grads = (leaf.grad, leaf_a.grad)
         ops.flush_deferred_wgrad()
         if dp.active:   # D's (and a trainable A's) small parameters; their layer buckets are in flight: overlaps E's backward
             self._reducer.flush(self._flat["D"])
             if asr_steps:
                 self._reducer.flush(self._flat["A"])
-        elif (os.environ.get("AAS_EARLY_ADAM", "1") == "1" and not torch.cuda.is_current_stream_capturing()
+        elif (knobs.get("EARLY_ADAM") and not torch.cuda.is_current_stream_capturing()
               and ops.DIRECT_WGRAD[0] and ops.LINEAR_DIRECT[0]):
             # D's (and a trainable A's) gradients are complete once the products queued on the weight-gradient stream have run:
             # their Adam steps and weight-plane refreshes go onto that stream now and overlap E's backward instead of
@@ -517,7 +520,7 @@ class Trainer(object):
     def _lanes_ok(self, same_shape=True):
         """AAS_TWO_LANES = auto (default): the two-lane schedule when the noisy and clean batches have different padded
         lengths (real loaders), the batched-D schedule when they are equal (0.1-0.3 ms / step faster at config 2); 1 / 0 force."""
-        mode = os.environ.get("AAS_TWO_LANES", "auto")
+        mode = str(knobs.get("TWO_LANES"))
         return self._interleave_ok() and (mode == "1" or (mode == "auto" and not same_shape))
 
     def _two_lane_core(self, inputs, cl_inputs, scales, ctc_meta, asr_steps):
@@ -541,7 +544,7 @@ class Trainer(object):
             self._side_stream = ops.chain_stream()
         side = self._side = self._side_stream
         side.wait_stream(main)
-        ops.set_rnn_cu_limit(int(os.environ.get("AAS_LANE_CUS", "0")) or ops.device_cus() // 2)
+        ops.set_rnn_cu_limit(knobs.get("LANE_CUS") or ops.device_cus() // 2)
         if dp.active:
             self._reducer.expect(self._flat["D"], 2)      # every D layer is back-propagated twice: reduce after the second
         self._wait_kt()
@@ -580,6 +583,8 @@ class Trainer(object):
         main.wait_stream(side)          # A's gradient wrt enhanced (everything queued on the side stream so far)
         leaf_a.grad.record_stream(main)
         gsum = ops.add3(leaf.grad, leaf_a.grad)
+        if getattr(self, "keep_enh_grads", False):
+            self._enh_grads = (leaf.grad, leaf_a.grad)
         torch.autograd.backward([enhanced, l_adv_cl], [gsum, None])
         main.wait_stream(side)
         if dp.active:
@@ -839,7 +844,7 @@ class Trainer(object):
         root gradients were produced there): called from the main stream, the side chain's backward would wait for everything
         queued on main - i.e. the acoustic backward for the tail of D's forward.  So the root gradients are created on the
         streams of their losses and the call is issued from a stream that has nothing queued."""
-        mode = os.environ.get("AAS_PAIR_BWD", "auto")
+        mode = str(knobs.get("PAIR_BWD"))
         if mode == "0" or (mode == "auto" and (getattr(self, "_host_ahead", False) or self.dp.active)):
             # Two independent backward calls, each issued from (and confined to) the stream of its chain: nothing ties the
             # chains together.  Right whenever the host queues ahead of the device (train_step_async), where the order in
@@ -850,7 +855,7 @@ class Trainer(object):
                 loss_side.backward()
             loss_main.backward()
             return
-        if os.environ.get("AAS_NEUTRAL_BWD", "1") != "1":
+        if not knobs.get("NEUTRAL_BWD"):
             side.wait_stream(main)
             torch.autograd.backward([loss_main, loss_side])
             return
@@ -859,7 +864,7 @@ class Trainer(object):
         g_main = torch.ones_like(loss_main)
         with torch.cuda.stream(side):
             g_side = torch.ones_like(loss_side)
-        caller = side if os.environ.get("AAS_BWD_FROM", "neutral") == "side" else self._neutral_stream
+        caller = side if knobs.get("BWD_FROM") == "side" else self._neutral_stream
         with torch.cuda.stream(caller):
             torch.autograd.backward([loss_main, loss_side], [g_main, g_side])
 
@@ -867,15 +872,15 @@ class Trainer(object):
         c = self.config
         exact_a = getattr(c, "asr_exact_fp32", None)
         if exact_a is None:
-            exact_a = os.environ.get("AAS_ASR_EXACT", "0") == "1"
+            exact_a = knobs.get("ASR_EXACT")
         # (not under hipGraph capture: replayed with the nodes of the two chains created alternately, the graph executor
         #  ran the chains strictly one after the other - 26.4 ms vs 21.7 with one chain captured after the other)
-        return (self._overlap_asr() and not exact_a and os.environ.get("AAS_INTERLEAVE", "1") == "1"
+        return (self._overlap_asr() and not exact_a and knobs.get("INTERLEAVE")
                 and not torch.cuda.is_current_stream_capturing())
 
     @staticmethod
     def _overlap_asr():
-        return os.environ.get("AAS_OVERLAP_ASR", "1") == "1"
+        return knobs.get("OVERLAP_ASR")
 
     def _acoustic_branch(self, enhanced, targets, sizes, target_sizes, N_glob, ctc_meta, scale=None):
         """A(enhanced) -> CTC/N -> backward down to a private leaf (optionally on a second stream)."""
@@ -895,7 +900,7 @@ class Trainer(object):
         self._side.wait_stream(main)
         exact_a = getattr(c, "asr_exact_fp32", None)
         if exact_a is None:
-            exact_a = os.environ.get("AAS_ASR_EXACT", "0") == "1"
+            exact_a = knobs.get("ASR_EXACT")
         prev = ops.get_precision()
         with torch.cuda.stream(self._side):
             if exact_a:

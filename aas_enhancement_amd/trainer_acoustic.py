@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from . import ops
+from . import knobs, ops
 from .trainer_AAS import Trainer as _AASTrainer
 
 
@@ -75,7 +75,7 @@ class Trainer(_AASTrainer):
             else:
                 l_CTC = self.CTCLoss(prob, targets, sizes, target_sizes, prepared=ctc_meta) / n_glob
             # (AAS_AC_BWD_CUS: CU cap of the BPTT launches, leaving CUs to the weight-gradient products beside them; 0 = whole chip)
-            ops.set_rnn_cu_limit(int(os.environ.get("AAS_AC_BWD_CUS", "0")))
+            ops.set_rnn_cu_limit(knobs.get("AC_BWD_CUS"))
             l_CTC.backward()
             ops.set_rnn_cu_limit(0)
             ops.sync_wgrad()

@@ -50,6 +50,8 @@ int aas_device_cus(void);
  *   536870912 mode 2: the exact (fp32-input MFMA) LSTM BPTT kernel instead of the six-product one,
  *   1073741824 four-wave workgroups in aas_gemm_f32 (default: eight waves where both operands take 16-byte loads). */
 int aas_set_debug_flags(int flags);
+/* the bits currently set (bench.py refuses to report a headline value while this is non-zero) */
+int aas_get_debug_flags(void);
 /* Tag (>= 1) of the persistent recurrent launches queued after the call.  Every bounded spin in those kernels gives
  * up after ~0.5 s and stores the tag of its launch in a sticky error word at byte 4096 of the launch's `sync` buffer
  * (never cleared by the library): the host reads it at its next synchronisation point and names the layer. */

@@ -122,10 +122,11 @@ def test_chain_schedules_agree_config2(gpu, monkeypatch, precision2):
     from aas_enhancement_amd.trainer_AAS import Trainer
     N, F, T, H, HA, M, L = 30, 80, 200, 500, 1000, 128, 20
     res = {}
-    for mode, env in (("serial", {"AAS_OVERLAP_ASR": "0"}), ("two_streams", {"AAS_OVERLAP_ASR": "1", "AAS_INTERLEAVE": "0"}),
-                      ("alternating", {"AAS_OVERLAP_ASR": "1", "AAS_INTERLEAVE": "1"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    from aas_enhancement_amd import knobs
+    for mode, kn in (("serial", dict(OVERLAP_ASR=False)), ("two_streams", dict(OVERLAP_ASR=True, INTERLEAVE=False)),
+                     ("alternating", dict(OVERLAP_ASR=True, INTERLEAVE=True))):
+        for k, v in kn.items():
+            monkeypatch.setitem(knobs._values, k, v)
         G, D = stackedBRNN(I=F, H=H, L=4), stackedBRNN(I=F, H=H, L=4)
         A = DeepSpeech(nn.GRU, LABELS, HA, 5, True, 11, 2, M, 2, nFreq=F)
         for m, s, cs in ((G, 9001, None), (D, 9002, None), (A, 9003, 0.1)):

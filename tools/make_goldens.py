@@ -78,13 +78,16 @@ def gnorm(model):  # trainer_AAS.py:353-361
     return float(torch.pow(g, 0.5))
 
 
-def aas_iteration(G, D, A, og, od, oa, ny, cl, cfg, kt, it, diff):
-    """trainer_AAS.py:131-194, line by line, on reference modules."""
+def aas_iteration(G, D, A, og, od, oa, ny, cl, cfg, kt, it, diff, enh_grads=None):
+    """trainer_AAS.py:131-194, line by line, on reference modules.  `enh_grads` (a list) collects, through a tensor hook that
+    changes nothing, the gradient arriving at `enhanced` in each backward pass: [adversarial (:148), CTC (:170)]."""
     G.zero_grad(); D.zero_grad(); A.zero_grad()
     inputs, targets, pct, target_sizes = t(ny["inputs"]), t(ny["targets"]), t(ny["pct"]).clone(), t(ny["target_sizes"])
     mask = t(ny["mask"]).bool()
     N = inputs.size(0)
     enhanced = G(inputs)
+    if enh_grads is not None:
+        enhanced.register_hook(lambda g: enh_grads.append(g.detach().clone().numpy()))
     enhanced_D = enhanced.detach()
     ae_ny_G = D(enhanced)
     l_adv_ny_G, _ = diff(ae_ny_G, enhanced, mask)
@@ -255,6 +258,46 @@ def f3_config2():
     np.savez_compressed(os.path.join(OUT, "f3_aas_config2.npz"), **out)
 
 
+def f3b_config2_kt():
+    """F3b: iteration 0 of config 2 with kt0 = 0.3, so that the D-step term (trainer_AAS.py:156-160) is NOT identically zero at
+    size: every parameter gradient of E, D and A as norm + 64 samples, the three networks' total gradient norms, and the two
+    gradients that arrive at `enhanced` (adversarial, CTC).  Same weights / batches as F3 iteration 0."""
+    Fdim, H, HA, M, N, T, L = 80, 500, 1000, 128, 30, 200, 20
+    G, D, A = build_aas(Fdim, H, HA, M, 5, seed=9000)
+    cfg = dict(w_adversarial=1.0, w_acoustic=1.0, gamma=0.5, lambda_k=0.001, allow_ASR_update_iter=0)
+    og, od, oa = adam(G, 1e-5), adam(D, 1e-5), adam(A, 1e-5)
+    diff = REF.L1Loss_mask()
+    kt0 = 0.3
+    out = dict(weight_seed=9000, lr=1e-5, N=N, F=Fdim, T=T, H=H, HA=HA, M=M, L=L, kt0=kt0, noisy_seed=123, clean_seed=124, label_seed=125)
+    ny = dict(inputs=prng.uniform(123, (N, Fdim, T), 0.0, 6.0), mask=np.zeros((N, 1, T), np.uint8), pct=np.ones(N, np.float32),
+              targets=prng.randint(125, (N * L,), 1, 28).astype(np.int32), target_sizes=np.full(N, L, np.int32))
+    cl = dict(inputs=prng.uniform(124, (N, Fdim, T), 0.0, 6.0), mask=np.zeros((N, 1, T), np.uint8))
+    eg = []
+    kt, sc, grads, enh, ae, prob, sizes = aas_iteration(G, D, A, og, od, oa, ny, cl, cfg, kt0, 0, diff, enh_grads=eg)
+    assert len(eg) == 2
+    for k, v in sc.items():
+        out["it0." + k] = np.float64(v)
+    ie, il = sample_idx(31, enh.shape, 256), sample_idx(41, prob.shape, 256)
+    out["it0.enh_idx"], out["it0.enh_samples"] = ie, enh.reshape(-1)[ie]
+    out["it0.logit_idx"], out["it0.logit_samples"] = il, prob.reshape(-1)[il]
+    tot = dict(G=0.0, D=0.0, A=0.0)
+    for k, g in grads.items():
+        ig = sample_idx(51, g.shape, min(64, g.size))
+        out["it0.gradsample_idx." + k] = ig
+        out["it0.gradsample." + k] = g.reshape(-1)[ig]
+        sq = float((g.astype(np.float64) ** 2).sum())
+        out["it0.gradnorm." + k] = float(np.sqrt(sq))
+        tot[k[0]] += sq
+    for nm in tot:
+        out["it0.gradnorm_total." + nm] = float(np.sqrt(tot[nm]))
+    for nm, g in (("adv", eg[0]), ("ctc", eg[1])):
+        ig = sample_idx(53, g.shape, 256)
+        out["it0.enh_grad_idx." + nm], out["it0.enh_grad_samples." + nm] = ig, g.reshape(-1)[ig]
+        out["it0.enh_grad_norm." + nm] = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+    print("F3b", sc, {k: out[k] for k in out if "total" in k or "enh_grad_norm" in k}, flush=True)
+    np.savez_compressed(os.path.join(OUT, "f3b_aas_config2_kt.npz"), **out)
+
+
 def f4_ops():
     """F4: per-op vectors from the reference's own BRNN / BatchRNN / DeepSpeech.conv / L1Loss_mask."""
     out = {}
@@ -316,6 +359,14 @@ def f4_ops():
     out["paired.a"], out["paired.b"], out["paired.y"] = xa.numpy(), xb.numpy(), Dp.forward_paired(xa, xb).detach().numpy()
     for k, v in Dp.state_dict().items():
         out["paired.sd." + k] = v.numpy().copy()
+    # stackedBRNN.forward_with_intermediate_output (model.py:240-252): [output, h4 as N x H x T]
+    Gi = REF.stackedBRNN(I=6, O=6, H=10, L=4)
+    load_weights(Gi, 611)
+    xi = t(prng.normal(612, (3, 6, 17)))
+    yo, yh = Gi.forward_with_intermediate_output(xi)
+    out["inter.x"], out["inter.y"], out["inter.h"] = xi.numpy(), yo.detach().numpy(), yh.detach().numpy()
+    for k, v in Gi.state_dict().items():
+        out["inter.sd." + k] = v.numpy().copy()
     np.savez_compressed(os.path.join(OUT, "f4_ops.npz"), **out)
     print("F4 keys", len(out))
 
@@ -690,6 +741,38 @@ def f10_acoustic():
     print("F10 keys", len(out))
 
 
+def f11_am_model_ken():
+    """F11: AM_training/model.py's own DeepSpeech_ken (:337-470), the class AM_training/train.py builds: include_first_BN
+    True / False, nDownsample 1 / 2 - forward logits, the gradient of a fixed cotangent wrt input and every parameter, and the
+    BatchNorm running statistics after the pass (tiny sizes, every tensor)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("am_ref_model", "/root/reference/AM_training/model.py")
+    AMR = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(AMR)
+    out = {}
+    for tag, kw in dict(bn=dict(include_first_BN=True, nDownsample=1), nobn=dict(include_first_BN=False, nDownsample=1),
+                        nobn_ds2=dict(include_first_BN=False, nDownsample=2), lstm_nobn=dict(include_first_BN=False, nDownsample=1)).items():
+        rt = nn.LSTM if tag.startswith("lstm") else nn.GRU
+        A = AMR.DeepSpeech_ken(rnn_type=rt, labels=LABELS, rnn_hidden_size=12, rnn_layers=3, kernel_sz=11, stride=2, map=8, cnn_layers=2,
+                               nFreq=10, **kw)
+        load_weights(A, 8300 + len(tag), conv_std=0.1)
+        p = "ken_%s." % tag
+        for k, v in A.state_dict().items():
+            out[p + "sd0." + k] = v.numpy().copy()
+        x = t(prng.uniform(8310, (3, 10, 90), 0.0, 6.0)).requires_grad_(True)
+        y = A(x)
+        gy = t(prng.normal(8311, tuple(y.shape)))
+        y.backward(gy)
+        out[p + "x"], out[p + "y"], out[p + "gy"], out[p + "gx"] = x.detach().numpy(), y.detach().numpy(), gy.numpy(), x.grad.numpy()
+        for k, v in A.named_parameters():
+            out[p + "gw." + k] = v.grad.numpy()
+        for k, v in A.state_dict().items():
+            if "running" in k:
+                out[p + "sd1." + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "f11_am_model_ken.npz"), **out)
+    print("F11 keys", len(out))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip F3 (config 2, minutes of CPU)")
@@ -698,7 +781,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if a.only:
         table = dict(f1=f1_tiny, f2=f2_dce, f3=f3_config2, f4=f4_ops, f5=f5_fsegan_am, f6=f6_fsegan_config4,
-                     f7=f7_am_config5, f8=f8_host_side, f9=f9_rnn_kind, f10=f10_acoustic)
+                     f7=f7_am_config5, f8=f8_host_side, f9=f9_rnn_kind, f10=f10_acoustic, f3b=f3b_config2_kt, f11=f11_am_model_ken)
         for k in a.only.split(","):
             table[k]()
         sys.exit(0)
@@ -708,8 +791,10 @@ if __name__ == "__main__":
     f2_dce()
     f8_host_side()
     f9_rnn_kind()
+    f11_am_model_ken()
     if not a.skip_big:
         f3_config2()
+        f3b_config2_kt()
         f6_fsegan_config4()
         f7_am_config5()
         f10_acoustic()
