@@ -24,6 +24,8 @@ SIGNATURES = {
     "aas_device_cus": [],
     "aas_set_debug_flags": [c_int],
     "aas_get_debug_flags": [],
+    "aas_get_gemm_max_steps": [],
+    "aas_release_retired_workspaces": [],
     "aas_set_precision": [c_int],
     "aas_set_rnn_launch_tag": [c_int],
     "aas_set_rnn_cu_limit": [c_int],
@@ -52,6 +54,7 @@ SIGNATURES = {
     "aas_add3_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64],
     "aas_scale_rows_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int],
     "aas_axpby_f32": [c_vp, c_vp, c_vp, c_f32, c_f32, c_i64],
+    "aas_leaky_relu_f32": [c_vp, c_vp, c_vp, c_vp, c_f32, c_i64],
     "aas_scale_dev_f32": [c_vp, c_vp, c_vp, c_vp, c_f32, c_i64],
     "aas_colsum_f32": [c_vp, c_vp, c_i64, c_int, c_i64, c_vp, c_int],
     "aas_sqsum_f32": [c_vp, c_vp, c_i64, c_vp],

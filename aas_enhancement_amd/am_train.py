@@ -14,6 +14,7 @@ import argparse
 import json
 import os
 import random
+import sys
 import time
 
 import numpy as np
@@ -41,9 +42,9 @@ def _bwd_cus():
     return 0 if ops._precision[0] == 1 else ops.device_cus() // 2
 
 
-class AMTrainer(object):
+class AMTrainer(ops.TrainerContext):
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), dp=None, labels=None, sync_bn=False, optim="adam", momentum=0.9):
-        self.precision = ops.get_precision()   # the arithmetic this trainer runs in (ops.precision)
+        self._init_context()   # arithmetic mode + launch settings this trainer runs in (ops.TrainerContext)
         self.model = model
         self.criterion = CTCLoss()
         ops.name_layers(model, "A")
@@ -202,7 +203,7 @@ class AMTrainer(object):
 
     # ---- epoch loop (:293-486) ---------------------------------------------------------------------------------
     def fit(self, train_batches, val_batches, epochs, save_path=None, best_path=None, start_epoch=0, print_every=100,
-            on_epoch_end=None, history=None, presharded=False):
+            on_epoch_end=None, history=None, presharded=False, transcript_prob=0.0):
         """`train_batches(epoch)` / `val_batches()` return iterables of batch tuples.  Writes the running package to
         `save_path` after every epoch and the best-validation-WER package to `best_path`.  Returns the history dict.
         Data parallel: `presharded` says the batches are already this rank's shard (DataLoader(dp=...)); otherwise every rank
@@ -231,7 +232,7 @@ class AMTrainer(object):
             avg_loss /= max(n_batches, 1)
             if rank0:
                 print("Training Summary Epoch: [{0}]\tAverage Loss {loss:.3f}\t".format(epoch + 1, loss=avg_loss))
-            wer, cer = self.validate(val_batches()) if val_batches is not None else (float("nan"), float("nan"))
+            wer, cer = self.validate(val_batches(), transcript_prob=transcript_prob) if val_batches is not None else (float("nan"), float("nan"))
             hist["loss_results"].append(avg_loss); hist["wer_results"].append(wer); hist["cer_results"].append(cer)
             if rank0:
                 print("Validation Summary Epoch: [{0}]\tAverage WER {wer:.3f}\tAverage CER {cer:.3f}\t".format(epoch + 1, wer=wer, cer=cer))
@@ -311,41 +312,107 @@ def weights_init(model, seed=None):
             m.bias.data.zero_()
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser(description="DeepSpeech acoustic-model CTC training (AM_training/train.py flags)")
-    ap.add_argument("--train_manifest", required=True)
-    ap.add_argument("--val_manifest", required=True)
-    ap.add_argument("--labels_path", default="labels.json")
-    ap.add_argument("--batch_size", default=30, type=int)
-    ap.add_argument("--num_workers", default=1, type=int)
-    ap.add_argument("--nFreq", default=40, type=int)
-    ap.add_argument("--rnn_size", default=1000, type=int)
-    ap.add_argument("--rnn_layers", default=5, type=int)
-    ap.add_argument("--rnn_type", default="gru")
-    ap.add_argument("--conv_map", default=128, type=int)
+def str2bool(v):
+    return str(v).lower() in ("true", "1")
+
+
+def build_parser():
+    """The reference's parser, flag for flag and default for default (AM_training/train.py:24-110), plus this build's extras at the
+    end.  A reference command line therefore trains the model the reference would: --batch_size 20 --rnn_size 500 --rnn_layers 2
+    --conv_map 256 --lr 1e-5 --epochs 300 unless told otherwise."""
+    ap = argparse.ArgumentParser(description="DeepSpeech training")
+    ap.add_argument("--DB_name", type=str, default="librispeech")
+    ap.add_argument("--expnum", type=int, default=0)
+    ap.add_argument("--train_manifest", metavar="DIR", help="path to train manifest csv", default="data/librispeech_logMel_train_manifest.csv")
+    ap.add_argument("--val_manifest", metavar="DIR", help="path to validation manifest csv", default="data/librispeech_logMel_val_manifest.csv")
+    ap.add_argument("--batch_size", default=20, type=int, help="Batch size for training")
+    ap.add_argument("--num_workers", default=1, type=int, help="Number of workers used in data-loading")
+    ap.add_argument("--labels_path", default="labels.json", help="Contains all characters for transcription")
+    # used only with --preprocess code (the reference's SpectrogramDataset); this build's LMFB kernel fixes 16 kHz / 20 ms hamming / 10 ms
+    ap.add_argument("--sample_rate", default=16000, type=int, help="Sample rate")
+    ap.add_argument("--window_size", default=.02, type=float, help="Window size for spectrogram in seconds")
+    ap.add_argument("--window_stride", default=.01, type=float, help="Window stride for spectrogram in seconds")
+    ap.add_argument("--window", default="hamming", help="Window type for spectrogram generation")
+    ap.add_argument("--rnn_size", default=500, type=int, help="Hidden size of RNNs")
+    ap.add_argument("--rnn_layers", default=2, type=int, help="Number of RNN layers")
+    ap.add_argument("--rnn_type", default="gru", help="Type of the RNN. rnn|gru|lstm are supported")
+    ap.add_argument("--conv_layers", default=2, type=int)
+    ap.add_argument("--cnn_residual_blocks", default=1, type=int)   # (ResidualDeepSpeech only: out of scope, accepted and unused)
+    ap.add_argument("--conv_map", default=256, type=int)
     ap.add_argument("--conv_kernel", default=11, type=int)
     ap.add_argument("--conv_stride", default=2, type=int)
-    ap.add_argument("--conv_layers", default=2, type=int)
-    ap.add_argument("--epochs", default=70, type=int)
-    ap.add_argument("--lr", default=1e-4, type=float)
-    ap.add_argument("--gpu", default=0, type=int)
-    ap.add_argument("--print_every", default=100, type=int)
-    ap.add_argument("--save_folder", default="models/")
-    ap.add_argument("--model_path", default="models/deepspeech_final.pth.tar")
-    ap.add_argument("--continue_from", default="")
-    ap.add_argument("--DB_name", default="librispeech")
-    ap.add_argument("--expnum", default=0, type=int)
-    ap.add_argument("--preprocess", default="file", help="file: LMFB .pt7 tensors | code: waveforms + the LMFB HIP kernel")
-    ap.add_argument("--sortagrad", default=False, type=lambda v: str(v).lower() in ("true", "1"),
-                    help="first epoch in manifest (increasing length) order, no reshuffling afterwards (train.py:109,270-272,484-486)")
+    ap.add_argument("--nFreq", default=40, type=int)
+    ap.add_argument("--n_mels", default=40, type=int)
+    ap.add_argument("--preprocess", default="file", type=str, help="file: LMFB .pt7 tensors | code: waveforms + the LMFB HIP kernel")
+    ap.add_argument("--process_mel", default=False, type=str2bool)
+    ap.add_argument("--normalize", default=False, type=str2bool)
+    ap.add_argument("--arch_ver", default="ken", type=str, help="ken (1D CNN, lReLU): the only architecture on the hot path")
+    ap.add_argument("--nDownsample", type=int, default=1)
+    ap.add_argument("--print_every", type=int, default=100)
+    ap.add_argument("--epochs", default=300, type=int, help="Number of training epochs")
+    ap.add_argument("--gpu", default=-1, type=int)
+    ap.add_argument("--lr", "--learning-rate", default=1e-5, type=float, help="initial learning rate")
+    ap.add_argument("--momentum", default=0.9, type=float, help="momentum")
+    ap.add_argument("--optim", default="adam", help="adam|sgd")
+    ap.add_argument("--one_sample_DEBUG", default=False, type=str2bool)
+    ap.add_argument("--include_first_BN", default=True, type=str2bool)
+    ap.add_argument("--log_params", dest="log_params", action="store_true", help="Log parameter values and gradients")
+    ap.add_argument("--save_folder", default="models/", help="Location to save epoch models")
+    ap.add_argument("--model_path", default="", help="Location to save best validation model (set from --DB_name / --expnum, train.py:138)")
+    ap.add_argument("--continue_from", default="", help="Continue from checkpoint model")
+    ap.add_argument("--augment", type=str2bool, default=False, help="Use random tempo and gain perturbations.")
+    ap.add_argument("--transcript_prob", type=float, default=0.002)
+    ap.add_argument("--sortagrad", default=False, type=str2bool, help="load minibatch with order of increasing length from shorter to longer")
+    # ---- this build's extras (absent from the reference)
     ap.add_argument("--precision", default=None, choices=("fp32", "fp32eq", "bf16x3"),
                     help="absent: AAS_PRECISION from the environment, else fp32 | fp32 (the reference's arithmetic) | fp32eq (fp32-equivalent six-product GEMMs) | bf16x3 (split-bf16 fast mode)")
-    ap.add_argument("--optim", default="adam", help="adam|sgd (sgd: momentum, nesterov; train.py:171-174)")
-    ap.add_argument("--momentum", default=0.9, type=float)
-    ap.add_argument("--seed", default=123456, type=int)
+    ap.add_argument("--seed", default=123456, type=int, help="torch.manual_seed (train.py:112 hard-codes 123456)")
     ap.add_argument("--dist_backend", default="nccl")
     ap.add_argument("--sync_bn", action="store_true", help="data parallel: all-reduce the BatchNorm statistics (global-batch BN)")
-    a = ap.parse_args(argv)
+    return ap
+
+
+def resolve_args(a):
+    """What train.py:128-138,201-214 derives from the flags before it builds anything; and what this build cannot honour, said loudly."""
+    if a.arch_ver != "ken":
+        raise NotImplementedError("--arch_ver %s: only 'ken' (DeepSpeech_ken, 1-D convolutions + LeakyReLU) is on the MI355X hot path; "
+                                  "ResidualDeepSpeech / ResidualCNN4block are out of scope (SURVEY.md 2)" % a.arch_ver)
+    if a.process_mel:
+        a.nFreq = a.n_mels                                      # train.py:131-132
+    a.model_path = "models/" + a.DB_name + "_" + str(a.expnum) + "_final.pth.tar"     # train.py:138 (always overwritten)
+    notes = []
+    if a.preprocess == "code":
+        if not a.process_mel:
+            raise NotImplementedError("--preprocess code without --process_mel true asks for the 161-bin log-spectrogram + CMVN features of the "
+                                      "reference's SpectrogramDataset; this build extracts log-Mel filterbank features on the GPU (LMFB kernel): "
+                                      "pass --process_mel true --n_mels N")
+        if (a.sample_rate, a.window_size, a.window_stride, a.window) != (16000, .02, .01, "hamming"):
+            raise NotImplementedError("the LMFB kernel is built for 16 kHz / 20 ms hamming window / 10 ms hop (train.py:39-42 defaults)")
+        for name in ("normalize", "augment"):
+            if getattr(a, name):
+                notes.append("--%s true is not implemented by the GPU feature extraction: ignored" % name)
+    else:
+        for name, dflt in (("sample_rate", 16000), ("window_size", .02), ("window_stride", .01), ("window", "hamming"), ("normalize", False), ("augment", False)):
+            if getattr(a, name) != dflt:
+                notes.append("--%s is used only with --preprocess code (train.py:38): ignored in file mode" % name)
+    if a.gpu < 0:
+        notes.append("--gpu -1 selects the reference's CPU path; this build has none (HIP only): running on cuda:0")
+        a.gpu = 0
+    for name in ("one_sample_DEBUG", "log_params"):
+        if getattr(a, name):
+            notes.append("--%s: accepted for command-line compatibility, no effect" % name)
+    for n_ in notes:
+        print("[am_train] " + n_, file=sys.stderr)
+    return a
+
+
+def main(argv=None):
+    ap = build_parser()
+    a, unparsed = ap.parse_known_args(argv)
+    if len(unparsed) > 0:                                       # train.py:121-125
+        print(unparsed)
+        assert len(unparsed) == 0, "length of unparsed option should be 0"
+    a = resolve_args(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         import torch.distributed as dist
@@ -368,8 +435,13 @@ def main(argv=None):
         tr, start_epoch, hist = AMTrainer.resume(a.continue_from, lr=a.lr, gpu=a.gpu, dp=dp, labels=labels, sync_bn=a.sync_bn, optim=a.optim,
                                                  momentum=a.momentum)
     else:
-        model = DeepSpeech(rnn_hidden_size=a.rnn_size, rnn_layers=a.rnn_layers, rnn_type=supported_rnns[a.rnn_type.lower()], labels=labels,
-                           kernel_sz=a.conv_kernel, stride=a.conv_stride, map=a.conv_map, cnn_layers=a.conv_layers, nFreq=a.nFreq)
+        rnn_type = a.rnn_type.lower()
+        assert rnn_type in supported_rnns, "rnn_type should be either lstm, rnn or gru"
+        audio_conf = (dict(sample_rate=a.sample_rate, window_size=a.window_size, window_stride=a.window_stride, window=a.window, n_mels=a.n_mels,
+                           process_mel=a.process_mel) if a.preprocess == "code" else None)
+        model = DeepSpeech(rnn_hidden_size=a.rnn_size, rnn_layers=a.rnn_layers, rnn_type=supported_rnns[rnn_type], labels=labels, audio_conf=audio_conf,
+                           kernel_sz=a.conv_kernel, stride=a.conv_stride, map=a.conv_map, cnn_layers=a.conv_layers, nFreq=a.nFreq,
+                           nDownsample=a.nDownsample, include_first_BN=a.include_first_BN)     # train.py:228-239
         weights_init(model)
         tr, start_epoch, hist = AMTrainer(model.cuda(), lr=a.lr, dp=dp, labels=labels, sync_bn=a.sync_bn, optim=a.optim, momentum=a.momentum), 0, None
     # batch order (train.py:270-272,484-486): sortagrad keeps the manifest (increasing length) order for the first epoch and never
@@ -381,8 +453,13 @@ def main(argv=None):
     n_train = len(dl._sp["ny/train"])
     train_batches = lambda epoch: (dl.next("ny", "train") for _ in range(n_train))
     val_batches = lambda: (dl.next("ny", "val") for _ in range(dl.num_batches("val")))
-    tr.fit(train_batches, val_batches, a.epochs, save_path="%s/%s_%d.pth.tar" % (a.save_folder, a.DB_name, a.expnum), best_path=a.model_path,
-           start_epoch=start_epoch, print_every=a.print_every, history=hist, presharded=dp.active)
+    file_path = "%s/%s_%d.pth.tar" % (a.save_folder, a.DB_name, a.expnum)      # always overwritten by the most recent epoch's model
+    if dp.rank == 0:
+        print("Number of parameters: %d" % DeepSpeech.get_param_size(tr.model))
+        os.makedirs(os.path.dirname(a.model_path) or ".", exist_ok=True)
+        torch.save(DeepSpeech.serialize(tr.model, optimizer=tr.opt, epoch=0), file_path)     # train.py:288-291 ("save model file for error check")
+    tr.fit(train_batches, val_batches, a.epochs, save_path=file_path, best_path=a.model_path, start_epoch=start_epoch, print_every=a.print_every,
+           history=hist, presharded=dp.active, transcript_prob=a.transcript_prob)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

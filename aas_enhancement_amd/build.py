@@ -27,6 +27,7 @@ def build(force=False, verbose=True):
     srcs = sorted(f for f in os.listdir(SRC) if f.endswith(".hip"))
     hdrs = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "aas_hip.h"))
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "aas_warpctc.h"))
     jobs = []
     for f in srcs:
         src, obj = os.path.join(SRC, f), os.path.join(OBJ, f[:-4] + ".o")

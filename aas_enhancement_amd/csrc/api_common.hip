@@ -1,4 +1,9 @@
 #include <stdarg.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <stdlib.h>
 
 #include "common.h"
@@ -32,6 +37,56 @@ extern "C" int aas_set_debug_flags(int flags) {
     return 0;
 }
 extern "C" int aas_get_debug_flags(void) { return g_debug_flags; }
+
+namespace {
+struct WsKey {
+    int dev, kind;
+    hipStream_t s;
+    bool operator<(const WsKey& o) const { return dev != o.dev ? dev < o.dev : kind != o.kind ? kind < o.kind : s < o.s; }
+};
+struct WsBlock {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+std::mutex g_ws_mu;
+std::map<WsKey, WsBlock> g_ws;
+std::vector<std::pair<int, void*>> g_ws_retired;   // (device, block)
+}  // namespace
+
+void* aas_stream_workspace(int kind, hipStream_t s, size_t bytes, size_t floor_bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    WsBlock& w = g_ws[WsKey{dev, kind, s}];
+    if (w.bytes < bytes) {
+        // a stream under hipGraph capture can neither be synchronised nor allocate
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+        size_t want = bytes < floor_bytes ? floor_bytes : bytes;
+        if (want < 2 * w.bytes) want = 2 * w.bytes;      // geometric growth: the retired blocks of a stream sum to less than its live one
+        void* p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+        if (w.p) g_ws_retired.emplace_back(dev, w.p);    // still referenced by queued launches / captured graphs: never freed here
+        w.p = p;
+        w.bytes = want;
+    }
+    return w.p;
+}
+
+extern "C" int aas_release_retired_workspaces(void) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int n = 0;
+    for (auto& e : g_ws_retired) {
+        (void)hipSetDevice(e.first);
+        (void)hipDeviceSynchronize();
+        if (hipFree(e.second) == hipSuccess) ++n;
+    }
+    g_ws_retired.clear();
+    (void)hipSetDevice(prev);
+    return n;
+}
 
 const char* aas_ablation_env(const char* name) {
     static const bool on = getenv("AAS_ABLATION") && atoi(getenv("AAS_ABLATION")) == 1;

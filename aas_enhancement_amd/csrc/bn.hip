@@ -315,33 +315,14 @@ inline Geom4 geom4(int64_t R) {
     return g;
 }
 
-struct Ws {
-    double* p = nullptr;
-    size_t bytes = 0;
-};
-std::mutex g_ws_mu;
-std::unordered_map<hipStream_t, Ws> g_ws;   // partial-sum workspace, one per stream
-
 // -> nullptr when the 16-byte path does not apply (C, alignment) or no workspace can be had (first use under hipGraph capture)
 double* part_ws(hipStream_t s, int64_t R, int C, const void* a, const void* b, const void* c, const void* d) {
     if (C % 4 != 0 || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
                         reinterpret_cast<uintptr_t>(d)) & 15) != 0 || (aas_debug_flags_value() & 32768))
         return nullptr;
     const size_t bytes = sizeof(double) * 2 * (size_t)C * (size_t)geom4(R).RB;
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    Ws& w = g_ws[s];
-    if (w.bytes < bytes) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-        if (w.p) {
-            if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
-            (void)hipFree(w.p);
-        }
-        const size_t want = bytes < ((size_t)2 << 20) ? ((size_t)2 << 20) : bytes;
-        if (hipMalloc(&w.p, want) != hipSuccess) { w.p = nullptr; w.bytes = 0; return nullptr; }
-        w.bytes = want;
-    }
-    return w.p;
+    // per (device, stream); an outgrown block is retired, not freed (captured graphs keep its address): common.h
+    return static_cast<double*>(aas_stream_workspace(AAS_WS_BN_PARTIALS, s, bytes, (size_t)2 << 20));
 }
 
 // eval mode: y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta (+ LeakyReLU)

@@ -26,6 +26,12 @@ int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A,
                    int64_t strideB, int64_t strideC, int kdivA, int64_t kouterA, int kdivB, int64_t kouterB, int nmulti,
                    const float* const* Am, const float* const* Bm, float* const* Cm, const int* Km, const float* d_alpha);
 int aas_rnn_cus();  // aas_device_cus() capped by aas_set_rnn_cu_limit()
+// Scratch block of at least `bytes` for launches on stream `s` of the current device, one per (device, stream, kind); grown on
+// demand (at least doubling).  A block that is outgrown is RETIRED, not freed: a captured hipGraph may have its address baked into
+// its nodes, and a queued launch may still read it - retired blocks are released by aas_release_retired_workspaces() or at exit.
+// -> nullptr when the block would have to grow while `s` is under hipGraph capture (nothing may be allocated there).
+enum { AAS_WS_GEMM_SLABS = 0, AAS_WS_BN_PARTIALS = 1 };
+void* aas_stream_workspace(int kind, hipStream_t s, size_t bytes, size_t floor_bytes);
 
 #define AAS_CHECK(cond, ...)            \
     do {                                \

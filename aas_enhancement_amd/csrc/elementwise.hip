@@ -255,6 +255,32 @@ extern "C" int aas_axpby_f32(aasStream_t stream, float* y, const float* x, float
     return 0;
 }
 
+// y = (ref >= 0 ? 1 : slope) * x: the forward pass with ref == x, the backward pass with x = dy and ref = the forward input
+__global__ __launch_bounds__(256) void leaky_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ ref,
+                                                    float slope, int64_t n4, int64_t n) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = i0; i < n4; i += st) {
+        const float4 a = reinterpret_cast<const float4*>(x)[i], r = reinterpret_cast<const float4*>(ref)[i];
+        float4 o;
+        o.x = r.x >= 0.f ? a.x : slope * a.x;
+        o.y = r.y >= 0.f ? a.y : slope * a.y;
+        o.z = r.z >= 0.f ? a.z : slope * a.z;
+        o.w = r.w >= 0.f ? a.w : slope * a.w;
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+    for (int64_t i = 4 * n4 + i0; i < n; i += st) y[i] = ref[i] >= 0.f ? x[i] : slope * x[i];
+}
+
+extern "C" int aas_leaky_relu_f32(aasStream_t stream, float* y, const float* x, const float* ref, float slope, int64_t n) {
+    AAS_CHECK(y && x && ref && n >= 0, "aas_leaky_relu_f32: bad args");
+    if (n == 0) return 0;
+    const bool al = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ref)) & 15) == 0;
+    const int64_t n4 = al ? n / 4 : 0;
+    hipLaunchKernelGGL(leaky_kernel, dim3(grid_for(n4 > 0 ? n4 : n)), dim3(256), 0, (hipStream_t)stream, y, x, ref, slope, n4, n);
+    AAS_LAUNCH_CHECK("aas_leaky_relu_f32");
+    return 0;
+}
+
 extern "C" int aas_scale_dev_f32(aasStream_t stream, float* y, const float* x, const float* d_alpha, float alpha, int64_t n) {
     AAS_CHECK(y && x && d_alpha && n >= 0, "aas_scale_dev_f32: bad args");
     if (n == 0) return 0;

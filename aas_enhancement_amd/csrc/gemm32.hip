@@ -334,40 +334,28 @@ __global__ __launch_bounds__(256) void gemm32_reduce_kernel(const float* __restr
 
 __device__ float g_zero_block[64];   // zero-initialised: where out-of-range lanes of an LDS-DMA fetch from
 
-struct Ws {
-    float* p = nullptr;
-    size_t bytes = 0;
-};
-std::mutex g_ws_mu;
-std::unordered_map<hipStream_t, Ws> g_ws;   // one slab workspace per stream (products on different streams overlap)
-
+// one slab workspace per (device, stream): products on different streams overlap.  A block that is outgrown is retired, never freed
+// under a caller's feet (a captured hipGraph of the training step has the block's address in its GEMM and reduce nodes); under
+// capture the block cannot grow: the caller then runs the product without split-K.
 float* workspace(hipStream_t s, size_t bytes) {
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    Ws& w = g_ws[s];
-    if (w.bytes < bytes) {
-        // a stream under hipGraph capture can neither be synchronised nor allocate: the caller runs the product without split-K
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-        // (the old block may still be read by a queued reduce launch: it is released when the stream has drained)
-        if (w.p) {
-            if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
-            (void)hipFree(w.p);
-        }
-        size_t want = bytes < ((size_t)64 << 20) ? ((size_t)64 << 20) : bytes;
-        if (hipMalloc(&w.p, want) != hipSuccess) { w.p = nullptr; w.bytes = 0; return nullptr; }
-        w.bytes = want;
-    }
-    return w.p;
+    return static_cast<float*>(aas_stream_workspace(AAS_WS_GEMM_SLABS, s, bytes, (size_t)64 << 20));
 }
 
+constexpr int MAX_DEV = 64;
+std::mutex g_dev_mu;
+
+// the device address of g_zero_block is a per-device fact (every device has its own copy of the module's globals)
 const float* zero_block() {
-    static const float* z = nullptr;
-    if (!z) {
+    static const float* z[MAX_DEV] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (!z[dev]) {
         void* d = nullptr;
         if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_zero_block)) != hipSuccess) return nullptr;
-        z = (const float*)d;
+        z[dev] = (const float*)d;
     }
-    return z;
+    return z[dev];
 }
 
 template <bool AKC, bool BKC, int TMW>
@@ -377,12 +365,17 @@ int launch32(G32& p, dim3 grid, hipStream_t s) {
     // WHOLE CU back when it retires - a persistent recurrent launch waiting for residency needs whole CUs
     static const bool whole = aas_ablation_env("AAS_GEMM32_WHOLE_CU") && atoi(aas_ablation_env("AAS_GEMM32_WHOLE_CU")) != 0;
     const int LDS = whole ? 84 * 1024 : LDS0;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm32_kernel<AKC, BKC, TMW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                84 * 1024) != hipSuccess)
-            return -1;
-        attr_done = true;
+    static bool attr_done[MAX_DEV] = {false};     // the raised dynamic-LDS limit is per device too
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return -1;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        if (!attr_done[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm32_kernel<AKC, BKC, TMW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    84 * 1024) != hipSuccess)
+                return -1;
+            attr_done[dev] = true;
+        }
     }
     p.per = 0;
     if (!(p.flags & 4096)) {   // XCD-aware tile order (debug bit 4096: plain 3-D grid)
@@ -456,6 +449,9 @@ extern "C" int aas_set_gemm_max_steps(int n) {
     return 0;
 }
 
+int aas_gemm_max_steps_value();
+extern "C" int aas_get_gemm_max_steps(void) { return aas_gemm_max_steps_value(); }
+
 extern "C" int aas_set_gemm_variant(int v) {
     g_variant = v ? 1 : 0;
     return 0;
@@ -493,6 +489,9 @@ int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A,
         const float* Bi = nmulti > 0 ? Bm[i] : B;
         ok = ok && (akc ? (kdivA == 0 && ok_kc(Ai, lda, strideA)) : ok_rc(Ai, lda, M, kdivA, kouterA, strideA));
         ok = ok && (bkc ? (kdivB == 0 && ok_kc(Bi, ldb, strideB)) : ok_rc(Bi, ldb, N, kdivB, kouterB, strideB));
+        // a k-contiguous operand is fetched in chunks of 4 k guarded on the chunk's first element: EVERY problem's own reduction
+        // extent must be whole chunks, or the products of k = K_i .. K_i | 3 would be added to C_i
+        if (nmulti > 0 && Km && (akc || bkc)) ok = ok && Km[i] % 4 == 0;
     }
     // the 16-byte epilogue: whole float4 columns, 16-byte aligned rows of C / addend / bias; two-level k rows step without a division
     ok = ok && N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && (!bias || al16(bias)) && (!addend || (al16(addend) && ldd % 4 == 0));

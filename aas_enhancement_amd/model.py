@@ -236,6 +236,9 @@ class _FCWeights(nn.Module):
         nn.init.uniform_(self.weight, -b, b)
 
 
+DeepSpeech_ken = None   # bound below: AM_training/model.py's name for the same class
+
+
 class _BNLinear(nn.Sequential):
     """fc.0.module = Sequential(BatchNorm1d, Linear(bias=False)) (model.py:315-318)."""
 
@@ -244,8 +247,13 @@ class _BNLinear(nn.Sequential):
 
 
 class DeepSpeech(nn.Module):
+    """AAS/model.py:256-335 `DeepSpeech` = AM_training/model.py:337-470 `DeepSpeech_ken` (the class AM_training/train.py builds;
+    same layers and state_dict keys).  `include_first_BN` is the AM_training constructor's extra argument (:341,364-367): False
+    leaves the first convolution without its BatchNorm - conv.0 conv, conv.1 LeakyReLU, conv.2 conv, conv.3 BatchNorm, as the
+    reference's Sequential then numbers them."""
+
     def __init__(self, rnn_type=nn.LSTM, labels="abc", rnn_hidden_size=512, rnn_layers=2, bidirectional=True,
-                 kernel_sz=11, stride=2, map=256, cnn_layers=2, nFreq=40, nDownsample=1, audio_conf=None):
+                 kernel_sz=11, stride=2, map=256, cnn_layers=2, nFreq=40, nDownsample=1, audio_conf=None, include_first_BN=True):
         super().__init__()
         self.nFreq = nFreq
         self._version = "0.0.1"
@@ -255,7 +263,8 @@ class DeepSpeech(nn.Module):
         self.cnn_layers = cnn_layers
         self._labels = labels
         num_classes = len(labels)
-        conv_list = [_ConvK(nFreq, map, kernel_sz, stride), _BNParams(map), _LeakySlope(map)]
+        self.include_first_BN = bool(include_first_BN)
+        conv_list = [_ConvK(nFreq, map, kernel_sz, stride)] + ([_BNParams(map)] if include_first_BN else []) + [_LeakySlope(map)]
         s2 = 1 if nDownsample == 1 else stride
         for _ in range(cnn_layers - 1):
             conv_list += [_ConvK(map, map, kernel_sz, s2), _BNParams(map), _LeakySlope(map)]
@@ -270,8 +279,9 @@ class DeepSpeech(nn.Module):
     def output_length(self, T):
         """Number of output frames T' for T input frames (two un-padded temporal convolutions, model.py:288-301)."""
         t = T
-        for i in range(0, len(self.conv), 3):
-            t = (t - self.conv[i].kernel_size) // self.conv[i].stride + 1
+        for m in self.conv:
+            if isinstance(m, _ConvK):
+                t = (t - m.kernel_size) // m.stride + 1
         return t
 
     def forward(self, x):  # [N,nFreq,T] -> [N,T',C]
@@ -284,10 +294,16 @@ class DeepSpeech(nn.Module):
         """forward() as a generator: yields None after the convolutional front-end and after every recurrent layer,
         finally the output [N,T',C] (see stackedBRNN.forward_stages)."""
         h = ops.layout(x, "nct_ntc")                                     # channels-last [N,T,F]
-        for i in range(0, len(self.conv), 3):
-            cv, bn, act = self.conv[i], self.conv[i + 1], self.conv[i + 2]
+        mods, i = list(self.conv), 0
+        while i < len(mods):
+            cv = mods[i]
             h = ops.conv1d_cl(h, cv.weight, cv.bias, cv.stride)
-            h = bn(h, slope=float(act.negative_slope))
+            if isinstance(mods[i + 1], _BNParams):     # BatchNorm with the LeakyReLU fused into its apply launch
+                h = mods[i + 1](h, slope=float(mods[i + 2].negative_slope))
+                i += 3
+            else:                                      # include_first_BN=False: the activation alone
+                h = ops.leaky_relu(h, float(mods[i + 1].negative_slope))
+                i += 2
         h = ops.layout(h, "swap01")                                      # [N,T',M] -> [T',N,M]
         yield None
         for layer in self.rnns:
@@ -311,10 +327,13 @@ class DeepSpeech(nn.Module):
     def load_model_package(cls, package, gpu=-1):
         sd = package["state_dict"]
         n_freq = package.get("nFreq", sd["conv.0.weight"].shape[1])  # the reference always builds 40-in
+        # (the reference's packages carry neither include_first_BN nor nDownsample, AM_training/model.py:457-470 rebuilds with the
+        #  defaults; the first is visible in the keys - a BatchNorm at conv.1 or not - and is honoured so such a checkpoint loads)
+        first_bn = package.get("include_first_BN", "conv.1.weight" in sd)
         model = cls(rnn_hidden_size=package["rnn_size"], rnn_layers=package["rnn_layers"],
                     rnn_type=supported_rnns[package["rnn_type"]], map=package["cnn_map"], stride=package["cnn_stride"],
                     kernel_sz=package["cnn_kernel"], cnn_layers=package["cnn_layers"], labels=package["labels"],
-                    nFreq=n_freq)
+                    nFreq=n_freq, nDownsample=package.get("nDownsample", 1), include_first_BN=first_bn)
         model.load_state_dict(sd)
         if gpu >= 0:
             model = model.cuda()
@@ -330,6 +349,10 @@ class DeepSpeech(nn.Module):
             "rnn_type": supported_rnns_inv.get(model.rnn_type, getattr(model.rnn_type, "__name__", "gru").lower()),
             "labels": model._labels, "state_dict": model.state_dict(),
         }
+        if getattr(model, "nDownsample", 1) != 1:      # (extra keys only when they differ from what the reference's loader assumes)
+            package["nDownsample"] = model.nDownsample
+        if not getattr(model, "include_first_BN", True):
+            package["include_first_BN"] = False
         if optimizer is not None:
             package["optim_dict"] = optimizer.state_dict()
         if avg_loss is not None:
@@ -361,3 +384,6 @@ class DeepSpeech(nn.Module):
         return {"version": model._version, "rnn_size": model.rnn_size, "rnn_layers": model.rnn_layers,
                 "cnn_map": model.cnn_map, "cnn_kernel": model.cnn_kernel, "cnn_stride": model.cnn_stride,
                 "cnn_layers": model.cnn_layers, "rnn_type": supported_rnns_inv[model.rnn_type]}
+
+
+DeepSpeech_ken = DeepSpeech   # AM_training/model.py:337, AM_training/train.py:152 (`--arch_ver ken`)

@@ -147,15 +147,76 @@ class precision(object):
         return False
 
 
+class LaunchState(object):
+    """The library's queue-time settings that belong to ONE trainer (beside its arithmetic mode): the lifetime cap of its GEMM
+    workgroups and the kernel-selection (debug) bits.  The library keeps them process-wide and reads them when a launch is queued;
+    a trainer's entry points run under `launch_state(self.launch)`, which installs its values and puts the previous ones back - so a
+    validation model and a training model in one process, or two trainers built with different settings, never queue a launch under
+    each other's.  (The CU budget of the persistent launches and the launch tag are set per phase / per launch inside a step and
+    never outlive it.)  None = leave the library's current value alone."""
+    __slots__ = ("gemm_max_steps", "debug_flags")
+
+    def __init__(self, gemm_max_steps=None, debug_flags=None):
+        self.gemm_max_steps, self.debug_flags = gemm_max_steps, debug_flags
+
+
+class launch_state(object):
+    def __init__(self, st):
+        self.st = st
+
+    def __enter__(self):
+        self.prev = None
+        st = self.st
+        if st is not None and (st.gemm_max_steps is not None or st.debug_flags is not None):
+            L = lib()
+            self.prev = (int(L.aas_get_gemm_max_steps()), int(L.aas_get_debug_flags()))
+            if st.gemm_max_steps is not None and int(st.gemm_max_steps) != self.prev[0]:
+                L.aas_set_gemm_max_steps(int(st.gemm_max_steps))
+            if st.debug_flags is not None and int(st.debug_flags) != self.prev[1]:
+                L.aas_set_debug_flags(int(st.debug_flags))
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            L = lib()
+            if int(L.aas_get_gemm_max_steps()) != self.prev[0]:
+                L.aas_set_gemm_max_steps(self.prev[0])
+            if int(L.aas_get_debug_flags()) != self.prev[1]:
+                L.aas_set_debug_flags(self.prev[1])
+        return False
+
+
 def with_trainer_precision(fn):
-    """Decorator for trainer methods: run under `ops.precision(self.precision)`."""
+    """Decorator for trainer entry points: run under the trainer's own arithmetic mode (`self.precision`) and launch settings
+    (`self.launch`, a LaunchState)."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(self, *a, **k):
-        with precision(getattr(self, "precision", None)):
+        with precision(getattr(self, "precision", None)), launch_state(getattr(self, "launch", None)):
             return fn(self, *a, **k)
     return wrapped
+
+
+class TrainerContext(object):
+    """What every trainer class shares about its library context: the arithmetic mode it was built in, its launch settings, and the
+    one way to switch the mode that also refreshes the cached weight operand planes of its networks."""
+
+    def _init_context(self):
+        self.precision = get_precision()
+        self.launch = LaunchState()
+
+    def _context_networks(self):
+        return [m for m in (getattr(self, n, None) for n in ("G", "D", "ASR", "model")) if m is not None]
+
+    def set_precision(self, mode):
+        """Switch this trainer to another arithmetic mode (0 fp32 / 1 split-bf16 / 2 fp32-equivalent) and bring the cached weight
+        operand planes of its networks up to date for it, off the critical path."""
+        self.precision = int(mode)
+        with precision(self.precision):
+            for net in self._context_networks():
+                if any(True for _ in net.parameters()):
+                    refresh_weight_planes(net)
 
 
 def set_rnn_cu_limit(cus):
@@ -1377,6 +1438,32 @@ class _BatchNormRows(torch.autograd.Function):
             check(lib().aas_bn_bwd_apply(stream(), ptr(x), ptr(dy), ptr(dx), R, C, ptr(gamma), ptr(beta), float(ctx.slope),
                                          ptr(stats), ptr(dgamma), ptr(dbeta), 0, ptr(glob), ptr(loc), ptr(ctx.rows)), "aas_bn_bwd_apply")
         return dx, (dgamma if ctx.needs_input_grad[1] else None), (dbeta if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
+
+
+class _LeakyReLU(torch.autograd.Function):
+    """nn.LeakyReLU(negative_slope) on its own (AM_training/model.py:364-367, include_first_BN=False: no BatchNorm to fuse it into)."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        require_cuda(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(lib().aas_leaky_relu_f32(stream(), ptr(y), ptr(x), ptr(x), float(slope), x.numel()), "aas_leaky_relu_f32")
+        ctx.save_for_backward(x)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(lib().aas_leaky_relu_f32(stream(), ptr(dx), ptr(dy), ptr(x), ctx.slope, x.numel()), "aas_leaky_relu_f32")
+        return dx, None
+
+
+def leaky_relu(x, slope):
+    return _LeakyReLU.apply(x, slope)
 
 
 def batchnorm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, slope=1.0):

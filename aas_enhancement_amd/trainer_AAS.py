@@ -51,7 +51,7 @@ class _LazyScales(object):
         return self.cnt[i]
 
 
-class Trainer(object):
+class Trainer(ops.TrainerContext):
     def __init__(self, config, data_loader=None, models=None):
         self.config = config
         self.data_loader = data_loader
@@ -89,20 +89,11 @@ class Trainer(object):
         self.dp = None
         # the arithmetic this trainer runs in: the library's setting when it is built (config.precision / AAS_PRECISION / fp32);
         # every step and validation entry point runs under ops.precision(self.precision); set_precision() switches it
-        self.precision = ops.get_precision()
+        self._init_context()
         # a parameter of D is used from two streams when the step switches schedules: autograd synchronises the accumulation
         # correctly and says so once per process; the notice is not actionable here
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-
-    def set_precision(self, mode):
-        """Switch this trainer to another arithmetic mode (0 fp32 / 1 split-bf16 / 2 fp32-equivalent) and bring the cached weight
-        operand planes of its networks up to date for it, off the critical path."""
-        self.precision = int(mode)
-        with ops.precision(self.precision):
-            for net in (self.G, self.D, self.ASR):
-                if any(True for _ in net.parameters()):
-                    ops.refresh_weight_planes(net)
 
     def build_model(self):
         print("initialize enhancement & discriminator model")

@@ -8,9 +8,9 @@ from . import ops
 from .utils import AverageMeter, _get_variable_nograd, attach_n_valid
 
 
-class Trainer(object):
+class Trainer(ops.TrainerContext):
     def __init__(self, config, data_loader=None, models=None):
-        self.precision = ops.get_precision()   # the arithmetic this trainer runs in (ops.precision)
+        self._init_context()   # arithmetic mode + launch settings this trainer runs in (ops.TrainerContext)
         self.config, self.data_loader = config, data_loader
         self.lr, self.beta1, self.beta2 = config.lr, config.beta1, config.beta2
         self.diffLoss = L1Loss_mask()

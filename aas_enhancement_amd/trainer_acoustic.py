@@ -109,6 +109,7 @@ class Trainer(_AASTrainer):
         l_ctc = float(self.dp.reduce_scalars(l_CTC.detach().reshape(1).double()).item())
         ops.check_rnn_health((l_ctc,))
         self.ctc_tr_local.update(l_ctc, n_glob)
+        self._last_sync_l_ctc = l_ctc
         return dict(l_ctc=l_ctc, enhanced=enhanced, prob=prob)
 
     @ops.with_trainer_precision
@@ -150,6 +151,8 @@ class Trainer(_AASTrainer):
     def read_scalars(self):
         """One D2H copy: the last queued step's loss; feeds the running CTC average of the log line; a synchronisation
         point - raises if a persistent kernel timed out or the run diverged."""
+        if getattr(self, "_acc", None) is None:      # only synchronous train_step calls so far: nothing queued to read back
+            return dict(l_ctc=getattr(self, "_last_sync_l_ctc", None))
         l_ctc, s, n = self._acc.tolist()
         self._acc[1:3].zero_()
         self._acc_live = False

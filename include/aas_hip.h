@@ -122,6 +122,12 @@ int aas_set_gemm_variant(int variant);
  * persistent recurrent launches of the training step (trainer_AAS.py:131-194 on this build's schedule) become resident only when
  * enough CUs are free at once. */
 int aas_set_gemm_max_steps(int steps);
+int aas_get_gemm_max_steps(void);
+/* The library's own scratch (split-K slabs of aas_gemm_f32, BatchNorm partial sums) is one block per (device, stream), grown on
+ * demand; a block that is outgrown is retired, NOT freed, because a captured hipGraph may hold its address.  This call frees the
+ * retired blocks (device-synchronising): only when no captured graph that ran library launches is going to be replayed again.
+ * Returns the number of blocks released.  Synchronous. */
+int aas_release_retired_workspaces(void);
 /* C[M,N] (+)= sum_r kscale[r % knb] * A[r,M]^T B[r,N]   (fp32 mode): the TN product of aas_gemm_f32 with a per-reduction-row weight
  * applied while A is staged - the D-step weight gradients of a batched [enhanced; clean] discriminator pass carry the BEGAN factor
  * (-kt) on the enhanced utterances only (trainer_AAS.py:152-160); r = (t, n) time-major, knb = utterances per time step. */
@@ -190,6 +196,10 @@ int aas_add3_f32(aasStream_t stream, float* out, const float* a, const float* b,
  * Per-utterance weighting of the weight-gradient products when D(enhanced) and D(clean) share one
  * batched pass: parameter gradients of the enhanced half carry (-kt) (trainer_AAS.py:152-160). */
 int aas_scale_rows_f32(aasStream_t stream, float* out, const float* in, const float* scale, int64_t rows, int Nb, int C);
+/* y[i] = ref[i] >= 0 ? x[i] : slope * x[i].  nn.LeakyReLU(negative_slope = map) on its own - the first activation of
+ * AM_training/model.py:364-367 DeepSpeech_ken(include_first_BN=False), where no BatchNorm launch is there to fuse it into:
+ * forward with ref = x, backward with x = dy and ref = the forward input (y may alias x). */
+int aas_leaky_relu_f32(aasStream_t stream, float* y, const float* x, const float* ref, float slope, int64_t n);
 /* y = alpha * x + beta * y  (gradient scaling / accumulation; y may alias x) */
 int aas_axpby_f32(aasStream_t stream, float* y, const float* x, float alpha, float beta, int64_t n);
 /* y = (alpha * d_alpha[0]) * x with the factor read from device memory (y may alias x) */

@@ -78,9 +78,10 @@ class RefStackedBRNN(nn.Module):
 
 class RefDeepSpeech(nn.Module):
     def __init__(self, rnn_type=nn.GRU, labels="abc", rnn_hidden_size=512, rnn_layers=2,
-                 kernel_sz=11, stride=2, map=256, cnn_layers=2, nFreq=40, nDownsample=1):
+                 kernel_sz=11, stride=2, map=256, cnn_layers=2, nFreq=40, nDownsample=1, include_first_BN=True):
         super().__init__()
-        convs = [nn.Conv1d(nFreq, map, kernel_sz, stride=stride), nn.BatchNorm1d(map),
+        # include_first_BN: AM_training/model.py:341,364-367 (DeepSpeech_ken) - False leaves the first convolution without BatchNorm
+        convs = [nn.Conv1d(nFreq, map, kernel_sz, stride=stride)] + ([nn.BatchNorm1d(map)] if include_first_BN else []) + [
                  nn.LeakyReLU(map)]  # negative_slope == map (model.py:291)
         s2 = 1 if nDownsample == 1 else stride
         for _ in range(cnn_layers - 1):

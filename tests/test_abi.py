@@ -31,6 +31,18 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().aas_rnn_sync_bytes() >= 4096
 
 
+def test_library_exports_the_warpctc_abi():
+    """include/aas_warpctc.h: warp-ctc's four exported functions, under warp-ctc's names."""
+    from aas_enhancement_amd import _lib, build
+    build.build(verbose=False)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    src = open(os.path.join(ROOT, "include", "aas_warpctc.h")).read()
+    for n in ("get_warpctc_version", "ctcGetStatusString", "compute_ctc_loss", "get_workspace_size"):
+        assert n in src and hasattr(L, n), n
+    L.ctcGetStatusString.restype = ctypes.c_char_p
+    assert L.get_warpctc_version() == 2 and L.ctcGetStatusString(2) == b"invalid value"
+
+
 def test_no_cpu_fallback():
     from aas_enhancement_amd import ops
     from aas_enhancement_amd.model import L1Loss_mask, stackedBRNN
@@ -95,11 +107,46 @@ def test_greedy_decoder_and_wer():
     assert d.wer("the cat sat", "the cat sit") == 1 and d.cer("abc", "axc") == 1
 
 
-def test_config_flags_match_reference_defaults():
+def test_cli_flags_and_defaults_equal_the_references():
+    """F12 (tools/make_goldens.py f12: the reference's own parsers replayed): every flag of AM_training/train.py:24-110 and of
+    Speech_enhancement_by_AAS/config.py exists here with the SAME default - a reference command line trains the same model."""
+    import json
+    from aas_enhancement_amd import am_train
     from aas_enhancement_amd.config import get_config
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "f12_cli_defaults.json")))
+    ours = vars(am_train.build_parser().parse_args([]))
+    for k, v in ref["AM_training/train.py"].items():
+        assert k in ours, "am_train lacks --" + k
+        assert ours[k] == v, (k, ours[k], v)
     c, _ = get_config([])
-    assert (c.trainer, c.batch_size, c.nFeat, c.rnn_size, c.rnn_layers, c.lr, c.beta1, c.gamma, c.lambda_k, c.max_iter) == \
-        ("AAS", 20, 40, 500, 4, 1e-5, 0.5, 0.5, 0.001, 30000000)
+    for k, v in ref["Speech_enhancement_by_AAS/config.py"].items():
+        assert hasattr(c, k), "config lacks --" + k
+        assert getattr(c, k) == v, (k, getattr(c, k), v)
+    # what train.py:128-138 derives before it builds anything
+    a = am_train.resolve_args(am_train.build_parser().parse_args(["--process_mel", "true", "--n_mels", "80", "--DB_name", "x", "--expnum", "3", "--gpu", "0"]))
+    assert a.nFreq == 80 and a.model_path == "models/x_3_final.pth.tar"
+    with pytest.raises(NotImplementedError):
+        am_train.resolve_args(am_train.build_parser().parse_args(["--arch_ver", "ResidualDeepSpeech"]))
+    with pytest.raises(NotImplementedError):
+        am_train.resolve_args(am_train.build_parser().parse_args(["--preprocess", "code"]))
+
+
+def test_ablation_switches_are_not_read_from_the_environment_by_default():
+    """knobs.py: AAS_<NAME> variables take effect only together with AAS_ABLATION=1 (checked in child interpreters)."""
+    import subprocess
+    import sys
+    code = "from aas_enhancement_amd import knobs; print(knobs.get('SKIP_WGRAD'), knobs.get('EBWD_CUS'), sorted(knobs.active()))"
+    env = dict(os.environ, AAS_SKIP_WGRAD="1", AAS_EBWD_CUS="96")
+    env.pop("AAS_ABLATION", None)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.stdout.split()[:2] == ["False", "128"] and "[]" in r.stdout and "ignoring" in r.stderr, (r.stdout, r.stderr)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, AAS_ABLATION="1"), capture_output=True, text=True)
+    assert r.stdout.split()[:2] == ["True", "96"] and "SKIP_WGRAD" in r.stdout, (r.stdout, r.stderr)
+    from aas_enhancement_amd import knobs
+    assert knobs.active() == {}
+    with knobs.override(TWO_LANES="1"):
+        assert knobs.active() == {"TWO_LANES": "1"}
+    assert knobs.active() == {}
 
 
 def test_bench_launcher_builds_the_torchrun_command_and_relays(monkeypatch, capsys):

@@ -153,3 +153,203 @@ def test_forward_with_intermediate_output_golden(gpu, precision):
     assert rel_err(out[0], z["inter.y"]) < tol
     assert rel_err(out[1], z["inter.h"]) < tol
     assert rel_err(G(torch.from_numpy(z["inter.x"]).cuda()), z["inter.y"]) < tol
+
+
+# ---- AM_training's model class (DeepSpeech_ken) ---------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["bn", "nobn", "nobn_ds2", "lstm_nobn"])
+def test_deepspeech_ken_variants_golden(gpu, precision, tag):
+    """F11: AM_training/model.py:337-470 DeepSpeech_ken with / without the first BatchNorm (`--include_first_BN`), `--nDownsample`
+    1 / 2, GRU / LSTM: same state_dict keys as the reference's Sequential numbering, logits, input gradient, every parameter
+    gradient, BatchNorm running statistics after the pass."""
+    from aas_enhancement_amd.model import DeepSpeech_ken
+    z = load("f11_am_model_ken.npz")
+    p = "ken_%s." % tag
+    A = DeepSpeech_ken(nn.LSTM if tag.startswith("lstm") else nn.GRU, LABELS, 12, 3, True, 11, 2, 8, 2, nFreq=10,
+                       nDownsample=2 if tag.endswith("ds2") else 1, include_first_BN=(tag == "bn"))
+    sd0 = sub(z, p + "sd0.")
+    assert set(A.state_dict().keys()) == set(sd0.keys())
+    load_sd(A, sd0)
+    A.cuda()
+    x = torch.from_numpy(z[p + "x"]).cuda().requires_grad_(True)
+    y = A(x)
+    assert tuple(y.shape) == tuple(z[p + "y"].shape) and y.shape[1] == A.output_length(x.shape[2])
+    y.backward(torch.from_numpy(z[p + "gy"]).cuda())
+    ft, gt = (1e-5, 2e-4) if precision != 1 else (1e-4, 1e-3)
+    assert rel_err(y, z[p + "y"]) < ft
+    assert rel_err(x.grad, z[p + "gx"]) < gt
+    for k, v in A.named_parameters():
+        g = z[p + "gw." + k]
+        if k.endswith(".bias") and np.abs(g).max() < 1e-5:    # conv bias in front of a train-mode BatchNorm: exact gradient 0
+            continue
+        assert float((v.grad.cpu() - torch.from_numpy(g)).abs().max()) <= gt * float(np.abs(g).max()) + 1e-6, k
+    for k, v in A.state_dict().items():
+        if "running" in k and not (k.startswith("conv") and "running_mean" in k):
+            assert rel_err(v, z[p + "sd1." + k]) < 1e-4, k
+    # the package round trip keeps the variant (the reference's packages do not record it: the keys do)
+    B = DeepSpeech_ken.load_model_package(DeepSpeech_ken.serialize(A))
+    assert set(B.state_dict().keys()) == set(sd0.keys()) and B.output_length(90) == A.output_length(90)
+
+
+# ---- per-trainer launch state --------------------------------------------------------------------------------------
+def test_two_trainers_with_different_launch_state_interleave(gpu):
+    """Two trainers in one process with different library settings - arithmetic mode, GEMM workgroup-lifetime cap, kernel-selection
+    bits - stepping in alternation produce, bit for bit, what each produces alone; and neither leaves its settings behind."""
+    from aas_enhancement_amd import ops
+    from aas_enhancement_amd._lib import lib
+    from aas_enhancement_amd.trainer_AAS import Trainer
+    from tests.test_gpu_step import build_tiny
+    from tests.helpers import batch_from
+    z = load("f1_aas_tiny.npz")
+    settings = [dict(precision=0, launch=ops.LaunchState(gemm_max_steps=48, debug_flags=0)),
+                dict(precision=1, launch=ops.LaunchState(gemm_max_steps=0, debug_flags=512))]
+
+    def make(i):
+        tr = Trainer(cfg(lr=float(z["cfg_lr"])), None, models=build_tiny(z))
+        tr.kt = float(z["kt0"])
+        tr.set_precision(settings[i]["precision"])
+        tr.launch = settings[i]["launch"]
+        return tr
+
+    def run(trs, order):
+        out = {id(t): [] for t in trs}
+        its = {id(t): 0 for t in trs}
+        for i in order:
+            t = trs[i]
+            it = its[id(t)]
+            r = t.train_step(batch_from(z, "it%d.ny." % it), batch_from(z, "it%d.cl." % it), it, log_norms=False)
+            out[id(t)].append([r[k] for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt")] + [float(r["enhanced"].double().sum())])
+            its[id(t)] += 1
+        return [np.asarray(out[id(t)]) for t in trs], [{k: v.detach().clone() for k, v in t.G.state_dict().items()} for t in trs]
+    before = (ops.get_precision(), int(lib().aas_get_gemm_max_steps()), int(lib().aas_get_debug_flags()))
+    alone = [run([make(i)], [0, 0, 0]) for i in (0, 1)]
+    both = run([make(0), make(1)], [0, 1, 1, 0, 0, 1])
+    assert (ops.get_precision(), int(lib().aas_get_gemm_max_steps()), int(lib().aas_get_debug_flags())) == before
+    for i in (0, 1):
+        assert np.array_equal(alone[i][0][0], both[0][i]), i
+        for k, v in alone[i][1][0].items():
+            assert torch.equal(v, both[1][i][k]), (i, k)
+    assert not np.array_equal(both[0][0], both[0][1])       # (the two modes do differ in the last bits)
+
+
+# ---- warp-ctc's own C ABI -------------------------------------------------------------------------------------------
+class _CtcOptUnion(ctypes.Union):
+    _fields_ = [("num_threads", ctypes.c_uint), ("stream", ctypes.c_void_p)]
+
+
+class _CtcOptions(ctypes.Structure):
+    _anonymous_ = ("u",)
+    _fields_ = [("loc", ctypes.c_int), ("u", _CtcOptUnion), ("blank_label", ctypes.c_int)]
+
+
+def test_warpctc_abi_entry_points(gpu):
+    """include/aas_warpctc.h: get_workspace_size / compute_ctc_loss with warp-ctc's exact signatures (ctcOptions by value, costs on
+    the host) against the numpy fp64 oracle - what warpctc_pytorch's binding calls (trainer_AAS.py:168 through CTCLoss)."""
+    from aas_enhancement_amd import _lib
+    from oracle import ctc_np
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    L.get_workspace_size.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _CtcOptions, ctypes.POINTER(ctypes.c_size_t)]
+    L.compute_ctc_loss.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_void_p, _CtcOptions]
+    L.ctcGetStatusString.restype = ctypes.c_char_p
+    assert L.get_warpctc_version() >= 2 and L.ctcGetStatusString(0) == b"no error"
+    rng = np.random.RandomState(5)
+    T, N, C = 85, 6, 29
+    acts = torch.from_numpy((rng.randn(T, N, C) * 2).astype(np.float32)).cuda()
+    ll = np.array([20, 7, 1, 0, 12, 20], np.int32)
+    al = np.array([85, 60, 85, 2, 40, 85], np.int32)
+    labels = np.concatenate([rng.randint(1, C, size=k) for k in ll]).astype(np.int32)
+    st = torch.cuda.Stream()
+    opt = _CtcOptions()
+    opt.loc, opt.stream, opt.blank_label = 1, st.cuda_stream, 0
+    sz = ctypes.c_size_t(0)
+    assert L.get_workspace_size(ll.ctypes.data, al.ctypes.data, C, N, opt, ctypes.byref(sz)) == 0 and sz.value > 0
+    ws = torch.empty(sz.value, dtype=torch.uint8, device="cuda")
+    grads = torch.full_like(acts, 7.0)
+    costs = np.zeros(N, np.float32)
+    torch.cuda.synchronize()
+    assert L.compute_ctc_loss(acts.data_ptr(), grads.data_ptr(), labels.ctypes.data, ll.ctypes.data, al.ctypes.data, C, N, costs.ctypes.data,
+                              ws.data_ptr(), opt) == 0
+    rc, rg = ctc_np.ctc_batch(acts.cpu().numpy(), labels, al, ll)
+    assert np.allclose(costs, rc, rtol=1e-5)
+    assert np.abs(grads.cpu().numpy() - rg).max() < 2e-5
+    # gradients may be NULL (costs only); CPU location and a bad blank label are refused with warp-ctc's status codes
+    costs2 = np.zeros(N, np.float32)
+    assert L.compute_ctc_loss(acts.data_ptr(), None, labels.ctypes.data, ll.ctypes.data, al.ctypes.data, C, N, costs2.ctypes.data, ws.data_ptr(), opt) == 0
+    assert np.allclose(costs2, rc, rtol=1e-5)
+    opt.loc = 0
+    assert L.compute_ctc_loss(acts.data_ptr(), None, labels.ctypes.data, ll.ctypes.data, al.ctypes.data, C, N, costs2.ctypes.data, ws.data_ptr(), opt) == 3
+    opt.loc, opt.blank_label = 1, C
+    assert L.compute_ctc_loss(acts.data_ptr(), None, labels.ctypes.data, ll.ctypes.data, al.ctypes.data, C, N, costs2.ctypes.data, ws.data_ptr(), opt) == 2
+
+
+# ---- ADVICE r4 ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+def test_multi_problem_gemm_with_unequal_reduction_extents(gpu, mode):
+    """aas_gemm_f32_multi with per-problem K that are NOT multiples of 4 ({100, 98}) in all three operand forms: a k-contiguous
+    operand is fetched in 4-k chunks, so such problems must take the general kernel (the chunk guard looked at the
+    launch's largest K only and added k = 98..99 of the second problem's operands into its result)."""
+    from aas_enhancement_amd import ops
+    M, N, Ks = 128, 192, [100, 98]
+    g = torch.Generator().manual_seed(17)
+    Kmax = max(Ks)
+    outs, want, As, Bs = [], [], [], []
+    keep = []
+    for K in Ks:
+        a, b = torch.randn(M, Kmax, generator=g), torch.randn(N, Kmax, generator=g)      # columns K..Kmax hold data that must NOT be summed
+        want.append(a[:, :K].double() @ b[:, :K].double().t())
+        if mode == "nt":
+            A, B = a.cuda(), b.cuda()
+        elif mode == "nn":
+            A, B = a.cuda(), b.t().contiguous().cuda()
+        else:
+            A, B = a.t().contiguous().cuda(), b.t().contiguous().cuda()
+        keep += [A, B]
+        As.append(A.data_ptr()); Bs.append(B.data_ptr())
+        outs.append(torch.zeros(M, N, device="cuda"))
+    lda = Kmax if mode != "tn" else M
+    ldb = Kmax if mode == "nt" else N
+    ops.gemm_multi({"nt": ops.NT, "nn": ops.NN, "tn": ops.TN}[mode], M, N, Ks, As, lda, Bs, ldb, [o.data_ptr() for o in outs], N)
+    for o, w in zip(outs, want):
+        assert rel_err(o, w) < 1e-5, mode
+
+
+def test_split_k_workspace_growth_keeps_captured_graphs_valid(gpu):
+    """A hipGraph captured while the split-K slab block of its stream was small must still replay correctly after a deeper product
+    on the same stream made the block grow (the old block used to be freed; it is retired now)."""
+    from aas_enhancement_amd import _lib, ops
+    L = _lib.lib()
+    prev = int(L.aas_get_gemm_max_steps())
+    L.aas_set_gemm_max_steps(16)
+    try:
+        st = torch.cuda.Stream()
+        g = torch.Generator().manual_seed(23)
+        M, N, K = 256, 256, 16384                    # deep and narrow: split-K with slabs
+        a, b = torch.randn(K, M, generator=g).cuda(), torch.randn(K, N, generator=g).cuda()
+        c = torch.zeros(M, N, device="cuda")
+        want = a.double().t() @ b.double()
+        with torch.cuda.stream(st):
+            ops.gemm(ops.TN, M, N, K, a, M, b, N, c, N)      # sizes the block for this stream
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            ops.gemm(ops.TN, M, N, K, a, M, b, N, c, N)
+        c.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert rel_err(c, want) < 2e-5
+        # a much larger split product on the same stream: the block has to grow past the 64 MB floor
+        M2, N2, K2 = 2048, 2048, 8192
+        a2, b2 = torch.randn(K2, M2, generator=g).cuda(), torch.randn(K2, N2, generator=g).cuda()
+        c2 = torch.zeros(M2, N2, device="cuda")
+        with torch.cuda.stream(st):
+            ops.gemm(ops.TN, M2, N2, K2, a2, M2, b2, N2, c2, N2)
+        torch.cuda.synchronize()
+        assert rel_err(c2, a2.double().t() @ b2.double()) < 2e-5
+        junk = [torch.full((32 << 20,), float("nan"), device="cuda") for _ in range(4)]     # would land on a freed block
+        c.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert rel_err(c, want) < 2e-5
+        del junk
+    finally:
+        L.aas_set_gemm_max_steps(prev)

@@ -103,6 +103,31 @@ def test_brnn_ops(kind, tag):
         assert rel_err(v.grad, z[p + "gw." + k]) < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["bn", "nobn", "nobn_ds2", "lstm_nobn"])
+def test_deepspeech_ken_variants(tag):
+    """F11: the oracle's acoustic model against AM_training/model.py's own DeepSpeech_ken (:337-470) with / without the first
+    BatchNorm, nDownsample 1 / 2, GRU / LSTM: logits, input gradient, every parameter gradient, running statistics."""
+    z = load("f11_am_model_ken.npz")
+    p = "ken_%s." % tag
+    kw = dict(include_first_BN=(tag == "bn"), nDownsample=2 if tag.endswith("ds2") else 1)
+    A = RM.RefDeepSpeech(nn.LSTM if tag.startswith("lstm") else nn.GRU, LABELS, 12, 3, 11, 2, 8, 2, nFreq=10, **kw)
+    sd0 = sub(z, p + "sd0.")
+    assert set(A.state_dict().keys()) == set(sd0.keys())
+    load_sd(A, sd0)
+    x = torch.from_numpy(z[p + "x"]).requires_grad_(True)
+    y = A(x)
+    y.backward(torch.from_numpy(z[p + "gy"]))
+    assert rel_err(y, z[p + "y"]) < 1e-5 and rel_err(x.grad, z[p + "gx"]) < 1e-4
+    for k, v in A.named_parameters():
+        g = z[p + "gw." + k]
+        if k.endswith(".bias") and np.abs(g).max() < 1e-5:   # a conv bias in front of a train-mode BatchNorm: true gradient 0, rounding noise
+            continue
+        assert float((v.grad - torch.from_numpy(g)).abs().max()) <= 1e-4 * float(np.abs(g).max()) + 1e-6, k
+    for k, v in A.state_dict().items():
+        if "running" in k:
+            assert rel_err(v, z[p + "sd1." + k]) < 1e-5, k
+
+
 def test_fsegan_and_am_steps():
     from tests.tools_shim import make_batch  # noqa: F401  (same portable batch builder as the generator)
     z = load("f5_fsegan_am.npz")

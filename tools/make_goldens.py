@@ -773,6 +773,37 @@ def f11_am_model_ken():
     print("F11 keys", len(out))
 
 
+def f12_cli_defaults():
+    """F12: the command-line contracts as data - every flag and default of AM_training/train.py's parser (:24-110) and of
+    Speech_enhancement_by_AAS/config.py's.  train.py cannot be imported here (warpctc_pytorch, data.data_loader are absent), so
+    its `parser.add_argument(...)` calls are read from its syntax tree and replayed on a fresh argparse parser; config.py imports."""
+    import ast
+    import json
+    src = open("/root/reference/AM_training/train.py").read()
+    tree = ast.parse(src)
+    ns = {"str2bool": (lambda v: v.lower() in ("true", "1")), "int": int, "float": float, "str": str}
+    par = argparse.ArgumentParser()
+    for node in ast.walk(tree):
+        if (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "add_argument"
+                and isinstance(node.func.value, ast.Name) and node.func.value.id == "parser"):
+            args = [ast.literal_eval(a_) for a_ in node.args]
+            kw = {}
+            for k in node.keywords:
+                kw[k.arg] = ns[k.value.id] if (isinstance(k.value, ast.Name) and k.value.id in ns) else ast.literal_eval(k.value)
+            par.add_argument(*args, **kw)
+    am = vars(par.parse_args([]))
+    import config as REFCFG     # the reference's Speech_enhancement_by_AAS/config.py
+    argv, sys.argv = sys.argv, ["main.py"]
+    try:
+        c, _ = REFCFG.get_config()
+    finally:
+        sys.argv = argv
+    aas = {k: v for k, v in vars(c).items()}
+    with open(os.path.join(OUT, "f12_cli_defaults.json"), "w") as f:
+        json.dump({"AM_training/train.py": am, "Speech_enhancement_by_AAS/config.py": aas}, f, indent=1, sort_keys=True)
+    print("F12", len(am), "AM flags,", len(aas), "AAS flags")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip F3 (config 2, minutes of CPU)")
@@ -781,7 +812,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if a.only:
         table = dict(f1=f1_tiny, f2=f2_dce, f3=f3_config2, f4=f4_ops, f5=f5_fsegan_am, f6=f6_fsegan_config4,
-                     f7=f7_am_config5, f8=f8_host_side, f9=f9_rnn_kind, f10=f10_acoustic, f3b=f3b_config2_kt, f11=f11_am_model_ken)
+                     f7=f7_am_config5, f8=f8_host_side, f9=f9_rnn_kind, f10=f10_acoustic, f3b=f3b_config2_kt, f11=f11_am_model_ken, f12=f12_cli_defaults)
         for k in a.only.split(","):
             table[k]()
         sys.exit(0)
@@ -792,6 +823,7 @@ if __name__ == "__main__":
     f8_host_side()
     f9_rnn_kind()
     f11_am_model_ken()
+    f12_cli_defaults()
     if not a.skip_big:
         f3_config2()
         f3b_config2_kt()
