@@ -55,6 +55,8 @@ SIGNATURES = {
     "aas_scale_rows_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int],
     "aas_axpby_f32": [c_vp, c_vp, c_vp, c_f32, c_f32, c_i64],
     "aas_leaky_relu_f32": [c_vp, c_vp, c_vp, c_vp, c_f32, c_i64],
+    "aas_step_prologue": [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp],
+    "aas_began_step_raw": [c_vp, c_vp, ctypes.c_double, ctypes.c_double, c_vp, c_int, ctypes.c_double, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double],
     "aas_scale_dev_f32": [c_vp, c_vp, c_vp, c_vp, c_f32, c_i64],
     "aas_colsum_f32": [c_vp, c_vp, c_i64, c_int, c_i64, c_vp, c_int],
     "aas_sqsum_f32": [c_vp, c_vp, c_i64, c_vp],

@@ -370,7 +370,84 @@ __global__ void began_step_kernel(const float* __restrict__ l_ny, const float* _
     out[4] += c * n_batch;
     out[5] += n_batch;
 }
+// ---- step prologue: every buffer of the step that starts from zero, and the per-utterance weights of the batched discriminator
+// pass, in ONE launch (was: one fill launch per gradient buffer / loss accumulator, neg + two copies + fill for the weights)
+struct ZeroList {
+    void* p[8];
+    unsigned long long bytes[8];        // multiples of 16 except possibly the last chunk of each buffer (handled bytewise)
+    unsigned long long first[9];        // first 4 KB chunk of each buffer in the launch's chunk numbering
+    int n;
+};
+__global__ __launch_bounds__(256) void step_prologue_kernel(ZeroList z, float* __restrict__ rs, int n_neg, int n_one,
+                                                            const double* __restrict__ kt) {
+    const unsigned long long total = z.first[z.n];
+    for (unsigned long long c = blockIdx.x; c < total; c += gridDim.x) {
+        int b = 0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i)
+            if (i < z.n && c >= z.first[i]) b = i;
+        const unsigned long long off = (c - z.first[b]) * 4096ull + (unsigned long long)threadIdx.x * 16ull;
+        char* q = static_cast<char*>(z.p[b]) + off;
+        if (off + 16 <= z.bytes[b]) {
+            *reinterpret_cast<f32x4*>(q) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else if (off < z.bytes[b]) {
+            for (unsigned long long i = off; i < z.bytes[b]; ++i) static_cast<char*>(z.p[b])[i] = 0;
+        }
+    }
+    if (rs != nullptr && blockIdx.x == 0) {
+        const float neg = -(float)kt[0];
+        for (int i = threadIdx.x; i < n_neg + n_one; i += 256) rs[i] = i < n_neg ? neg : 1.0f;
+    }
+}
+
+// BEGAN controller from the RAW sums of the step (no scaling / summing launches in between): L_ny = s_ny * sum|D(E(x)) - E(x)|,
+// L_cl = s_cl * sum|D(c) - c|, L_ctc = s_ctc * sum of the per-utterance CTC costs
+__global__ void began_step_raw_kernel(const double* __restrict__ l1_sums, double s_ny, double s_cl, const float* __restrict__ costs, int n_costs,
+                                      double s_ctc, double* __restrict__ kt, double* __restrict__ out, double gamma, double lambda_k,
+                                      double n_batch) {
+    float cs = 0.f;                                   // (fp32 running sum in utterance order: what the colsum launch did)
+    for (int i = 0; i < n_costs; ++i) cs += costs[i];
+    const double a = (double)(float)(l1_sums[0] * s_ny), b = (double)(float)(l1_sums[1] * s_cl), c = (double)(float)((double)cs * s_ctc);
+    double k = kt[0] + lambda_k * (gamma * b - a);
+    k = k < 0.0 ? 0.0 : (k > 1.0 ? 1.0 : k);
+    kt[0] = k;
+    out[0] = a; out[1] = b; out[2] = c; out[3] = k;
+    out[4] += c * n_batch;
+    out[5] += n_batch;
+}
 }  // namespace
+
+extern "C" int aas_step_prologue(aasStream_t stream, int n, void* const* bufs, const size_t* bytes, float* rs, int n_neg, int n_one,
+                                 const double* d_kt) {
+    AAS_CHECK(n >= 0 && n <= 8 && (n == 0 || (bufs && bytes)), "aas_step_prologue: at most 8 buffers");
+    AAS_CHECK(rs == nullptr || (d_kt != nullptr && n_neg >= 0 && n_one >= 0), "aas_step_prologue: the weight vector needs d_kt");
+    ZeroList z;
+    memset(&z, 0, sizeof(z));
+    z.n = n;
+    unsigned long long chunks = 0;
+    for (int i = 0; i < n; ++i) {
+        AAS_CHECK(bufs[i] != nullptr && (reinterpret_cast<uintptr_t>(bufs[i]) & 15) == 0, "aas_step_prologue: buffer %d is null or not 16-byte aligned", i);
+        z.p[i] = bufs[i];
+        z.bytes[i] = bytes[i];
+        z.first[i] = chunks;
+        chunks += (bytes[i] + 4095) / 4096;
+    }
+    z.first[n] = chunks;
+    if (chunks == 0 && rs == nullptr) return 0;
+    const unsigned long long g = chunks < 1 ? 1 : (chunks > 8192 ? 8192 : chunks);
+    hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, z, rs, n_neg, n_one, d_kt);
+    AAS_LAUNCH_CHECK("aas_step_prologue");
+    return 0;
+}
+
+extern "C" int aas_began_step_raw(aasStream_t stream, const double* d_l1_sums, double scale_ny, double scale_cl, const float* d_ctc_costs,
+                                  int n_costs, double scale_ctc, double* d_kt, double* d_out6, double gamma, double lambda_k, double n_batch) {
+    AAS_CHECK(d_l1_sums && d_ctc_costs && n_costs >= 0 && d_kt && d_out6, "aas_began_step_raw: null pointer");
+    hipLaunchKernelGGL(began_step_raw_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_l1_sums, scale_ny, scale_cl, d_ctc_costs, n_costs,
+                       scale_ctc, d_kt, d_out6, gamma, lambda_k, n_batch);
+    AAS_LAUNCH_CHECK("aas_began_step_raw");
+    return 0;
+}
 
 extern "C" int aas_adam_tick(aasStream_t stream, double* d_step, double lr, double beta1, double beta2, float* d_hyper) {
     AAS_CHECK(d_step && d_hyper, "aas_adam_tick: null pointer");

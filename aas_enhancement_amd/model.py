@@ -182,11 +182,12 @@ class stackedBRNN(nn.Module):
         out = ops.linear_rows(h, self.final_linear.weight, self.final_linear.bias, wgrad_row_scale)
         return ops.layout(out, "tnc_nct")                                 # [T,N,O] -> [N,O,T]
 
-    def forward_stages(self, input, wgrad_row_scale=None):
+    def forward_stages(self, input, wgrad_row_scale=None, pair=None):
         """forward() as a generator that yields after every layer (None) and finally the output: lets a trainer queue
-        two independent networks layer by layer on two HIP streams (trainer_AAS: discriminator beside acoustic model)."""
+        two independent networks layer by layer on two HIP streams (trainer_AAS: discriminator beside acoustic model).
+        pair = (a, b): the input is [a ; b] along the batch axis, laid down time-major without a concatenated copy."""
         rs = wgrad_row_scale
-        h = ops.layout(input, "nct_tnc")
+        h = ops.layout_cat_nct_tnc(pair[0], pair[1]) if pair is not None else ops.layout(input, "nct_tnc")
         h = ops.linear_rows(h, self.first_linear.weight, self.first_linear.bias, rs)
         yield None
         for l in range(1, self.L + 1):

@@ -698,6 +698,39 @@ def layout(x, kind):
     return _Layout.apply(x, kind)
 
 
+class _LayoutCatNCT(torch.autograd.Function):
+    """[a ; b] along the batch axis and [N,C,T] -> [T,N,C] in one step: two transposing launches straight into the halves of the
+    time-major tensor instead of a concatenated copy and a transpose of it (the batched [enhanced; clean] discriminator input).
+    Only `a` receives a gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        require_cuda(a, b)
+        a, b = _c(a), _c(b)
+        Na, C, T = a.shape
+        Nb = b.shape[0]
+        assert tuple(b.shape[1:]) == (C, T)
+        N = Na + Nb
+        out = torch.empty((T, N, C), device=a.device, dtype=torch.float32)
+        check(lib().aas_transpose_f32(stream(), ptr(a), ptr(out), Na, C, T, C * T, T, C, N * C), "aas_transpose_f32")
+        check(lib().aas_transpose_f32(stream(), ptr(b), out.data_ptr() + 4 * Na * C, Nb, C, T, C * T, T, C, N * C), "aas_transpose_f32")
+        ctx.na = Na
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        T, N, C = g.shape
+        ga = torch.empty((ctx.na, C, T), device=g.device, dtype=torch.float32)
+        # rows (t, n < Na) of g back to [Na, C, T]: in[b = n][r = t][c] with strides (C, N*C), out[b][c][t]
+        check(lib().aas_transpose_f32(stream(), ptr(g), ptr(ga), ctx.na, T, C, C, N * C, C * T, T), "aas_transpose_f32")
+        return ga, None
+
+
+def layout_cat_nct_tnc(a, b):
+    return _LayoutCatNCT.apply(a, b)
+
+
 # --------------------------------------------------------------------------------------- linear
 class _LinearRows(torch.autograd.Function):
     """y[..., N] = x[..., K] W[N,K]^T (+ b) on the flattened leading dims."""
@@ -1582,6 +1615,58 @@ def l1_sum(a, b):
     return _L1Sum.apply(a, b)
 
 
+# ---- device-resident step: loss roots without scaling / slicing / summing launches in between ------------------------------------
+_unit_roots = {}
+
+
+def unit_root(like):
+    """A cached all-ones root gradient for `like` (a raw loss root): `torch.autograd.backward([root], [unit_root(root)])` queues no fill
+    launch, and the fused loss functions below recognise it and skip the multiplication by it."""
+    key = (like.device, like.dtype, tuple(like.shape))
+    u = _unit_roots.get(key)
+    if u is None:
+        u = torch.ones(like.shape, device=like.device, dtype=like.dtype)
+        u._aas_unit = True
+        _unit_roots[key] = u
+    return u
+
+
+class _L1Pair(torch.autograd.Function):
+    """The two masked-L1 sums of the batched discriminator pass (model.py:23-31 twice: trainer_AAS.py:146-147 on the enhanced rows
+    with `enhanced` itself as the target, :176-177 on the clean rows), each with its weight / nElement scale folded into the
+    backward launch: acc[0] += sum|ae[:N] - leaf|, acc[1] += sum|ae[N:] - clean| (acc: fp64 [2], zeroed by the step prologue and
+    returned as the root).  Backward writes d(ae) for both halves into ONE tensor and d(leaf) (the target's gradient)."""
+
+    @staticmethod
+    def forward(ctx, ae, leaf, clean, s_ny, s_cl, acc):
+        require_cuda(ae, leaf, clean)
+        ae, leaf, clean = _c(ae), _c(leaf), _c(clean)
+        n0, n1 = leaf.numel(), clean.numel()
+        assert ae.numel() == n0 + n1 and acc.dtype == torch.float64 and acc.numel() == 2
+        check(lib().aas_l1_fwd(stream(), ptr(ae), ptr(leaf), n0, ptr(acc)), "aas_l1_fwd")
+        check(lib().aas_l1_fwd(stream(), ae.data_ptr() + 4 * n0, ptr(clean), n1, acc.data_ptr() + 8), "aas_l1_fwd")
+        ctx.save_for_backward(ae, leaf, clean)
+        ctx.scales = (float(s_ny), float(s_cl))
+        ctx.mark_dirty(acc)
+        return acc
+
+    @staticmethod
+    def backward(ctx, g):
+        ae, leaf, clean = ctx.saved_tensors
+        n0, n1 = leaf.numel(), clean.numel()
+        gs = None if getattr(g, "_aas_unit", False) else _c(g.to(torch.float32))
+        dae = torch.empty_like(ae)
+        dleaf = torch.empty_like(leaf) if ctx.needs_input_grad[1] else None
+        check(lib().aas_l1_bwd(stream(), ptr(ae), ptr(leaf), n0, ctx.scales[0], ptr(gs), ptr(dae), ptr(dleaf), 0), "aas_l1_bwd")
+        check(lib().aas_l1_bwd(stream(), ae.data_ptr() + 4 * n0, ptr(clean), n1, ctx.scales[1], (gs.data_ptr() + 4) if gs is not None else None,
+                               dae.data_ptr() + 4 * n0, None, 0), "aas_l1_bwd")
+        return dae, dleaf, None, None, None, None
+
+
+def l1_pair(ae, leaf, clean, s_ny, s_cl, acc):
+    return _L1Pair.apply(ae, leaf, clean, s_ny, s_cl, acc)
+
+
 def ctc_prepare(labels, act_lens, label_lens, device):  # device may be "cpu": the caller uploads `meta` itself
     """Upload the CTC metadata (flat labels, label offsets, label lengths, act lengths) in ONE host->device copy.
     Call it BEFORE queueing the forward pass: a pageable-memory H2D copy blocks the host until the stream has
@@ -1637,6 +1722,60 @@ class _CTC(torch.autograd.Function):
 
 def ctc_sum(acts, labels, act_lens, label_lens, blank=0, prepared=None):
     return _CTC.apply(acts, labels, act_lens, label_lens, blank, prepared)
+
+
+class _CTCScaled(torch.autograd.Function):
+    """CTC with the loss weight (w_acoustic / N, trainer_AAS.py:168) folded into the kernel's gradient scale: the root is the vector
+    of per-utterance costs [N] (summed and scaled where it is consumed - aas_began_step_raw), backward hands the scaled gradient over
+    without a launch."""
+
+    @staticmethod
+    def forward(ctx, acts, blank, prepared, scale):
+        require_cuda(acts)
+        acts = _c(acts)
+        T, N, C = acts.shape
+        dev = acts.device
+        pr = prepared
+        if pr["N"] != N:
+            raise ValueError("CTC: %d length entries for %d utterances" % (pr["N"], N))
+        meta, nl, max_l = pr["meta"], pr["nl"], pr["max_l"]
+        d_lab, d_off, d_ll, d_al = meta[:nl], meta[nl:nl + N], meta[nl + N:nl + 2 * N], meta[nl + 2 * N:]
+        smax = 2 * max_l + 1
+        ws = torch.empty((N * (T * smax + T),), device=dev, dtype=torch.float64)
+        costs = torch.empty((N,), device=dev, dtype=torch.float32)
+        grads = torch.empty_like(acts)
+        lp = ptr(d_lab) if nl > 0 else ptr(meta)
+        with _timed("ctc", "ctc[N=%d,T=%d,L<=%d]" % (N, T, max_l), 0.0, 2 * T):
+            check(lib().aas_ctc_loss_async(stream(), ptr(acts), ptr(grads), lp, ptr(d_off), ptr(d_ll), ptr(d_al), C, N, T,
+                                           max_l, ptr(costs), ptr(ws), int(blank), float(scale)), "aas_ctc_loss_async")
+        ctx.save_for_backward(grads)
+        return costs
+
+    @staticmethod
+    def backward(ctx, g):
+        (grads,) = ctx.saved_tensors
+        if not getattr(g, "_aas_unit", False):     # a general root gradient: per-utterance factors on the [T, N, C] gradient
+            grads = grads * g.to(torch.float32).view(1, -1, 1)
+        return grads, None, None, None
+
+
+def ctc_scaled(acts, blank, prepared, scale):
+    return _CTCScaled.apply(acts, blank, prepared, scale)
+
+
+def step_prologue(bufs, rs=None, n_neg=0, n_one=0, kt=None):
+    """ONE launch at the head of a device-resident step: zero `bufs` (flat gradient buffers, loss accumulators) and write the
+    per-utterance weights rs = [-kt] * n_neg + [1] * n_one of the batched discriminator pass (include/aas_hip.h: aas_step_prologue)."""
+    import ctypes
+    n = len(bufs)
+    vp = (ctypes.c_void_p * max(n, 1))(*[int(b.data_ptr()) for b in bufs])
+    sz = (ctypes.c_size_t * max(n, 1))(*[int(b.numel() * b.element_size()) for b in bufs])
+    check(lib().aas_step_prologue(stream(), n, vp, sz, ptr(rs), int(n_neg), int(n_one), ptr(kt)), "aas_step_prologue")
+
+
+def began_step_raw(l1_acc, s_ny, s_cl, costs, s_ctc, d_kt, d_out6, gamma, lambda_k, n_batch):
+    check(lib().aas_began_step_raw(stream(), ptr(l1_acc), float(s_ny), float(s_cl), ptr(costs), int(costs.numel()), float(s_ctc), ptr(d_kt),
+                                   ptr(d_out6), float(gamma), float(lambda_k), float(n_batch)), "aas_began_step_raw")
 
 
 # --------------------------------------------------------------------------------------- reductions / optimiser

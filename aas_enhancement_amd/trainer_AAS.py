@@ -350,10 +350,23 @@ class Trainer(ops.TrainerContext):
         asr_steps = optimizer_asr is not None and (it is None or it > c.allow_ASR_update_iter)
         if not capturing:
             ops.sync_wgrad()
-        for f in self._flat.values():
-            f.flat_g.zero_()
         N = inputs.size(0)
         dev = inputs.device
+        # device-resident glue as library launches (knobs.FUSED_GLUE; single process, equal padded lengths): ONE prologue launch zeroes
+        # the flat gradient buffers and the loss accumulators and writes the discriminator's per-utterance weights [-kt]*N + [1]*N;
+        # the losses stay raw device sums until the controller launch consumes them (no scaling / slicing / summing launches)
+        fused = (knobs.get("FUSED_GLUE") and not dp.active and not capturing and tuple(cl_inputs.shape) == tuple(inputs.shape)
+                 and not self._lanes_ok(True) and self._interleave_ok())
+        self._fused = None
+        if fused:
+            if getattr(self, "_l1_acc", None) is None or self._rs_pair.numel() != 2 * N:
+                self._l1_acc = torch.zeros(2, device=dev, dtype=torch.float64)
+                self._rs_pair = torch.empty(2 * N, device=dev, dtype=torch.float32)
+            ops.step_prologue([f.flat_g for f in self._flat.values()] + [self._l1_acc], self._rs_pair, N, N, self._kt_dev)
+            self._fused = {}
+        else:
+            for f in self._flat.values():
+                f.flat_g.zero_()
         if dp.active:
             cnt = self._upload_small(torch.tensor([float(N), float(nv_ny), float(nv_cl)], dtype=torch.float64), dev)
             # global N, nElement(noisy), nElement(clean): all-reduced asynchronously and kept on the device; the loss scales are
@@ -404,7 +417,12 @@ class Trainer(ops.TrainerContext):
             if on and not capturing:
                 ops.refresh_weight_planes(net)
         if not dp.active:   # controller + log scalars in one tiny launch
-            ops.began_step(l_adv_ny_G, l_adv_cl, l_CTC, self._kt_dev, self._g_out, self.gamma, self.lb, n_glob)
+            if self._fused:     # from the raw sums: L = scale x sum inside the launch
+                ops.began_step_raw(self._fused["l1"], scales[0], scales[1], self._fused["costs"], scales[2], self._kt_dev, self._g_out,
+                                   self.gamma, self.lb, n_glob)
+                self._fused = None
+            else:
+                ops.began_step(l_adv_ny_G, l_adv_cl, l_CTC, self._kt_dev, self._g_out, self.gamma, self.lb, n_glob)
             return enhanced, prob
         # data parallel: the three loss scalars are all-reduced and kt advanced on the auxiliary stream - the main stream goes
         # straight on to the next step and only waits for this event where kt is read (the weight-gradient scaling of D)
@@ -436,9 +454,12 @@ class Trainer(ops.TrainerContext):
         overlap = self._overlap_asr()
         acoustic = None
         self._wait_kt()
-        rs = torch.empty(N + cl_inputs.size(0), device=dev, dtype=torch.float32)
-        rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
-        rs[N:] = 1.0
+        if getattr(self, "_fused", None) is not None:
+            rs = self._rs_pair.detach()        # written by the step prologue: [-kt] * N + [1] * N
+        else:
+            rs = torch.empty(N + cl_inputs.size(0), device=dev, dtype=torch.float32)
+            rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
+            rs[N:] = 1.0
         # the two utterance classes of the batched pass and their weights (device scalars), for the row-major weight-gradient GEMM
         rs._aas_classes = [(0, N, rs[0:1]), (N, cl_inputs.size(0), None)]
         if overlap:  # two chains of persistent launches side by side, half the chip each
@@ -794,7 +815,11 @@ class Trainer(ops.TrainerContext):
             if main is not caller:
                 for t_ in (enhanced, leaf, cl_inputs, rs):
                     t_.record_stream(main)
-            gD = self.D.forward_stages(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
+            fused = getattr(self, "_fused", None) is not None and scales is not None and mask is None
+            if fused:
+                gD = self.D.forward_stages(None, wgrad_row_scale=rs, pair=(leaf, cl_inputs))
+            else:
+                gD = self.D.forward_stages(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
         gA = self.ASR.forward_stages(leaf_a)
         ae = out_a = None
         while ae is None or out_a is None:
@@ -804,6 +829,22 @@ class Trainer(ops.TrainerContext):
             if out_a is None:
                 with torch.cuda.stream(side):
                     out_a = next(gA)
+        if fused:
+            # raw roots: the L1 sums [2] and the CTC costs [N]; their weights ride in the backward launches (ops.l1_pair / ctc_scaled)
+            with torch.cuda.stream(main):
+                l_pair = ops.l1_pair(ae, leaf, cl_inputs, scales[0], scales[1], self._l1_acc.detach())
+            with torch.cuda.stream(side):
+                prob = out_a.transpose(0, 1)
+                l_CTC = ops.ctc_scaled(prob, self.CTCLoss.blank, ctc_meta, scales[2])
+            self._fused.update(l1=l_pair.detach(), costs=l_CTC.detach())
+            with torch.cuda.stream(main):
+                self._backward_pair(l_pair, l_CTC, main, side)
+            if main is not caller:
+                caller.wait_stream(main)
+                for t_ in (leaf.grad, ae):
+                    if t_ is not None:
+                        t_.record_stream(caller)
+            return None, None, prob, None, leaf_a
         with torch.cuda.stream(main):
             if mask is not None:   # eager path: masked-L1 modules (host-side n_valid)
                 l_adv_ny_G, _ = self.diffLoss(ae[:Nn], leaf, mask)
@@ -842,9 +883,10 @@ class Trainer(ops.TrainerContext):
             # which the host queues the two chains does not matter; and data parallel, where the utility stream that the
             # paired call is issued from also carries the collectives (the acoustic backward then waited for the end of D's
             # forward: 19.3 vs 18.4 ms / step with one-rank RCCL).
+            unit = (lambda l: ops.unit_root(l)) if getattr(self, "_fused", None) is not None else (lambda l: None)
             with torch.cuda.stream(side):
-                loss_side.backward()
-            loss_main.backward()
+                torch.autograd.backward([loss_side], [unit(loss_side)])
+            torch.autograd.backward([loss_main], [unit(loss_main)])
             return
         if not knobs.get("NEUTRAL_BWD"):
             side.wait_stream(main)

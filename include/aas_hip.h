@@ -398,6 +398,16 @@ int aas_adam_tick(aasStream_t stream, double* d_step, double lr, double beta1, d
  * last two feed the running CTC average of the log line, :169-170,198-203). */
 int aas_began_step(aasStream_t stream, const float* d_l_adv_ny_G, const float* d_l_adv_cl, const float* d_l_ctc, double* d_kt,
                    double* d_out6, double gamma, double lambda_k, double n_batch);
+/* The same controller from the step's RAW device sums, so that no scaling / summing launch sits between the loss kernels and it:
+ * d_l1_sums[2] = sum|D(E(x)) - E(x)|, sum|D(c) - c| (aas_l1_fwd accumulators), d_ctc_costs[n_costs] = per-utterance CTC costs
+ * (aas_ctc_loss_async); L_ny = scale_ny * sums[0] (scale = w_adversarial / nElement, model.py:30, trainer_AAS.py:147), L_cl likewise,
+ * L_ctc = scale_ctc * sum(costs) (w_acoustic / N, :168); each rounded to fp32 as the tensors of the reference are. */
+int aas_began_step_raw(aasStream_t stream, const double* d_l1_sums, double scale_ny, double scale_cl, const float* d_ctc_costs, int n_costs,
+                       double scale_ctc, double* d_kt, double* d_out6, double gamma, double lambda_k, double n_batch);
+/* Start of a training step in ONE launch: zero up to 8 device buffers (16-byte aligned; the flat gradient buffers = zero_grad_all,
+ * trainer_AAS.py:134, and the loss accumulators) and, when rs != NULL, write the per-utterance weights of the batched
+ * [enhanced; clean] discriminator pass: rs[0 .. n_neg) = -(float) d_kt[0] (the D-step factor, :156-160), rs[n_neg .. n_neg + n_one) = 1. */
+int aas_step_prologue(aasStream_t stream, int n, void* const* bufs, const size_t* bytes, float* rs, int n_neg, int n_one, const double* d_kt);
 
 /* ---------------------------------------------------------------- features --------------------
  * log-Mel filterbank: wave [N,S] -> out [N,n_mels,T] with T = 1 + S/hop; hamming(periodic) window
