@@ -125,6 +125,12 @@ class DPContext(object):
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             tensor.copy_(host)
             return _Done()
+        if tensor.is_cuda:
+            from . import ops
+            # (ops.Profiler class "coll": HIP events on the issuing stream around the call - WHEN a bucket's collective becomes
+            #  eligible relative to the step's other launches; tools/event_timeline.py --classes rnn,gemm,coll)
+            with ops._timed("coll", "allreduce[%.1f MB]" % (tensor.numel() * tensor.element_size() / 2.0 ** 20), 0.0):
+                return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def broadcast_(self, tensor, src=0):

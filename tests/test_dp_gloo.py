@@ -314,3 +314,61 @@ def test_precision_context_restores_the_previous_mode():
         assert ops.get_precision() == base
     finally:
         ops.set_precision(base)
+
+
+# ---- bench.py --gpus 8: the worker-side bookkeeping on eight gloo ranks (CPU) ----------------------------------------------------
+def _bench8_worker(rank, world, port, q):
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        from aas_enhancement_amd.dist import DPContext
+        dp = DPContext.from_env()
+        assert dp.active and dp.world == world and dp.rank == rank
+        dev = torch.device("cpu")
+        # every rank draws its own shard of the synthetic global batch: same shapes, different members of the PRNG families
+        ny, cl = bench.make_batches(rank, dev, n=3)
+        sig = torch.tensor([float(ny[0].double().sum()), float(cl[0].double().sum()), float(ny[1].double().sum())], dtype=torch.float64)
+        gathered = [torch.zeros_like(sig) for _ in range(world)]
+        dist.all_gather(gathered, sig)
+        # global normalisers as the trainer forms them (N, nElement noisy / clean summed over the ranks)
+        counts = dp.global_counts([ny[0].shape[0], ny[4].n_valid, cl[4].n_valid])
+        # the timed region: rank r "measured" (1 + r/10) s for 4 steps - the contract takes the MAX over ranks
+        dt = bench.max_over_ranks(1.0 + rank / 10.0, world, dev)
+        value, ms = bench.whole_job(world, bench.N_PER * bench.T, dt, 4)
+        q.put((rank, [g.tolist() for g in gathered], list(counts), dt, value, ms, bench.rank_seeds(rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_worker_bookkeeping_world8():
+    """What `bench.py --gpus 8` does on each of its eight ranks besides stepping the trainer, on eight gloo ranks here: per-rank
+    shards of the synthetic batch are distinct and reproducible, the global normalisers are the sums over the ranks, the step time
+    is the MAX over ranks on every rank, `value` is the whole job's frames / s (8 x 30 x 200 frames per step), and the launcher
+    path hands `--gpus 8` to eight workers (tests/test_abi.py covers the command line)."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys_path = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, sys_path)
+    import bench
+    sigs = res[0][1]
+    assert len({tuple(s) for s in sigs}) == world                          # eight different shards ...
+    assert all(r[1] == sigs for r in res)                                  # ... and every rank saw the same eight
+    assert [r[6] for r in res] == [(123 + r, 125 + r, 124 + r) for r in range(world)]
+    for r in res:
+        assert r[2] == [3 * world, 3 * bench.T * world, 3 * bench.T * world]   # global N, nElement(noisy), nElement(clean)
+        assert r[3] == pytest.approx(1.7)                                  # MAX over ranks (rank 7's 1.7 s), on every rank
+        assert r[4] == pytest.approx(world * bench.N_PER * bench.T / (1.7 / 4)) and r[5] == pytest.approx(425.0)

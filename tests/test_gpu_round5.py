@@ -353,3 +353,48 @@ def test_split_k_workspace_growth_keeps_captured_graphs_valid(gpu):
         del junk
     finally:
         L.aas_set_gemm_max_steps(prev)
+
+
+def test_22bit_bptt_exchange_is_below_the_references_own_thread_count_spread(gpu):
+    """fp32 headline: the reduce-scatter BPTT exchanges partial sums whose two low mantissa bits carry the step tag (a 22-bit
+    exchange, <= 2 ulp per partial).  Is that visible at the gradient level?  The same F3b step runs twice: with the shipped
+    kernels, and with the BPTT on the counter-based kernels of round 1 (kernel-selection bit 256: whole fp32 words exchanged, and a
+    different summation order on top).  The difference between the two - an UPPER bound of the 22-bit effect - is compared, per
+    parameter, with how far the reference's own fp32-CPU gradient samples move when only the CPU thread count changes (F3c: 8 / 3 /
+    1 threads).  Both are measured against the same 64 samples per parameter, in units of the largest sample."""
+    from aas_enhancement_amd import ops
+    from aas_enhancement_amd.trainer_AAS import Trainer
+    z, zc = load("f3b_aas_config2_kt.npz"), load("f3c_thread_spread.npz")
+    grads = []
+    for flags in (0, 256):
+        tr = Trainer(cfg(lr=float(z["lr"]), nFeat=80, rnn_size=500, allow_ASR_update_iter=0), None, models=_config2_models())
+        tr.kt = float(z["kt0"])
+        tr.launch = ops.LaunchState(debug_flags=flags)
+        ny, cl = _config2_batches(0)
+        tr.train_step_async(ny, cl, 0)
+        tr.read_scalars()
+        g = {}
+        for nm, m in (("G", tr.G), ("D", tr.D), ("A", tr.ASR)):
+            for k, p in m.named_parameters():
+                key = "%s.%s" % (nm, k)
+                if k in NOISE_PARAMS or ("it0.gradsample_idx." + key) not in z.files:
+                    continue
+                idx = torch.from_numpy(z["it0.gradsample_idx." + key].astype(np.int64)).cuda()
+                g[key] = p.grad.detach().reshape(-1)[idx].cpu().numpy()
+        grads.append(g)
+    assert not ops.rnn_timeout_flag()
+    dev22, spread, vs_ref = {}, {}, {}
+    for key in grads[0]:
+        ref = z["it0.gradsample." + key]
+        scale = float(np.abs(ref).max()) + 1e-30
+        dev22[key] = float(np.abs(grads[0][key] - grads[1][key]).max()) / scale
+        spread[key] = float(np.abs(zc["hi." + key] - zc["lo." + key]).max()) / scale
+        vs_ref[key] = float(np.abs(grads[0][key] - ref).max()) / scale
+    w22, wsp = max(dev22.values()), max(spread.values())
+    m22, msp = float(np.median(list(dev22.values()))), float(np.median(list(spread.values())))
+    print("shipped vs whole-word-exchange BPTT: worst %.2e median %.2e | reference across thread counts: worst %.2e median %.2e | shipped vs reference: worst %.2e"
+          % (w22, m22, wsp, msp, max(vs_ref.values())))
+    assert len(dev22) >= 70
+    # no parameter's samples move more than the reference's own worst thread-count movement, and the typical movement is smaller too
+    assert w22 <= wsp, (w22, wsp, max(dev22, key=dev22.get))
+    assert m22 <= msp, (m22, msp)

@@ -298,6 +298,35 @@ def f3b_config2_kt():
     np.savez_compressed(os.path.join(OUT, "f3b_aas_config2_kt.npz"), **out)
 
 
+def f3c_thread_spread():
+    """F3c: how far the reference's OWN fp32 result moves when only the CPU thread count changes (summation orders inside the
+    BLAS / oneDNN kernels): iteration 0 of F3b (kt0 = 0.3) run with 8, 3 and 1 threads; per parameter the 64 gradient samples of F3b
+    as min / max over the runs.  The yardstick for "is a rounding-level difference of this build's kernels visible at the gradient
+    level" (tests/test_gpu_round5.py: the 22-bit partial-sum exchange of the reduce-scatter BPTT)."""
+    Fdim, H, HA, M, N, T, L = 80, 500, 1000, 128, 30, 200, 20
+    cfg = dict(w_adversarial=1.0, w_acoustic=1.0, gamma=0.5, lambda_k=0.001, allow_ASR_update_iter=0)
+    ny = dict(inputs=prng.uniform(123, (N, Fdim, T), 0.0, 6.0), mask=np.zeros((N, 1, T), np.uint8), pct=np.ones(N, np.float32),
+              targets=prng.randint(125, (N * L,), 1, 28).astype(np.int32), target_sizes=np.full(N, L, np.int32))
+    cl = dict(inputs=prng.uniform(124, (N, Fdim, T), 0.0, 6.0), mask=np.zeros((N, 1, T), np.uint8))
+    runs = []
+    threads = (8, 3, 1)
+    for nt in threads:
+        torch.set_num_threads(nt)
+        G, D, A = build_aas(Fdim, H, HA, M, 5, seed=9000)
+        og, od, oa = adam(G, 1e-5), adam(D, 1e-5), adam(A, 1e-5)
+        _, sc, grads, *_ = aas_iteration(G, D, A, og, od, oa, ny, cl, cfg, 0.3, 0, REF.L1Loss_mask())
+        runs.append({k: g.reshape(-1)[sample_idx(51, g.shape, min(64, g.size))].copy() for k, g in grads.items()})
+        print("F3c threads", nt, sc["l_ctc"], flush=True)
+    torch.set_num_threads(8)
+    out = dict(threads=np.asarray(threads), kt0=0.3)
+    for k in runs[0]:
+        st = np.stack([r[k] for r in runs])
+        out["lo." + k], out["hi." + k] = st.min(0), st.max(0)
+    np.savez_compressed(os.path.join(OUT, "f3c_thread_spread.npz"), **out)
+    worst = max(float(np.abs(out["hi." + k] - out["lo." + k]).max() / (np.abs(out["hi." + k]).max() + 1e-30)) for k in runs[0])
+    print("F3c worst spread / max|sample|:", worst)
+
+
 def f4_ops():
     """F4: per-op vectors from the reference's own BRNN / BatchRNN / DeepSpeech.conv / L1Loss_mask."""
     out = {}
@@ -812,7 +841,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if a.only:
         table = dict(f1=f1_tiny, f2=f2_dce, f3=f3_config2, f4=f4_ops, f5=f5_fsegan_am, f6=f6_fsegan_config4,
-                     f7=f7_am_config5, f8=f8_host_side, f9=f9_rnn_kind, f10=f10_acoustic, f3b=f3b_config2_kt, f11=f11_am_model_ken, f12=f12_cli_defaults)
+                     f7=f7_am_config5, f8=f8_host_side, f9=f9_rnn_kind, f10=f10_acoustic, f3b=f3b_config2_kt, f11=f11_am_model_ken, f12=f12_cli_defaults, f3c=f3c_thread_spread)
         for k in a.only.split(","):
             table[k]()
         sys.exit(0)
@@ -827,6 +856,7 @@ if __name__ == "__main__":
     if not a.skip_big:
         f3_config2()
         f3b_config2_kt()
+        f3c_thread_spread()
         f6_fsegan_config4()
         f7_am_config5()
         f10_acoustic()
