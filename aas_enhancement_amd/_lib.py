@@ -25,6 +25,9 @@ SIGNATURES = {
     "aas_set_debug_flags": [c_int],
     "aas_get_debug_flags": [],
     "aas_get_gemm_max_steps": [],
+    "aas_rnn_xchg_prepare": [c_vp, c_vp, c_sz],
+    "aas_rnn_xchg_forget": [c_vp],
+    "aas_rnn_xchg_is_managed": [c_vp],
     "aas_release_retired_workspaces": [],
     "aas_set_precision": [c_int],
     "aas_set_rnn_launch_tag": [c_int],

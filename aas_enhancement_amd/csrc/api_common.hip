@@ -88,6 +88,76 @@ extern "C" int aas_release_retired_workspaces(void) {
     return n;
 }
 
+namespace {
+struct XchgState {
+    size_t bytes = 0;         // whole buffer: two halves of bytes / 2
+    unsigned parity = 0;      // half the NEXT launch works in
+    size_t dirty[2] = {0, 0}; // bytes of each half that its last launch may have left un-poisoned
+};
+std::mutex g_xchg_mu;
+std::map<void*, XchgState> g_xchg;
+}  // namespace
+
+extern "C" int aas_rnn_xchg_prepare(aasStream_t stream, void* xchg, size_t bytes) {
+    AAS_CHECK(xchg != nullptr && (reinterpret_cast<uintptr_t>(xchg) & 255) == 0 && bytes >= 8192 && bytes % 512 == 0,
+              "aas_rnn_xchg_prepare: a 256-byte aligned buffer of a multiple of 512 bytes");
+    AAS_HIP(hipMemsetAsync(xchg, 0xFF, bytes, (hipStream_t)stream));
+    std::lock_guard<std::mutex> lk(g_xchg_mu);
+    XchgState st;
+    st.bytes = bytes;
+    g_xchg[xchg] = st;
+    return 0;
+}
+
+extern "C" int aas_rnn_xchg_forget(void* xchg) {
+    std::lock_guard<std::mutex> lk(g_xchg_mu);
+    return g_xchg.erase(xchg) ? 0 : 1;
+}
+
+int aas_xchg_plan(void* xchg, size_t need_bytes, hipStream_t s, AasXchgPlan* out) {
+    out->base = static_cast<unsigned*>(xchg);
+    out->clean_ptr = nullptr;
+    out->clean_words = 0;
+    out->managed = 0;
+    std::lock_guard<std::mutex> lk(g_xchg_mu);
+    auto it = g_xchg.find(xchg);
+    if (it == g_xchg.end()) return 0;
+    XchgState& st = it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    need_bytes = (need_bytes + 15) & ~(size_t)15;
+    if (capturing || need_bytes > st.bytes / 2) {
+        // a captured launch would replay with the parity of capture time, and a launch that does not fit a half takes the whole
+        // buffer: either way the alternation ends here - the caller poisons the buffer itself from now on (correct, one launch more)
+        g_xchg.erase(it);
+        return 0;
+    }
+    const unsigned h = st.parity;
+    char* b = static_cast<char*>(xchg);
+    out->base = reinterpret_cast<unsigned*>(b + (size_t)h * (st.bytes / 2));
+    out->clean_ptr = reinterpret_cast<unsigned*>(b + (size_t)(h ^ 1) * (st.bytes / 2));
+    out->clean_words = (unsigned)(st.dirty[h ^ 1] / 4);
+    out->managed = 1;
+    st.dirty[h ^ 1] = 0;
+    st.dirty[h] = need_bytes;
+    st.parity = h ^ 1;
+    return 0;
+}
+
+int aas_xchg_legacy_fill(void* xchg, size_t bytes, hipStream_t s) {
+    {
+        std::lock_guard<std::mutex> lk(g_xchg_mu);
+        g_xchg.erase(xchg);
+    }
+    AAS_HIP(hipMemsetAsync(xchg, 0xFF, bytes, s));
+    return 0;
+}
+
+extern "C" int aas_rnn_xchg_is_managed(void* xchg) {
+    std::lock_guard<std::mutex> lk(g_xchg_mu);
+    return g_xchg.count(xchg) ? 1 : 0;
+}
+
 const char* aas_ablation_env(const char* name) {
     static const bool on = getenv("AAS_ABLATION") && atoi(getenv("AAS_ABLATION")) == 1;
     return on ? getenv(name) : nullptr;

@@ -30,6 +30,19 @@ int aas_rnn_cus();  // aas_device_cus() capped by aas_set_rnn_cu_limit()
 // demand (at least doubling).  A block that is outgrown is RETIRED, not freed: a captured hipGraph may have its address baked into
 // its nodes, and a queued launch may still read it - retired blocks are released by aas_release_retired_workspaces() or at exit.
 // -> nullptr when the block would have to grow while `s` is under hipGraph capture (nothing may be allocated there).
+// Managed exchange buffers of the persistent recurrent launches (aas_rnn_xchg_prepare): the buffer is two halves; a launch works in
+// one half - poisoned by its predecessor - and, inside the kernel, re-poisons what its predecessor dirtied in the OTHER half, so no
+// memset launch stands between two persistent launches.  -> managed = 0: the caller poisons the buffer itself (legacy path).
+struct AasXchgPlan {
+    unsigned* base;          // the half this launch works in
+    unsigned* clean_ptr;     // 16-byte aligned region of the other half to poison from inside the kernel
+    unsigned clean_words;    // (multiple of 4)
+    int managed;
+};
+int aas_xchg_plan(void* xchg, size_t need_bytes, hipStream_t s, AasXchgPlan* out);
+// the legacy path: poison `bytes` of the buffer with a memset launch; a managed buffer stops being managed (its halves no longer
+// hold what the protocol assumes)
+int aas_xchg_legacy_fill(void* xchg, size_t bytes, hipStream_t s);
 enum { AAS_WS_GEMM_SLABS = 0, AAS_WS_BN_PARTIALS = 1 };
 void* aas_stream_workspace(int kind, hipStream_t s, size_t bytes, size_t floor_bytes);
 

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(16 * U, 1) void rnn_bwd_rs_kernel(RnnP p) {
                 }
             }
     }
+    xchg_clean_other_half(p);           // managed exchange buffer: rnn_split_kernel.h
     // plain (L2-resident) publish stores when the whole set shares an XCD (rnn_split_kernel.h: xcd_set_colocated)
     __shared__ unsigned long long xcd_flag;
     unsigned long long local = 0ull;    // bit c: consumer slice c shares this workgroup's XCD
@@ -582,7 +583,15 @@ int run_bwd_rs(const char* name, RnnP p, hipStream_t s) {
         if (p.P * cdiv(p.N, cand) * 2 <= cus) { rpg = cand; break; }
     p.rpg = rpg;
     const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
-    AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, rbytes + XCD_TAB_BYTES, s));      // tag 3 = "no step's value yet" (+ the XCC table)
+    // tag 3 = "no step's value yet" (+ the XCC table): the poison memset - or, on a managed buffer (one launch for the batch), this
+    // launch's half, poisoned by its predecessor from inside its kernel
+    AasXchgPlan plan = {};
+    if (p.N <= qmax * rpg) aas_xchg_plan(p.xchg, rbytes + XCD_TAB_BYTES, s, &plan);
+    if (plan.managed) {
+        p.xchg = plan.base; p.clean_ptr = plan.clean_ptr; p.clean_words = plan.clean_words;
+    } else {
+        if (aas_xchg_legacy_fill(p.xchg, rbytes + XCD_TAB_BYTES, s)) return 2;
+    }
     for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {
         p.n0 = n0;
         const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;

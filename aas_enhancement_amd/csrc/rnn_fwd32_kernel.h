@@ -80,13 +80,18 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
     // exchange rows: [2][T][N] rows of KC 128-byte chunks (32 units: 64 B bf16 hi | 64 B bf16 lo)
     const int KC = Hp / 32;
     unsigned* xq = p.xchg;
-    auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xq, 0, (int)((int64_t)2 * T * N * KC * 128), 0x00020000);
+    // ring form of a managed buffer (exact kernels only): [2][4 time slots][N] rows, see rnn_split_kernel.h
+    const bool ring = EX && p.ring;
+    const int TR = ring ? 4 : T;
+    auto xrow_f = [&](int dd, int tt) -> int64_t { return ring ? (int64_t)(dd * 4 + (tt & 3)) : (int64_t)dd * T + tt; };
+    auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xq, 0, (int)((int64_t)2 * TR * N * KC * 128), 0x00020000);
+    xchg_clean_other_half(p);
     constexpr unsigned OOB = 0x80000000u;
     constexpr unsigned POISON = 0xFFFFFFFFu;
     __shared__ unsigned long long xcd_flag;
     bool plain = false;   // plain (L2-resident) publish stores once the set is verified to share an XCD
     if (p.xcd) {
-        unsigned* tab = xq + (int64_t)2 * T * N * KC * 32;
+        unsigned* tab = xq + (int64_t)2 * TR * N * KC * 32;
         plain = xcd_set_colocated(tab, xset, pslice, p.P, err, p.tag, &xcd_flag, p.sync + XSTAT_WORD + 4 * (MODE == LSTM_FWD ? 0 : 2)) && !(p.flags & 524288) && p.xcd == 1;
     }
 
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
         for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
             const int m = lane & 15, q = lane >> 4;
-            const int64_t xr0 = ((int64_t)d * T + tp) * N + q0;
+            const int64_t xr0 = xrow_f(d, tp) * N + q0;
             if (!(p.flags & 4)) {
                 // poll one word per producer slice of my k range (first row of the group)
                 const int nprod = (KS * 32) / U;
@@ -299,10 +304,15 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
         // stores its own fp32 word
         if constexpr (EX) {
             if (rowok && s + 1 < T && !(p.flags & 8)) {
-                const int64_t xr = ((int64_t)d * T + t) * N + gr;
+                const int64_t xr = xrow_f(d, t) * N + gr;
                 unsigned* wq = xq + xr * KC * 32 + unit;
                 if (plain) st_sc0_u32(wq, __float_as_uint(hval));
                 else st_sc1_u32(wq, __float_as_uint(hval));
+            }
+            if (ring && rowok && s >= 2) {     // the word published two steps ago is poison again (rnn_split_kernel.h: why this is safe)
+                unsigned* cq = xq + (xrow_f(d, d == 0 ? t - 2 : t + 2) * N + gr) * KC * 32 + unit;
+                if (plain) st_sc0_u32(cq, 0xFFFFFFFFu);
+                else st_sc1_u32(cq, 0xFFFFFFFFu);
             }
         } else {
             unsigned h0, l0;
@@ -364,7 +374,14 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
         if (p.P * cdiv(p.N, cand) * 2 <= cus) { rpg = cand; break; }
     p.rpg = rpg;
     const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
-    AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes + XCD_TAB_BYTES, s));
+    // managed buffer (exact kernels, one launch for the batch): ring of four time slots in this launch's half, no memset launch
+    AasXchgPlan plan = {};
+    if (EX && p.N <= qmax * rpg && p.T >= 4) aas_xchg_plan(p.xchg, (size_t)2 * 4 * p.N * (Hp / 32) * 128 + XCD_TAB_BYTES, s, &plan);
+    if (plan.managed) {
+        p.xchg = plan.base; p.clean_ptr = plan.clean_ptr; p.clean_words = plan.clean_words; p.ring = 1;
+    } else {
+        if (aas_xchg_legacy_fill(p.xchg, (size_t)xbytes + XCD_TAB_BYTES, s)) return 2;
+    }
     // one launch covers the batch: afterwards the buffer holds h_t of every step but each direction's last as operand planes
     aas_note_fwd_h_planes((!EX && p.N <= qmax * rpg) ? (Hp / 32) * 128 : 0);
     for (int n0 = 0; n0 < p.N; n0 += qmax * rpg) {

@@ -54,6 +54,10 @@ struct RnnP {
     int tag;             // written to the sticky error word when a bounded spin times out (aas_set_rnn_launch_tag)
     int flags;           // debug/ablation bits (aas_set_debug_flags): 1 no exchange loads, 2 no MFMA, 4 no wait, 8 no publish
     int xcd;             // bit 0: XCD-aware 1-D grid (8 sets of P workgroups, a set per XCD class); bit 1: plain publish stores
+    // managed exchange buffer (aas_rnn_xchg_prepare; common.h: AasXchgPlan): the region of the OTHER half this launch poisons itself
+    unsigned* clean_ptr;
+    unsigned clean_words;
+    int ring;            // exact forward kernels: h_t exchanged through 4 time slots ([2][4][N] rows), producers re-poison behind themselves
 };
 
 __device__ __forceinline__ unsigned ld_cnt(const unsigned* p) {

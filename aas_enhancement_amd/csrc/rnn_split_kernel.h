@@ -54,6 +54,21 @@ __device__ __forceinline__ void st_sc0_u32(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Managed exchange buffer (common.h: AasXchgPlan): every thread of the grid poisons its share of what the PREVIOUS launch on this
+// buffer left un-poisoned in the other half (write-through 16-byte stores; that launch is complete, nobody reads the region now,
+// and the launch after this one works there).  Replaces the poison memset launch in front of every persistent launch.
+__device__ __forceinline__ void xchg_clean_other_half(const RnnP& p) {
+    if (p.clean_words == 0) return;
+    const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned n4 = p.clean_words >> 2;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.clean_ptr, 0, (int)(p.clean_words * 4u), 0x00020000);
+    using B128 = decltype(__builtin_amdgcn_raw_buffer_load_b128(rs, 0, 0, 0));
+    const u32x4 poison = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (unsigned i = bid * blockDim.x + threadIdx.x; i < n4; i += nb * blockDim.x)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(B128, poison), rs, (int)(i * 16u), 0, 16);
+}
+
 // ---- operand fragments of one 32-wide k chunk, in the two arithmetic modes of the persistent kernels -----------------------
 // EX = false (aas_set_precision(1)): bf16 hi / lo halves, 8 consecutive k per lane, three v_mfma_f32_16x16x32_bf16.
 // EX = true  (aas_set_precision(0)): the fp32 values themselves, 8 consecutive k per lane (k = 8q + j feeds the j-th of eight
@@ -234,7 +249,12 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     }
 
     // exchange arrays: hi then lo, each rows x (Kxp/2) 32-bit words
-    const int64_t xrows = (int64_t)2 * T * N;           // fwd: [2][T][N]; bwd: [T][N][2]
+    // fwd: [2][T][N] rows - or, ring form of a managed buffer (exact forward kernels only), [2][4 time slots][N]: the row of time
+    // index t is slot t & 3, and its producers poison their words again two steps after they published them (below);  bwd: [T][N][2]
+    const bool ring = FWD && EX && p.ring;
+    const int64_t xrows = ring ? (int64_t)2 * 4 * N : (int64_t)2 * T * N;
+    auto xrow_f = [&](int dd, int tt) -> int64_t { return ring ? (int64_t)(dd * 4 + (tt & 3)) : (int64_t)dd * T + tt; };
+    xchg_clean_other_half(p);
     // row = KC chunks of 128 bytes; chunk c holds elements [32c, 32c+32): 64 B of bf16 hi then 64 B of bf16 lo, so the
     // hi and lo fragments of a chunk share one 128-byte line (half as many distinct lines per step as two arrays)
     const int KC = (Kxp + 31) / 32;
@@ -311,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int gr = q0 + mt * 16 + m;
-                const int64_t xr = FWD ? ((int64_t)d * T + tp) * N + gr : ((int64_t)tp * N + gr) * 2 + d;
+                const int64_t xr = FWD ? xrow_f(d, tp) * N + gr : ((int64_t)tp * N + gr) * 2 + d;
                 roff[mt] = (gr < NB && !(p.flags & 1)) ? (unsigned)((xr * KC + wave * KS) * 128) + frag_off0<EX>(q) : OOB;
             }
             const int klane = kb + q * 8;
@@ -362,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             // with 16-byte re-loads while the step's data is in flight.
             if (!(p.flags & 4)) {
                 const int nprod = (KS * 32) / U;               // producer slices inside this wave's k-range
-                const int64_t xr0 = FWD ? ((int64_t)d * T + tp) * N + q0 : ((int64_t)tp * N + q0) * 2 + d;
+                const int64_t xr0 = FWD ? xrow_f(d, tp) * N + q0 : ((int64_t)tp * N + q0) * 2 + d;
                 const int kprobe = kb + lane * U;
                 const bool probe = lane < nprod && kprobe < Kxp && !(p.flags & 1);
                 const unsigned* wp = xq + xr0 * KC * 32 + elem_word<EX>(kprobe);
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     const int gr = q0 + rb * 4 + i4;
-                    const int64_t xr = ((int64_t)d * T + tp) * N + gr;
+                    const int64_t xr = xrow_f(d, tp) * N + gr;
                     hoff[rb] = (gr < NB && !(p.flags & 1)) ? (unsigned)(xr * KC * 128 + (kb + bq * 4) * 4) : OOB;
                 }
                 auto load_all = [&]() {
@@ -566,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             }
             // publish: even-unit lanes store {own, partner} packed hi and lo words (pad units publish zeros)
             constexpr int GX = FWD ? 1 : G;
-            const int64_t xr = FWD ? ((int64_t)d * T + t) * N + gr : ((int64_t)t * N + gr) * 2 + d;
+            const int64_t xr = FWD ? xrow_f(d, t) * N + gr : ((int64_t)t * N + gr) * 2 + d;
             const int64_t rbase_w = xr * KC * 32;  // row start in 32-bit words
 #pragma unroll
             for (int g = 0; g < GX; ++g) {
@@ -576,6 +596,17 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                         unsigned* wq = xq + rbase_w + k;
                         if (plain) st_sc0_u32(wq, __float_as_uint(xv[g]));
                         else st_sc1_u32(wq, __float_as_uint(xv[g]));
+                    }
+                    if constexpr (FWD) {
+                        // ring: the word this lane published two steps ago is poison again.  Every workgroup of the set has read
+                        // that row: this workgroup is past the reduction barrier of step s, so all its waves have seen every
+                        // producer's h of step s-1, and a producer publishes that only after its own reads of step s-2's row.
+                        // The slot is written next at step s+2 - a whole step (with its vmcnt(0) waits) after this store.
+                        if (ring && rowok && s >= 2) {
+                            unsigned* cq = xq + (xrow_f(d, d == 0 ? t - 2 : t + 2) * N + gr) * KC * 32 + k;
+                            if (plain) st_sc0_u32(cq, 0xFFFFFFFFu);
+                            else st_sc1_u32(cq, 0xFFFFFFFFu);
+                        }
                     }
                 } else {
                     unsigned h0, l0;
@@ -692,11 +723,25 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
         const int rows = (p.N - n0) < qmax * rpg ? (p.N - n0) : qmax * rpg;
         p.n1 = n0 + rows;
         p.Q = cdiv(rows, rpg);
-        // poison the exchange arrays: a word is valid data once it is no longer 0xFFFFFFFF (+ the XCC table)
-        AAS_HIP(hipMemsetAsync(p.xchg, 0xFF, (size_t)xbytes + XCD_TAB_BYTES, s));
+        // poison the exchange arrays: a word is valid data once it is no longer 0xFFFFFFFF (+ the XCC table) - or, on a managed buffer
+        // (exact forward kernels, one launch for the batch), the ring of four time slots in this launch's half: no memset launch
+        AasXchgPlan plan = {};
+        unsigned* const xchg0 = p.xchg;
+        if (FWD && EX && p.N <= qmax * rpg && p.T >= 4) aas_xchg_plan(p.xchg, (size_t)2 * 4 * p.N * ((kxp + 31) / 32) * 128 + XCD_TAB_BYTES, s, &plan);
+        p.clean_ptr = nullptr; p.clean_words = 0; p.ring = 0;
+        if (plan.managed) {
+            p.xchg = plan.base; p.clean_ptr = plan.clean_ptr; p.clean_words = plan.clean_words; p.ring = 1;
+        } else {
+            if (aas_xchg_legacy_fill(p.xchg, (size_t)xbytes + XCD_TAB_BYTES, s)) return 2;
+        }
         p.xcd = (FWD && (p.Q * 2) % 8 == 0 && p.P * (p.Q * 2 / 8) <= 32 && rpg <= 8 && !(p.flags & 262144)) ? 1 : 0;   // (see rnn_fwd32_kernel.h)
         int rc = (mt == 1) ? launch_split_mt<MODE, 1, EX>(p, ks_need, s) : launch_split_mt<MODE, 2, EX>(p, ks_need, s);
-        if (rc != 0) return -1;
+        p.xchg = xchg0;
+        if (rc != 0) {
+            // (no kernel of this family covers the shape: the caller runs another one on the whole buffer.  A managed half that was
+            //  planned but not used stays poisoned: nothing was written.)
+            return -1;
+        }
         AAS_LAUNCH_CHECK(name);
     }
     return 0;

@@ -60,6 +60,7 @@ _TABLE = {
     "CLASS_WGRAD": (True, _b),
     "MULTI_WGRAD": (True, _b),
     "TN_WGRAD": (True, _b),
+    "MANAGED_XCHG": (True, _b),       # managed exchange buffers: no poison memset launch in front of a persistent launch
     "FUSED_GLUE": (True, _b),         # step prologue / epilogue launches instead of torch eager glue
     "GEMM32_MAXSTEPS": (48, _i),      # lifetime cap (k-steps) of a GEMM workgroup inside the training step
 }

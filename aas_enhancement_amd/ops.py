@@ -81,14 +81,35 @@ def check_rnn_health(scalars=()):
         raise FloatingPointError("training diverged: non-finite loss scalars %r" % (list(scalars),))
 
 
-def _xchg_buf(dev, T, N, H, G):
-    """split-bf16 exchange scratch of the persistent RNN kernels (per device+stream, grown on demand)."""
-    need = int(lib().aas_rnn_xchg_bytes(T, N, H, G))
-    key = ("xchg", dev, torch.cuda.current_stream().cuda_stream)
+def _xchg_buf(dev, T, N, H, G, kind="any"):
+    """Exchange scratch of the persistent RNN kernels, per device + stream (+ kind), grown on demand.
+    kind "fwd" / "bwd": a MANAGED buffer (include/aas_hip.h: aas_rnn_xchg_prepare) - twice the size a launch needs, poison-filled
+    once here; the library then alternates the launches between its halves and the kernels re-poison behind themselves, so no memset
+    launch precedes a persistent launch.  Forward and BPTT launches keep separate buffers (their exchange protocols differ).  When the
+    library had to fall back on a buffer (hipGraph capture, an A/B kernel that takes the whole buffer) it is prepared again here."""
+    if kind == "any":
+        need = int(lib().aas_rnn_xchg_bytes(T, N, H, G))
+        key = ("xchg", dev, torch.cuda.current_stream().cuda_stream)
+        b = _scratch.get(key)
+        if b is None or b.numel() < need:
+            b = torch.empty(need, dtype=torch.uint8, device=dev)
+            _scratch[key] = b
+        return b
+    if kind == "fwd":       # rows [2][T][N] of ceil(Hp / 32) 128-byte chunks (the legacy form is what sizes the buffer) + the XCC table
+        need = 2 * T * N * ((H + 31) // 32 + 1) * 128 + 8192
+    else:
+        need = int(lib().aas_rnn_xchg_bytes(T, N, H, G))
+    need = (2 * need + 511) // 512 * 512
+    key = ("xchg_" + kind, dev, torch.cuda.current_stream().cuda_stream)
     b = _scratch.get(key)
-    if b is None or b.numel() < need:
+    grown = b is None or b.numel() < need
+    if grown:
+        if b is not None:
+            lib().aas_rnn_xchg_forget(ptr(b))
         b = torch.empty(need, dtype=torch.uint8, device=dev)
         _scratch[key] = b
+    if (grown or not lib().aas_rnn_xchg_is_managed(ptr(b))) and not torch.cuda.is_current_stream_capturing():
+        check(lib().aas_rnn_xchg_prepare(stream(), ptr(b), b.numel()), "aas_rnn_xchg_prepare")
     return b
 
 
@@ -1026,7 +1047,7 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None):
     if keep is not None and _precision[0] == 1:   # a buffer of the layer's own: it is read again by the backward pass
         xchg = torch.empty(int(lib().aas_rnn_xchg_bytes(T, N, H, G)), dtype=torch.uint8, device=dev)
     else:
-        xchg = _xchg_buf(dev, T, N, H, G)
+        xchg = _xchg_buf(dev, T, N, H, G, "fwd" if (_precision[0] != 1 and knobs.get("MANAGED_XCHG")) else "any")
     rflops = 2.0 * 2 * T * N * H * G * H  # both directions, T steps of [N,H]x[H,G*H]
     lib().aas_set_rnn_launch_tag(2 * lid if lid else 1)
     if kind == "rnn":
@@ -1059,7 +1080,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     dev = x.device
     dy = _c(dy)
     sync = _sync_buf(dev)
-    xchg = _xchg_buf(dev, T, N, H, G)
+    xchg = _xchg_buf(dev, T, N, H, G, "bwd" if knobs.get("MANAGED_XCHG") else "any")
     R = T * N
     use_planes = (_precision[0] == 1 and kind != "rnn" and PLANES_BWD[0] and R >= 1024 and H >= 64 and I >= 64 and GH % 8 == 0
                   and w_ih_r.data_ptr() != w_ih.data_ptr() and (w_ih_r.data_ptr() - w_ih.data_ptr()) % 4 == 0)

@@ -56,6 +56,18 @@ int aas_get_debug_flags(void);
  * up after ~0.5 s and stores the tag of its launch in a sticky error word at byte 4096 of the launch's `sync` buffer
  * (never cleared by the library): the host reads it at its next synchronisation point and names the layer. */
 int aas_set_rnn_launch_tag(int tag);
+/* Exchange buffers of the persistent recurrent launches (the `xchg` argument of aas_lstm_fwd / _bwd, aas_gru_fwd / _bwd).  By
+ * default every launch poison-fills the part of the buffer it uses first (a memset launch of 8-50 MB per recurrent launch).  A
+ * buffer handed to aas_rnn_xchg_prepare ONCE (poison-filled there, `bytes` = at least twice what the largest launch needs:
+ * 2 * aas_rnn_xchg_bytes(...)) is MANAGED: the library alternates the launches on it between its two halves, every kernel
+ * re-poisons inside the kernel what its predecessor dirtied in the other half, and the fp32 forward kernels exchange h_t through a
+ * ring of four time slots that its producers clean behind themselves - no memset launch at all between recurrent launches.  The
+ * caller must not touch a managed buffer, must use it from one stream at a time, and calls aas_rnn_xchg_forget before freeing it.
+ * A launch under hipGraph capture, or one that needs more than half the buffer, ends the management of that buffer (the library
+ * falls back to the poison fill per launch from then on): always correct. */
+int aas_rnn_xchg_prepare(aasStream_t stream, void* xchg, size_t bytes);
+int aas_rnn_xchg_forget(void* xchg);
+int aas_rnn_xchg_is_managed(void* xchg);   /* 1 while the buffer is managed (a fallen-back buffer may be prepared again) */
 /* > 0 when the LAST aas_lstm_fwd / aas_gru_fwd call left h_t of every time step but each direction's last one in its
  * exchange buffer as operand planes (rows [2][T][N], this many bytes per row, interleaved hi | lo per 32 units, pad units
  * zero; the unpublished rows stay poisoned = NaN): the B operand of that layer's recurrent weight-gradient product
