@@ -62,6 +62,7 @@ _TABLE = {
     "TN_WGRAD": (True, _b),
     "MANAGED_XCHG": (True, _b),       # managed exchange buffers: no poison memset launch in front of a persistent launch
     "FUSED_GLUE": (True, _b),         # step prologue / epilogue launches instead of torch eager glue
+    "WGRAD_MAXSTEPS": (None, _opt_i),  # lifetime cap of the weight-gradient products alone (None: GEMM32_MAXSTEPS)
     "GEMM32_MAXSTEPS": (48, _i),      # lifetime cap (k-steps) of a GEMM workgroup inside the training step
 }
 

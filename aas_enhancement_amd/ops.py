@@ -376,6 +376,27 @@ def sync_wgrad():
         torch.cuda.current_stream().wait_stream(s)
 
 
+class _wgrad_gemm_cap(object):
+    """The weight-gradient products (side stream) under their own workgroup-lifetime cap (knobs.WGRAD_MAXSTEPS; None = the same cap as
+    every other GEMM): they run beside persistent launches that wait for whole CUs, the chain's own GEMMs run between them."""
+
+    def __enter__(self):
+        cap = knobs.get("WGRAD_MAXSTEPS")
+        self.prev = None
+        if cap is not None:
+            self.prev = int(lib().aas_get_gemm_max_steps())
+            if self.prev != int(cap):
+                lib().aas_set_gemm_max_steps(int(cap))
+            else:
+                self.prev = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            lib().aas_set_gemm_max_steps(self.prev)
+        return False
+
+
 class Profiler:
     """Optional HIP-event timing of individual launches on the launching stream (bench.py roofline).
     `classes` selects which launch classes are bracketed with events: "rnn" and/or "gemm"."""
@@ -1368,7 +1389,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         hook = WGRAD_HOOK[0]
 
         def run():
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), _wgrad_gemm_cap():
                 side.wait_event(ev)
                 wgrads(direct, True)
                 if hook is not None:
