@@ -398,3 +398,59 @@ def test_22bit_bptt_exchange_is_below_the_references_own_thread_count_spread(gpu
     # no parameter's samples move more than the reference's own worst thread-count movement, and the typical movement is smaller too
     assert w22 <= wsp, (w22, wsp, max(dev22, key=dev22.get))
     assert m22 <= msp, (m22, msp)
+
+
+# ---- managed exchange buffers (no poison memset launch in front of a persistent launch) ----------------------------------------------
+def _layer_run(ops, kind, T, N, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    G = 4 if kind == "lstm" else 3
+    b = 1.0 / np.sqrt(H)
+    # (one flat buffer, as the trainers' FlatBuffers lay the weights out: whether the two directions' products run as one launch
+    #  depends on the distance between the weight tensors, which separate allocations would leave to the allocator)
+    flat = ((torch.rand(4, G * H, H, generator=g) * 2 - 1) * b).cuda()
+    w = [flat[i].detach().requires_grad_(True) for i in range(4)]
+    x = (torch.randn(T, N, H, generator=g) * 0.5).cuda().requires_grad_(True)
+    gy = torch.randn(T, N, H, generator=g).cuda()
+    y = ops.birnn_layer(x, *w, kind=kind, residual=True)
+    y.backward(gy)
+    return [y.detach()] + [x.grad] + [wi.grad for wi in w]
+
+
+def test_managed_exchange_buffers_equal_the_poison_fill_path_bit_for_bit(gpu):
+    """A chain of persistent launches of changing kind / T / N / H queued back to back on one stream - the exchange buffer alternates
+    between its halves, every kernel re-poisons what its predecessor dirtied, the fp32 forward kernels exchange h_t through the
+    self-cleaning ring of four time slots - gives, bit for bit, what the same chain gives with a poison memset in front of every
+    launch (knobs.MANAGED_XCHG off).  Includes T < 4 (no ring: falls back and is prepared again), T = 4 / 5 (the ring's wrap),
+    ragged row groups (N = 7, 33), the 1000-unit GRU, and a kernel-selection bit that takes the whole buffer in between."""
+    from aas_enhancement_amd import knobs, ops
+    from aas_enhancement_amd._lib import lib
+    shapes = [("lstm", 200, 30, 500), ("gru", 85, 30, 1000), ("lstm", 200, 60, 500), ("lstm", 5, 7, 500), ("gru", 4, 33, 512),
+              ("lstm", 3, 30, 500), ("lstm", 64, 30, 500), ("gru", 85, 30, 1000), ("lstm", 9, 3, 16), ("lstm", 200, 30, 500)]
+    res = {}
+    for managed in (True, False):
+        with knobs.override(MANAGED_XCHG=managed):
+            out = []
+            for rep in range(2):                      # twice: the second pass starts on buffers the first one left behind
+                for i, (kind, T, N, H) in enumerate(shapes):
+                    if managed and rep == 1 and i == 4:
+                        lib().aas_set_debug_flags(256)        # all-gather / counter-based BPTT: takes the whole buffer (legacy fill)
+                    out.append(_layer_run(ops, kind, T, N, H, 100 + i))
+                    lib().aas_set_debug_flags(0)
+            torch.cuda.synchronize()
+            assert not ops.rnn_timeout_flag()
+            res[managed] = out
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        if i == len(shapes) + 4:      # (the launch under the kernel-selection bit ran another BPTT kernel: same values to rounding)
+            for ta, tb in zip(a, b):
+                assert rel_err(ta, tb) < 1e-5
+            continue
+        kind, T, N, H = shapes[i % len(shapes)]
+        for j, (ta, tb) in enumerate(zip(a, b)):
+            if j == 1 and T * N < 64:    # dx of a tiny batch: the general GEMM's split-K epilogue adds with fp32 atomics (order varies run to run)
+                assert rel_err(ta, tb) < 1e-5
+                continue
+            assert torch.equal(ta, tb), (i, j, shapes[i % len(shapes)])
+    # the buffers of this stream are managed again after the fall-backs
+    st = torch.cuda.current_stream().cuda_stream
+    keys = [k for k in ops._scratch if k[0] in ("xchg_fwd", "xchg_bwd") and k[2] == st]
+    assert len(keys) == 2 and all(lib().aas_rnn_xchg_is_managed(ops._scratch[k].data_ptr()) for k in keys)
