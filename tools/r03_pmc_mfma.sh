@@ -3,7 +3,7 @@
 set -u
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r03h}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="bench.py --precision 0 --steps 8 --warmup 3 --no-cpu-baseline --no-extras --profile-steps 0"
+CMD="bench.py --precision 0 --steps 8 --warmup 3 --no-cpu-baseline --no-extras --profile-steps 0 --no-traffic"
 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d /tmp/p_m -o run -- python3 $R/$CMD > /dev/null 2>&1
 python3 - <<PY > $O/f32_pmc_mfmautil.md
 import csv, glob, re
