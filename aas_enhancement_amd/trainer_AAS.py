@@ -504,9 +504,11 @@ class Trainer(ops.TrainerContext):
         # otherwise wait for each fully-resident 512-thread launch to retire
         ops.set_rnn_cu_limit(knobs.get("EBWD_CUS"))
         leaf_a.grad.record_stream(torch.cuda.current_stream())
-        gsum = ops.add3(leaf.grad, leaf_a.grad)
+        # the gradients arriving at `enhanced`: through D's input, as the L1 target (:146-147: `enhanced` is both), through A
+        tg = (self._fused or {}).get("tgrad") or [None]
+        gsum = ops.add3(leaf.grad, leaf_a.grad, tg[0])
         if getattr(self, "keep_enh_grads", False):   # parity gates / tests: the two gradients arriving at `enhanced` (:148, :170)
-            self._enh_grads = (leaf.grad, leaf_a.grad)
+            self._enh_grads = (ops.add3(leaf.grad, tg[0]) if tg[0] is not None else leaf.grad, leaf_a.grad)
         ops.flush_deferred_wgrad()
         if dp.active:   # D's (and a trainable A's) small parameters; their layer buckets are in flight: overlaps E's backward
             self._reducer.flush(self._flat["D"])
@@ -832,7 +834,8 @@ class Trainer(ops.TrainerContext):
         if fused:
             # raw roots: the L1 sums [2] and the CTC costs [N]; their weights ride in the backward launches (ops.l1_pair / ctc_scaled)
             with torch.cuda.stream(main):
-                l_pair = ops.l1_pair(ae, leaf, cl_inputs, scales[0], scales[1], self._l1_acc.detach())
+                self._fused["tgrad"] = []
+                l_pair = ops.l1_pair(ae, leaf, cl_inputs, scales[0], scales[1], self._l1_acc.detach(), self._fused["tgrad"])
             with torch.cuda.stream(side):
                 prob = out_a.transpose(0, 1)
                 l_CTC = ops.ctc_scaled(prob, self.CTCLoss.blank, ctc_meta, scales[2])

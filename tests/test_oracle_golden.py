@@ -54,6 +54,43 @@ def test_aas_step_tiny_three_iterations():
             assert rel_err(v, z["final.%s.%s" % (nm, k)]) < 1e-5, (nm, k)
 
 
+def test_aas_config2_gradients_with_live_D_step():
+    """F3b at size on the CPU oracle: iteration 0 of config 2 with kt0 = 0.3 - the scalars and every parameter gradient (norm + 64
+    samples) of E, D and A against the reference's (one oracle step: ~25 s on 4 threads).  Tolerance: the reference itself moves by
+    up to 1.1e-4 of a tensor's largest sample between thread counts (F3c)."""
+    from aas_enhancement_amd import prng
+    z, zc = load("f3b_aas_config2_kt.npz"), load("f3c_thread_spread.npz")
+    N, F, T, H, HA, M, L = [int(z[k]) for k in ("N", "F", "T", "H", "HA", "M", "L")]
+    G, D = RM.RefStackedBRNN(F, F, H, 4), RM.RefStackedBRNN(F, F, H, 4)
+    A = RM.RefDeepSpeech(nn.GRU, LABELS, HA, 5, 11, 2, M, 2, nFreq=F)
+    for m, seed, cs in ((G, 9001, None), (D, 9002, None), (A, 9003, 0.1)):
+        sd = m.state_dict()
+        for k, v in prng.fill_state_dict(sd, seed, conv_std=cs).items():
+            sd[k].copy_(torch.from_numpy(v))
+    cfg = RS.StepConfig(lr=float(z["lr"]))
+    og, od, oa = RS.make_optim(G, cfg), RS.make_optim(D, cfg), RS.make_optim(A, cfg)
+    ny = (torch.from_numpy(prng.uniform(123, (N, F, T), 0.0, 6.0)), torch.from_numpy(prng.randint(125, (N * L,), 1, 28).astype(np.int32)),
+          torch.ones(N), torch.full((N,), L, dtype=torch.int32), torch.zeros(N, 1, T, dtype=torch.uint8))
+    cl = (torch.from_numpy(prng.uniform(124, (N, F, T), 0.0, 6.0)), None, None, None, torch.zeros(N, 1, T, dtype=torch.uint8))
+    kt, sc = RS.aas_step(G, D, A, og, od, oa, ny, cl, cfg, float(z["kt0"]), 0)
+    for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "g_adv", "g_ctc_adv", "kt", "conv_measure"):
+        assert sc[k] == pytest.approx(float(z["it0." + k]), rel=1e-5), k
+    worst = 0.0
+    for nm, m in (("G", G), ("D", D), ("A", A)):
+        for k, p in m.named_parameters():
+            key = "%s.%s" % (nm, k)
+            if k in NOISE_PARAMS:
+                continue
+            ref = z["it0.gradsample." + key]
+            got = p.grad.reshape(-1)[torch.from_numpy(z["it0.gradsample_idx." + key].astype(np.int64))].numpy()
+            scale = float(np.abs(ref).max()) + 1e-30
+            e = float(np.abs(got - ref).max()) / scale
+            worst = max(worst, e)
+            assert e < 3e-4, (key, e)          # (F3c: the reference's own spread across thread counts reaches 1.1e-4)
+            assert float(p.grad.double().pow(2).sum().sqrt()) == pytest.approx(float(z["it0.gradnorm." + key]), rel=1e-4), key
+    assert len(zc.files) > 100 and worst < 3e-4
+
+
 def test_dce_config1_five_steps():
     from aas_enhancement_amd import prng
     z = load("f2_dce_config1.npz")
