@@ -6,16 +6,17 @@ import os, sys
 import numpy as np, torch, torch.nn as nn
 sys.path.insert(0, ".")
 from tests.test_gpu_step import cfg, LABELS, load_sd
-from aas_enhancement_amd import prng, ops, _lib
+from aas_enhancement_amd import knobs, prng, ops, _lib
 from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
 from aas_enhancement_amd.trainer_AAS import Trainer
 _lib.lib().aas_set_debug_flags(int(os.environ.get("SCHED_FLAGS", "0")))
 N, F, T, H, HA, M, L = 30, 80, 200, 500, 1000, 128, 20
 reps = int(os.environ.get("SCHED_REPS", "6"))
-modes = [("serial", {"AAS_OVERLAP_ASR": "0"})] + [("alt%d" % i, {"AAS_OVERLAP_ASR": "1", "AAS_INTERLEAVE": os.environ.get("SCHED_INTERLEAVE", "1")}) for i in range(reps)]
+modes = [("serial", dict(OVERLAP_ASR=False))] + [("alt%d" % i, dict(OVERLAP_ASR=True, INTERLEAVE=os.environ.get("SCHED_INTERLEAVE", "1") == "1")) for i in range(reps)]
 res = {}
 for mode, env in modes:
-    os.environ.update(env)
+    for k_, v_ in env.items():
+        knobs.set(k_, v_)
     G, D = stackedBRNN(I=F, H=H, L=4), stackedBRNN(I=F, H=H, L=4)
     A = DeepSpeech(nn.GRU, LABELS, HA, 5, True, 11, 2, M, 2, nFreq=F)
     for m, s, cs in ((G, 9001, None), (D, 9002, None), (A, 9003, 0.1)):
@@ -38,4 +39,4 @@ for k, v in res.items():
     if d.max() > 2e-5:
         bad += 1
         print("%-8s MISMATCH max %.1e  %s" % (k, d.max(), np.array2string(d, precision=0)))
-print("flags", os.environ.get("SCHED_FLAGS", "0"), "interleave", os.environ.get("SCHED_INTERLEAVE", "1"), "planes", os.environ.get("AAS_PLANES_PRE", "1"), ": %d of %d runs mismatch; timeout flag %s" % (bad, reps, ops.rnn_timeout_flag()))
+print("flags", os.environ.get("SCHED_FLAGS", "0"), "interleave", os.environ.get("SCHED_INTERLEAVE", "1"), "planes", knobs.get("PLANES_PRE"), ": %d of %d runs mismatch; timeout flag %s" % (bad, reps, ops.rnn_timeout_flag()))
