@@ -62,6 +62,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A hung rendezvous of a multi-process CPU test must fail, not stall the suite (pytest-timeout, when it is installed)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for it in items:
+        if it.get_closest_marker("gpu") is None and it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(600))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
