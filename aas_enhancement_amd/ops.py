@@ -5,11 +5,10 @@ modules (model.py) participate in autograd.  All tensors are fp32 CUDA (HIP) ten
 Layouts used internally:  sequences [T,N,H] row-major ("TNH"); conv front-end
 channels-last [N,T,C]; the module boundary keeps the reference's [N,C,T].
 """
-import os
 
 import torch
 
-from . import _lib, knobs
+from . import knobs
 from ._lib import check, lib, ptr, require_cuda, stream
 
 NT, NN, TN = 0, 1, 2

@@ -8,7 +8,6 @@ The step is one serial chain - E forward, A forward, CTC, A backward, E backward
 takes the whole chip; the weight-gradient products run on the side stream as in the AAS trainer.  `train_step_async` keeps
 the loss and the running CTC average of the log line on the device (no host synchronisation per step).
 """
-import os
 
 import torch
 
