@@ -364,7 +364,14 @@ class Trainer(ops.TrainerContext):
                 self._rs_pair = torch.empty(2 * N, device=dev, dtype=torch.float32)
             ops.step_prologue([f.flat_g for f in self._flat.values()] + [self._l1_acc], self._rs_pair, N, N, self._kt_dev)
             self._fused = {}
+        elif knobs.get("FUSED_GLUE") and not dp.active and not capturing:
+            # the other single-process device paths (ragged pair on the two-lane schedule, ...): the zero fills and the weights
+            # [-kt] * N of the enhanced pass in one prologue launch; their losses keep the autograd scaling
+            if getattr(self, "_rs_lane", None) is None or self._rs_lane.numel() != N:
+                self._rs_lane = torch.empty(N, device=dev, dtype=torch.float32)
+            ops.step_prologue([f.flat_g for f in self._flat.values()], self._rs_lane, N, 0, self._kt_dev)
         else:
+            self._rs_lane = None
             for f in self._flat.values():
                 f.flat_g.zero_()
         if dp.active:
@@ -562,7 +569,10 @@ class Trainer(ops.TrainerContext):
         if dp.active:
             self._reducer.expect(self._flat["D"], 2)      # every D layer is back-propagated twice: reduce after the second
         self._wait_kt()
-        rs = (-self._kt_dev).to(torch.float32).expand(N).contiguous()
+        if getattr(self, "_rs_lane", None) is not None and self._rs_lane.numel() == N and not dp.active:
+            rs = self._rs_lane.detach()          # written by the step prologue
+        else:
+            rs = (-self._kt_dev).to(torch.float32).expand(N).contiguous()
         rs._aas_classes = [(0, N, rs[0:1])]
 
         def alternate(gen_main, gen_side):
