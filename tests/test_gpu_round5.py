@@ -454,3 +454,76 @@ def test_managed_exchange_buffers_equal_the_poison_fill_path_bit_for_bit(gpu):
     st = torch.cuda.current_stream().cuda_stream
     keys = [k for k in ops._scratch if k[0] in ("xchg_fwd", "xchg_bwd") and k[2] == st]
     assert len(keys) == 2 and all(lib().aas_rnn_xchg_is_managed(ops._scratch[k].data_ptr()) for k in keys)
+
+
+# ---- the fused step-glue launches, op by op ------------------------------------------------------------------------------------------
+def test_step_prologue_zeroes_exactly_its_buffers_and_writes_the_weights(gpu):
+    from aas_enhancement_amd import ops
+    big = torch.full((3 * 1024 * 1024 + 256,), 7.0, device="cuda")
+    a = big[64:64 + 1000003]                      # 16-byte aligned start (64 floats in), odd length: bytewise tail
+    b = big[2 * 1024 * 1024:2 * 1024 * 1024 + 4096]
+    acc = torch.full((2,), 3.0, device="cuda", dtype=torch.float64)
+    rs = torch.full((70,), 9.0, device="cuda")
+    kt = torch.tensor([0.37], device="cuda", dtype=torch.float64)
+    ops.step_prologue([a, b, acc], rs[:60], 30, 30, kt)
+    torch.cuda.synchronize()
+    assert float(a.abs().sum()) == 0.0 and float(b.abs().sum()) == 0.0 and float(acc.abs().sum()) == 0.0
+    assert float(big[:64].min()) == 7.0 and float(big[64 + 1000003:2 * 1024 * 1024].min()) == 7.0     # neighbours untouched
+    assert float(big[2 * 1024 * 1024 + 4096:].min()) == 7.0
+    assert torch.equal(rs[:30], torch.full((30,), -float(np.float32(0.37)), device="cuda")) and torch.equal(rs[30:60], torch.ones(30, device="cuda"))
+    assert float(rs[60:].min()) == 9.0
+    ops.step_prologue([], rs[:8], 8, 0, kt)       # weights only
+    ops.step_prologue([b])                        # buffers only
+    torch.cuda.synchronize()
+    assert torch.equal(rs[:8], torch.full((8,), -float(np.float32(0.37)), device="cuda"))
+
+
+def test_fused_loss_roots_equal_the_autograd_composition(gpu):
+    """ops.layout_cat_nct_tnc + ops.l1_pair + ops.ctc_scaled + ops.began_step_raw against what they replace (torch.cat + ops.layout,
+    ops.l1_sum * scale on slices, ops.ctc_sum * scale, ops.began_step): same values and gradients."""
+    from aas_enhancement_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, F, T = 5, 12, 23
+    leaf0 = (torch.rand(N, F, T, generator=g) * 6).cuda()
+    clean = (torch.rand(N, F, T, generator=g) * 6).cuda()
+    W = (torch.randn(F, F, generator=g) * 0.3).cuda()
+    s_ny, s_cl, s_ctc = 1.0 / 97.0, 1.0 / 89.0, 1.0 / N
+
+    def net(x_tnc):                               # a stand-in for D: [T, 2N, F] -> [2N, F, T]
+        return ops.layout(torch.tanh(x_tnc @ W), "tnc_nct")
+    # fused
+    leaf = leaf0.clone().requires_grad_(True)
+    ae = net(ops.layout_cat_nct_tnc(leaf, clean))
+    acc = torch.zeros(2, device="cuda", dtype=torch.float64)
+    tg = []
+    root = ops.l1_pair(ae, leaf, clean, s_ny, s_cl, acc, tg)
+    torch.autograd.backward([root], [ops.unit_root(root)])
+    g_fused = leaf.grad + tg[0]
+    # unfused
+    leaf2 = leaf0.clone().requires_grad_(True)
+    ae2 = net(ops.layout(torch.cat([leaf2, clean], 0), "nct_tnc"))
+    l_ny = ops.l1_sum(ae2[:N], leaf2) * s_ny
+    l_cl = ops.l1_sum(ae2[N:], clean) * s_cl
+    (l_ny + l_cl).backward()
+    assert rel_err(ae, ae2) < 1e-6
+    assert float(acc[0]) * s_ny == pytest.approx(float(l_ny), rel=1e-6) and float(acc[1]) * s_cl == pytest.approx(float(l_cl), rel=1e-6)
+    assert rel_err(g_fused, leaf2.grad) < 1e-5
+    # CTC
+    Tp, C, L = 19, 29, 4
+    acts0 = torch.randn(Tp, N, C, generator=g).cuda()
+    labels = torch.randint(1, C, (N * L,), generator=g).int()
+    meta = ops.ctc_prepare(labels, torch.full((N,), Tp, dtype=torch.int32), torch.full((N,), L, dtype=torch.int32), torch.device("cuda"))
+    a1 = acts0.clone().requires_grad_(True)
+    costs = ops.ctc_scaled(a1, 0, meta, s_ctc)
+    torch.autograd.backward([costs], [ops.unit_root(costs)])
+    a2 = acts0.clone().requires_grad_(True)
+    l_ctc = ops.ctc_sum(a2, None, None, None, 0, meta) * s_ctc
+    l_ctc.backward()
+    assert float(costs.sum()) * s_ctc == pytest.approx(float(l_ctc), rel=1e-6)
+    assert rel_err(a1.grad, a2.grad) < 1e-6
+    # controller
+    kt1, kt2 = torch.tensor([0.3], device="cuda", dtype=torch.float64), torch.tensor([0.3], device="cuda", dtype=torch.float64)
+    o1, o2 = torch.zeros(6, device="cuda", dtype=torch.float64), torch.zeros(6, device="cuda", dtype=torch.float64)
+    ops.began_step_raw(acc, s_ny, s_cl, costs.detach(), s_ctc, kt1, o1, 0.5, 0.001, float(N))
+    ops.began_step(l_ny, l_cl, l_ctc, kt2, o2, 0.5, 0.001, float(N))
+    assert torch.allclose(o1, o2, rtol=1e-6) and float(kt1) == pytest.approx(float(kt2), rel=1e-9)
