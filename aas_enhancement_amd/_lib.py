@@ -31,6 +31,7 @@ SIGNATURES = {
     "aas_release_retired_workspaces": [],
     "aas_set_precision": [c_int],
     "aas_set_rnn_launch_tag": [c_int],
+    "aas_set_rnn_row_classes": [c_int, c_int, c_int],
     "aas_set_rnn_cu_limit": [c_int],
     "aas_gemm_f32": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int,
                      c_int, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_i64],

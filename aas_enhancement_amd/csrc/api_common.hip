@@ -201,6 +201,29 @@ extern "C" int aas_set_wgrad_wg_cap(int workgroups) { g_wgrad_cap = workgroups <
 static int g_fwd_h_pitch = 0;
 void aas_note_fwd_h_planes(int pitch_bytes) { g_fwd_h_pitch = pitch_bytes; }
 extern "C" int aas_rnn_last_fwd_h_pitch(void) { return g_fwd_h_pitch; }
+// Row classes of the NEXT forward recurrent launch (aas_lstm_fwd / aas_gru_fwd), consumed by it: batch rows [0, n_first) carry
+// sequences of T_first frames, rows [n_first, N) of T_rest frames, inside a launch of T = max of the two.  What the batched
+// discriminator pass over a noisy / clean pair of different padded lengths needs: the shorter class behaves exactly as in a launch
+// of its own (zero state before its first frame in either direction, zero output and no gradient beyond its last).
+static int g_cls_set = 0, g_cls_n = 0, g_cls_t0 = 0, g_cls_t1 = 0;
+extern "C" int aas_set_rnn_row_classes(int n_first, int T_first, int T_rest) {
+    if (n_first < 0 || T_first < 1 || T_rest < 1) {
+        aas_set_error("aas_set_rnn_row_classes: n_first=%d T_first=%d T_rest=%d", n_first, T_first, T_rest);
+        return 1;
+    }
+    g_cls_set = 1; g_cls_n = n_first; g_cls_t0 = T_first; g_cls_t1 = T_rest;
+    return 0;
+}
+int aas_rnn_row_classes_take(const char* who, int T, int N, int* n, int* t0, int* t1) {
+    if (!g_cls_set) { *n = N; *t0 = T; *t1 = T; return 0; }
+    g_cls_set = 0;
+    if (g_cls_n > N || g_cls_t0 > T || g_cls_t1 > T || (g_cls_t0 != T && g_cls_t1 != T)) {
+        aas_set_error("%s: row classes (%d rows x %d frames, the rest x %d) do not fit a launch of N=%d T=%d", who, g_cls_n, g_cls_t0, g_cls_t1, N, T);
+        return 1;
+    }
+    *n = g_cls_n; *t0 = g_cls_t0; *t1 = g_cls_t1;
+    return 0;
+}
 extern "C" int aas_set_rnn_launch_tag(int tag) {
     if (tag < 1) {
         aas_set_error("aas_set_rnn_launch_tag: tag must be >= 1");

@@ -290,6 +290,10 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
                 carry = c;
                 hval = og * tanhf_(c);
                 kp[0] = ig; kp[1] = fg; kp[2] = gg; kp[3] = og; kp[4] = c;
+                if (t >= (gr < p.cls_n ? p.cls_t0 : p.cls_t1)) {   // dead (t, row) of a shorter row class (rnn_kernel.h: RnnP)
+                    carry = 0.f; hval = 0.f;
+                    kp[0] = kp[1] = kp[2] = kp[3] = kp[4] = 0.f;
+                }
             } else {
                 const float rg = sigmoidf_(pin[0] + rs[0]);
                 const float zg = sigmoidf_(pin[1] + rs[1]);
@@ -298,6 +302,10 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
                 hval = (1.f - zg) * ng + zg * carry;
                 carry = hval;
                 kp[0] = rg; kp[1] = zg; kp[2] = ng; kp[3] = hn;
+                if (t >= (gr < p.cls_n ? p.cls_t0 : p.cls_t1)) {
+                    carry = 0.f; hval = 0.f;
+                    kp[0] = 0.f; kp[1] = 0.f; kp[2] = 1.f; kp[3] = 0.f;
+                }
             }
         }
         // publish (pad units publish zeros): split - even-unit lanes store {own, partner} packed hi and lo words; exact - every lane

@@ -57,6 +57,10 @@ struct RnnP {
     // managed exchange buffer (aas_rnn_xchg_prepare; common.h: AasXchgPlan): the region of the OTHER half this launch poisons itself
     unsigned* clean_ptr;
     unsigned clean_words;
+    // row classes (aas_set_rnn_row_classes; forward launches): rows < cls_n are live for t < cls_t0, the others for t < cls_t1; a dead
+    // (t, row) gets h = c = 0 and stored gate values under which BPTT forms zero gate gradients and carries nothing on, whatever dh is
+    // (LSTM: all zeros; GRU: z = 0, n = 1)
+    int cls_n, cls_t0, cls_t1;
     int ring;            // exact forward kernels: h_t exchanged through 4 time slots ([2][4][N] rows), producers re-poison behind themselves
 };
 
@@ -318,23 +322,26 @@ __global__ __launch_bounds__(256, 1) void rnn_kernel(RnnP p) {
                 rs[0] = red[0][row][u] + red[1][row][u] + red[2][row][u] + red[3][row][u];
             }
             const int64_t tn = (int64_t)t * N + gr;
+            const bool live = !FWD || t < (gr < p.cls_n ? p.cls_t0 : p.cls_t1);
             if (MODE == LSTM_FWD) {
-                const float ig = sigmoidf_(pin[i][0] + rs[0]);
-                const float fg = sigmoidf_(pin[i][1] + rs[1]);
-                const float gg = tanhf_(pin[i][2] + rs[2]);
-                const float og = sigmoidf_(pin[i][3] + rs[3]);
-                const float c = fg * carry[i] + ig * gg;
+                float ig = sigmoidf_(pin[i][0] + rs[0]);
+                float fg = sigmoidf_(pin[i][1] + rs[1]);
+                float gg = tanhf_(pin[i][2] + rs[2]);
+                float og = sigmoidf_(pin[i][3] + rs[3]);
+                float c = fg * carry[i] + ig * gg;
+                float h = og * tanhf_(c);
+                if (!live) { ig = fg = gg = og = c = h = 0.f; }
                 carry[i] = c;
-                const float h = og * tanhf_(c);
                 st_sc1(p.hout + ((int64_t)d * T * N + tn) * H + unit, h);
                                 *reinterpret_cast<f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4) = (f32x4){ig, fg, gg, og};
                 p.cst[((int64_t)d * T * N + tn) * H + unit] = c;
             } else if (MODE == GRU_FWD) {
-                const float rg = sigmoidf_(pin[i][0] + rs[0]);
-                const float zg = sigmoidf_(pin[i][1] + rs[1]);
-                const float hn = rs[2];
-                const float ng = tanhf_(pin[i][2] + rg * hn);
-                const float h = (1.f - zg) * ng + zg * carry[i];
+                float rg = sigmoidf_(pin[i][0] + rs[0]);
+                float zg = sigmoidf_(pin[i][1] + rs[1]);
+                float hn = rs[2];
+                float ng = tanhf_(pin[i][2] + rg * hn);
+                float h = (1.f - zg) * ng + zg * carry[i];
+                if (!live) { rg = zg = hn = h = 0.f; ng = 1.f; }
                 carry[i] = h;
                 st_sc1(p.hout + ((int64_t)d * T * N + tn) * H + unit, h);
                                 *reinterpret_cast<f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4) = (f32x4){rg, zg, ng, hn};

@@ -552,6 +552,10 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     const float h = og * tanhf_(c);
                     xv[0] = h;
                     kp[0] = ig; kp[1] = fg; kp[2] = gg; kp[3] = og; kp[4] = c;
+                    if (t >= (gr < p.cls_n ? p.cls_t0 : p.cls_t1)) {   // dead (t, row) of a shorter row class
+                        carry[i] = 0.f; xv[0] = 0.f;
+                        kp[0] = kp[1] = kp[2] = kp[3] = kp[4] = 0.f;
+                    }
                 } else if (MODE == GRU_FWD) {
                     const float rg = sigmoidf_(pin[i][0] + rs[0]);
                     const float zg = sigmoidf_(pin[i][1] + rs[1]);
@@ -561,6 +565,10 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                     carry[i] = h;
                     xv[0] = h;
                     kp[0] = rg; kp[1] = zg; kp[2] = ng; kp[3] = hn;
+                    if (t >= (gr < p.cls_n ? p.cls_t0 : p.cls_t1)) {   // z = 0, n = 1: BPTT forms no gate gradient and carries nothing on
+                        carry[i] = 0.f; xv[0] = 0.f;
+                        kp[0] = 0.f; kp[1] = 0.f; kp[2] = 1.f; kp[3] = 0.f;
+                    }
                 } else if (MODE == LSTM_BWD) {
                     const float dh = pin[i][0] + rs[0];
                     const float ig = sav[i][0], fg = sav[i][1], gg = sav[i][2], og = sav[i][3];

@@ -742,29 +742,31 @@ def layout(x, kind):
 class _LayoutCatNCT(torch.autograd.Function):
     """[a ; b] along the batch axis and [N,C,T] -> [T,N,C] in one step: two transposing launches straight into the halves of the
     time-major tensor instead of a concatenated copy and a transpose of it (the batched [enhanced; clean] discriminator input).
-    Only `a` receives a gradient."""
+    Only `a` receives a gradient.  a and b may differ in T: the result has max(Ta, Tb) frames, zero beyond the shorter one's last
+    (the batched discriminator pass over a ragged pair, trainer_AAS._batched_D_core)."""
 
     @staticmethod
     def forward(ctx, a, b):
         require_cuda(a, b)
         a, b = _c(a), _c(b)
-        Na, C, T = a.shape
-        Nb = b.shape[0]
-        assert tuple(b.shape[1:]) == (C, T)
-        N = Na + Nb
-        out = torch.empty((T, N, C), device=a.device, dtype=torch.float32)
-        check(lib().aas_transpose_f32(stream(), ptr(a), ptr(out), Na, C, T, C * T, T, C, N * C), "aas_transpose_f32")
-        check(lib().aas_transpose_f32(stream(), ptr(b), out.data_ptr() + 4 * Na * C, Nb, C, T, C * T, T, C, N * C), "aas_transpose_f32")
-        ctx.na = Na
+        Na, C, Ta = a.shape
+        Nb, Tb = b.shape[0], b.shape[2]
+        assert b.shape[1] == C
+        N, T = Na + Nb, max(Ta, Tb)
+        out = (torch.empty if Ta == Tb else torch.zeros)((T, N, C), device=a.device, dtype=torch.float32)
+        check(lib().aas_transpose_f32(stream(), ptr(a), ptr(out), Na, C, Ta, C * Ta, Ta, C, N * C), "aas_transpose_f32")
+        check(lib().aas_transpose_f32(stream(), ptr(b), out.data_ptr() + 4 * Na * C, Nb, C, Tb, C * Tb, Tb, C, N * C), "aas_transpose_f32")
+        ctx.na, ctx.ta = Na, Ta
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = _c(g)
         T, N, C = g.shape
-        ga = torch.empty((ctx.na, C, T), device=g.device, dtype=torch.float32)
-        # rows (t, n < Na) of g back to [Na, C, T]: in[b = n][r = t][c] with strides (C, N*C), out[b][c][t]
-        check(lib().aas_transpose_f32(stream(), ptr(g), ptr(ga), ctx.na, T, C, C, N * C, C * T, T), "aas_transpose_f32")
+        Ta = ctx.ta
+        ga = torch.empty((ctx.na, C, Ta), device=g.device, dtype=torch.float32)
+        # rows (t < Ta, n < Na) of g back to [Na, C, Ta]: in[b = n][r = t][c] with strides (C, N*C), out[b][c][t]
+        check(lib().aas_transpose_f32(stream(), ptr(g), ptr(ga), ctx.na, Ta, C, C, N * C, C * Ta, Ta), "aas_transpose_f32")
         return ga, None
 
 
@@ -1022,8 +1024,9 @@ MULTI_WGRAD = [knobs.get("MULTI_WGRAD")]   # fp32 arithmetic: a layer's four wei
 TN_WGRAD = [knobs.get("TN_WGRAD")]   # weight-gradient products from row-major planes (aas_gemm_planes_tn)
 
 
-def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None):
-    """x [T,N,I] -> (hout[2,T,N,H], gact, cst).  keep: a dict that receives what the layer's weight-gradient products can
+def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None, row_len=None):
+    """x [T,N,I] -> (hout[2,T,N,H], gact, cst).  row_len = (n_first, T_first, T_rest): two row classes of different sequence length
+    in one launch (aas_set_rnn_row_classes; lstm / gru).  keep: a dict that receives what the layer's weight-gradient products can
     reuse: 'xp' = the input's operand planes, 'hx' / 'hpitch' = the forward launch's exchange buffer (h_t as planes)."""
     T, N, I = x.shape
     G = _GATES[kind]
@@ -1070,6 +1073,10 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None):
         xchg = _xchg_buf(dev, T, N, H, G, "fwd" if (_precision[0] != 1 and knobs.get("MANAGED_XCHG")) else "any")
     rflops = 2.0 * 2 * T * N * H * G * H  # both directions, T steps of [N,H]x[H,G*H]
     lib().aas_set_rnn_launch_tag(2 * lid if lid else 1)
+    if row_len is not None:
+        if kind == "rnn":
+            raise NotImplementedError("row classes of different length: lstm / gru layers only")
+        check(lib().aas_set_rnn_row_classes(int(row_len[0]), int(row_len[1]), int(row_len[2])), "aas_set_rnn_row_classes")
     if kind == "rnn":
         with _timed("rnn", "rnn_fwd[N=%d,H=%d]" % (N, H), rflops, T):
             check(lib().aas_rnn_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync)), "aas_rnn_fwd")
@@ -1422,7 +1429,7 @@ class _BiRNNLayer(torch.autograd.Function):
         trainable = any(ctx.needs_input_grad[1:5])    # (grad mode is off inside forward(): ask the context)
         ctx.keep = {} if (TN_WGRAD[0] and trainable and PLANES_BWD[0] and PLANES_EMIT[0]
                           and not torch.cuda.is_current_stream_capturing()) else None
-        hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid, keep=ctx.keep)
+        hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid, keep=ctx.keep, row_len=getattr(rs, "_aas_row_len", None))
         T_, N_, H_ = hout.shape[1], hout.shape[2], hout.shape[3]
         if _precision[0] == 2 and kind != "rnn" and PLANES_PRE[0] and T_ * N_ >= 1024 and H_ >= 64 and H_ % 4 == 0:
             y, yp = add3_planes3(hout[0], hout[1], x if residual else None, H_)

@@ -395,10 +395,11 @@ class Trainer(ops.TrainerContext):
         try:
             # two chains of half-chip persistent launches run side by side: the weight-gradient GEMMs never take more than the
             # other half of the CUs, so a recurrent launch always finds its CUs (AAS_WGRAD_WGS overrides)
-            lanes = self._lanes_ok(tuple(cl_inputs.shape) == tuple(inputs.shape))
+            lanes = self._lanes_ok(tuple(cl_inputs.shape) == tuple(inputs.shape) or self._ragged_batched_ok(inputs, cl_inputs))
             # (ops.set_wgrad_cap / AAS_WGRAD_WGS: a grid cap on the weight-gradient GEMMs, so that they never hold more than half
             #  of the CUs while a recurrent launch waits to become resident, bought 0.4 ms before the XCD-aware recurrent launches;
             #  since then it is worth +-0.05 ms with a frozen A and costs 1.5 ms with a trainable one: off by default)
+            self._last_schedule = "lanes" if lanes else ("batched" if cl_inputs.size(2) == inputs.size(2) else "batched-ragged")
             if lanes:
                 enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC = self._two_lane_core(inputs, cl_inputs, scales, ctc_meta, asr_steps)
             else:
@@ -469,6 +470,12 @@ class Trainer(ops.TrainerContext):
             rs[N:] = 1.0
         # the two utterance classes of the batched pass and their weights (device scalars), for the row-major weight-gradient GEMM
         rs._aas_classes = [(0, N, rs[0:1]), (N, cl_inputs.size(0), None)]
+        ragged = cl_inputs.size(2) != inputs.size(2)
+        if ragged:
+            # noisy / clean batches of different padded length in ONE pass of max(T) frames: the recurrent launches treat the two
+            # row classes as sequences of their own length (aas_set_rnn_row_classes), the losses read each class's own frames
+            assert self._ragged_batched_ok(inputs, cl_inputs)
+            rs._aas_row_len = (N, inputs.size(2), cl_inputs.size(2))
         if overlap:  # two chains of persistent launches side by side, half the chip each
             ops.set_rnn_cu_limit(ops.device_cus() // 2)
         if self._interleave_ok():
@@ -537,6 +544,20 @@ class Trainer(ops.TrainerContext):
             self._early_adam = True
         enhanced.backward(gsum)
         return enhanced, prob, l_adv_ny_G, l_adv_cl, l_CTC
+
+    def _ragged_batched_ok(self, inputs, cl_inputs):
+        """A noisy / clean pair that differs only in its padded length T can take the batched-D schedule (knobs.RAGGED_BATCHED): D's
+        recurrent launches carry two row classes.  Needs the interleaved device path and lstm / gru layers in D.  The batched pass
+        runs max(T) steps for every row, the two-lane schedule each batch's own: config 2 with noisy T = 200 measured 27.0 vs 28.8 ms
+        at clean T = 184 and 27.9 vs 26.8 at clean T = 120 (tools/ragged_bench.py), hence the length-ratio threshold."""
+        if not knobs.get("RAGGED_BATCHED") or str(knobs.get("TWO_LANES")) != "auto" or not self._interleave_ok():
+            return False
+        a, b = tuple(inputs.shape), tuple(cl_inputs.shape)
+        if len(a) != 3 or len(b) != 3 or a[1] != b[1] or a[2] == b[2]:
+            return False
+        if min(a[2], b[2]) < float(knobs.get("RAGGED_MIN_RATIO")) * max(a[2], b[2]):
+            return False
+        return all(m.kind in ("lstm", "gru") for m in self.D.modules() if getattr(m, "_aas_layer_id", None) is not None)
 
     def _lanes_ok(self, same_shape=True):
         """AAS_TWO_LANES = auto (default): the two-lane schedule when the noisy and clean batches have different padded
@@ -649,7 +670,8 @@ class Trainer(ops.TrainerContext):
             attach_n_valid(cl_mask)
         nv = lambda m: getattr(m, "n_valid", None)
         nv_ny, nv_cl = nv(mask), nv(cl_mask)
-        if nv_ny is None or nv_cl is None or (tuple(cl_inputs.shape) != tuple(inputs.shape) and not self._lanes_ok(False)):
+        if nv_ny is None or nv_cl is None or (tuple(cl_inputs.shape) != tuple(inputs.shape) and not self._lanes_ok(False)
+                                              and not self._ragged_batched_ok(inputs, cl_inputs)):
             return self.train_step(data_list, data_list_cl, iter, log_norms=False)
         dev = next(self.G.parameters()).device
         cl_inputs = _get_variable_nograd(cl_inputs)
@@ -828,7 +850,8 @@ class Trainer(ops.TrainerContext):
                 for t_ in (enhanced, leaf, cl_inputs, rs):
                     t_.record_stream(main)
             fused = getattr(self, "_fused", None) is not None and scales is not None and mask is None
-            if fused:
+            Tn, Tc = leaf.size(2), cl_inputs.size(2)
+            if fused or Tn != Tc:
                 gD = self.D.forward_stages(None, wgrad_row_scale=rs, pair=(leaf, cl_inputs))
             else:
                 gD = self.D.forward_stages(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
@@ -865,8 +888,8 @@ class Trainer(ops.TrainerContext):
                 l_adv_ny_G = l_adv_ny_G * c.w_adversarial
                 l_adv_cl = c.w_adversarial * l_adv_cl
             else:   # device path: (weight / normaliser) per loss as python floats or device scalars (data parallel)
-                l_adv_ny_G = ops.l1_sum(ae[:Nn], leaf) * scales[0]
-                l_adv_cl = ops.l1_sum(ae[Nn:], cl_inputs) * scales[1]
+                l_adv_ny_G = ops.l1_sum(ae[:Nn] if Tn >= Tc else ae[:Nn, :, :Tn], leaf) * scales[0]
+                l_adv_cl = ops.l1_sum(ae[Nn:] if Tc >= Tn else ae[Nn:, :, :Tc], cl_inputs) * scales[1]
             l_pair = l_adv_ny_G + l_adv_cl
         with torch.cuda.stream(side):
             prob = out_a.transpose(0, 1)

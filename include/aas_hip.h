@@ -56,6 +56,13 @@ int aas_get_debug_flags(void);
  * up after ~0.5 s and stores the tag of its launch in a sticky error word at byte 4096 of the launch's `sync` buffer
  * (never cleared by the library): the host reads it at its next synchronisation point and names the layer. */
 int aas_set_rnn_launch_tag(int tag);
+/* Row classes of the NEXT aas_lstm_fwd / aas_gru_fwd launch (consumed by it; not by aas_rnn_fwd): batch rows [0, n_first) hold
+ * sequences of T_first frames, rows [n_first, N) of T_rest frames, in a launch of T = max(T_first, T_rest) whose input is anything
+ * (e.g. zero padding) beyond a row's length.  The shorter class gets exactly what a launch of its own would give it: zero state
+ * in front of its first frame in either direction, h = 0 beyond its last, and - through the stored gate values - zero gate
+ * gradients there in the matching BPTT launch, whatever dy holds.  The reference's discriminator pass over an enhanced batch and
+ * a clean batch of different padded lengths (trainer_AAS.py:94-107 runs D twice) becomes one batched pass this way. */
+int aas_set_rnn_row_classes(int n_first, int T_first, int T_rest);
 /* Exchange buffers of the persistent recurrent launches (the `xchg` argument of aas_lstm_fwd / _bwd, aas_gru_fwd / _bwd).  By
  * default every launch poison-fills the part of the buffer it uses first (a memset launch of 8-50 MB per recurrent launch).  A
  * buffer handed to aas_rnn_xchg_prepare ONCE (poison-filled there, `bytes` = at least twice what the largest launch needs:

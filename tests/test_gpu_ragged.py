@@ -1,0 +1,117 @@
+"""Row classes of different sequence length inside one persistent recurrent launch (aas_set_rnn_row_classes) and the batched
+discriminator pass over a ragged noisy / clean pair built on them (trainer_AAS._batched_D_core; the reference runs D twice,
+trainer_AAS.py:94-107).  Checked against what the library itself computes with one launch per class."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _layer(kind, x, w, rs=None, residual=False):
+    from aas_enhancement_amd import ops
+    return ops.birnn_layer(x, w[0], w[1], w[2], w[3], kind=kind, residual=residual, rs=rs, lid=0)
+
+
+@pytest.mark.parametrize("kind,H,I,Na,Nb,Ta,Tb", [
+    ("lstm", 500, 500, 30, 30, 200, 184),     # D's layers at config 2: the 16-unit / 32-unit fp32 forward kernels
+    ("lstm", 500, 500, 30, 30, 150, 200),     # the FIRST class shorter
+    ("gru", 320, 96, 6, 10, 61, 40),          # GRU (z = 0, n = 1 encoding of the dead steps), unequal class sizes
+    ("lstm", 48, 24, 3, 5, 37, 23),           # small hidden size: the split-kernel family
+    ("gru", 40, 40, 4, 4, 19, 33),
+])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_row_classes_match_one_launch_per_class(gpu, kind, H, I, Na, Nb, Ta, Tb, mode):
+    from aas_enhancement_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1234 + H + Ta)
+    G = {"lstm": 4, "gru": 3}[kind]
+    flat = ((torch.rand(2 * G * H * (I + H), generator=g) - 0.5) * (2.0 / H ** 0.5)).to(dev)
+    o, w = 0, []
+    for shape in ((G * H, I), (G * H, H), (G * H, I), (G * H, H)):      # W_ih, W_hh, W_ih_rev, W_hh_rev in one flat buffer
+        n = shape[0] * shape[1]
+        w.append(flat[o:o + n].view(shape))
+        o += n
+    w = [w[0], w[1], w[2], w[3]]
+    xa = torch.randn(Ta, Na, I, generator=g).to(dev)
+    xb = torch.randn(Tb, Nb, I, generator=g).to(dev)
+    ga = torch.randn(Ta, Na, H, generator=g).to(dev)
+    gb = torch.randn(Tb, Nb, H, generator=g).to(dev)
+    T, N = max(Ta, Tb), Na + Nb
+    with ops.precision(mode):
+        # one launch per class
+        ref = {}
+        ws = [t.detach().clone().requires_grad_(True) for t in w]
+        xas, xbs = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+        ya = _layer(kind, xas, ws)
+        yb = _layer(kind, xbs, ws)
+        ((ya * ga).sum() + (yb * gb).sum()).backward()
+        torch.cuda.synchronize()
+        ref = dict(ya=ya.detach(), yb=yb.detach(), dxa=xas.grad, dxb=xbs.grad, dw=[t.grad for t in ws])
+        # one launch, two row classes; junk beyond a class's last frame in x AND in dy
+        ws2 = [t.detach().clone().requires_grad_(True) for t in w]
+        x = torch.randn(T, N, I, generator=g).to(dev)
+        x[:Ta, :Na] = xa
+        x[:Tb, Na:] = xb
+        x = x.requires_grad_(True)
+        rs = torch.ones(N, device=dev)
+        rs._aas_row_len = (Na, Ta, Tb)
+        y = _layer(kind, x, ws2, rs=rs)
+        dy = torch.randn(T, N, H, generator=g).to(dev)
+        dy[:Ta, :Na] = ga
+        dy[:Tb, Na:] = gb
+        y.backward(dy)
+        torch.cuda.synchronize()
+    tol = {0: 2e-5, 1: 2e-3, 2: 2e-5}[mode]
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+    yd = y.detach()
+    assert rel(yd[:Ta, :Na], ref["ya"]) < tol and rel(yd[:Tb, Na:], ref["yb"]) < tol
+    assert float(yd[Ta:, :Na].abs().max()) == 0.0 if Ta < T else True
+    assert float(yd[Tb:, Na:].abs().max()) == 0.0 if Tb < T else True
+    assert rel(x.grad[:Ta, :Na], ref["dxa"]) < tol and rel(x.grad[:Tb, Na:], ref["dxb"]) < tol
+    dead = x.grad[Ta:, :Na] if Ta < T else x.grad[Tb:, Na:]
+    assert float(dead.abs().max()) == 0.0          # no gradient reaches the padding, whatever dy held there
+    for a, b in zip([t.grad for t in ws2], ref["dw"]):
+        assert rel(a, b) < tol
+
+
+def test_row_classes_are_one_shot_and_validated(gpu):
+    from aas_enhancement_amd import _lib, ops
+    lib = _lib.lib()
+    assert lib.aas_set_rnn_row_classes(-1, 4, 4) != 0
+    assert lib.aas_set_rnn_row_classes(2, 0, 4) != 0
+    dev = torch.device("cuda:0")
+    H, I, T, N = 32, 16, 12, 4
+    g = torch.Generator().manual_seed(7)
+    w = [((torch.rand(s, generator=g) - 0.5) * 0.3).to(dev) for s in ((4 * H, I), (4 * H, H), (4 * H, I), (4 * H, H))]
+    x = torch.randn(T, N, I, generator=g).to(dev)
+    rs = torch.ones(N, device=dev)
+    rs._aas_row_len = (2, T, 5)
+    y1 = _layer("lstm", x, w, rs=rs)
+    y2 = _layer("lstm", x, w)              # the setting was consumed by the launch above
+    y3 = _layer("lstm", x, w)
+    torch.cuda.synchronize()
+    assert float(y1[5:, 2:].abs().max()) == 0.0 and float(y2[5:, 2:].abs().max()) > 0.0
+    assert torch.equal(y2, y3)
+    assert torch.equal(y1[:, :2], y2[:, :2])
+    rs._aas_row_len = (2, T + 1, 5)        # longer than the launch
+    with pytest.raises(RuntimeError, match="row classes"):
+        _layer("lstm", x, w, rs=rs)
+    rs._aas_row_len = (2, 5, 6)            # neither class spans the launch
+    with pytest.raises(RuntimeError, match="row classes"):
+        _layer("lstm", x, w, rs=rs)
+    y4 = _layer("lstm", x, w)              # a refused setting does not linger
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y4)
+    with pytest.raises(NotImplementedError):
+        rs._aas_row_len = (2, T, 5)
+        ops.birnn_layer(x, w[0][:H], w[1][:H], w[2][:H], w[3][:H], kind="rnn", rs=rs)

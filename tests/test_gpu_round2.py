@@ -174,15 +174,17 @@ def test_alternating_async_and_sync_steps_match_sync_only(gpu, precision2):
 
 
 def test_two_lane_schedule_on_ragged_pair_matches_synchronous_step(gpu, precision2):
-    """Noisy and clean batches of different padded length (what real loaders deliver): train_step_async takes the two-lane
-    schedule (E fwd || D(clean) fwd, D(enhanced) || A, E bwd || D(clean) bwd); same trajectory as the synchronous step's
-    two-pass branch, which the F1 goldens pin."""
+    """Noisy and clean batches of different padded length (what real loaders deliver): train_step_async takes the batched-D schedule
+    with two row classes in D's recurrent launches (default), or the two-lane schedule (E fwd || D(clean) fwd, D(enhanced) || A,
+    E bwd || D(clean) bwd; knobs.RAGGED_BATCHED off); same trajectory as the synchronous step's two-pass branch, which the F1
+    goldens pin."""
+    from aas_enhancement_amd import knobs
     from aas_enhancement_amd.trainer_AAS import Trainer
     z = load("f1_aas_tiny.npz")
     c = make_batch(3, 8, [52, 47, 41], 4000)
     cl = (torch.from_numpy(c["inputs"]), None, torch.from_numpy(c["pct"]), None, torch.from_numpy(c["mask"]))
     res = {}
-    for mode in ("sync", "lanes"):
+    for mode in ("sync", "lanes", "batched"):
         tr = Trainer(cfg(lr=float(z["cfg_lr"]), allow_ASR_update_iter=0), None, models=build_tiny(z))
         tr.kt = float(z["kt0"])
         out = []
@@ -191,16 +193,19 @@ def test_two_lane_schedule_on_ragged_pair_matches_synchronous_step(gpu, precisio
             if mode == "sync":
                 r = tr.train_step(ny, cl, it, log_norms=False)
             else:
-                tr.train_step_async(ny, cl, it)
+                with knobs.override(RAGGED_BATCHED=(mode == "batched")):
+                    tr.train_step_async(ny, cl, it)
                 assert tr._kt_dev_live          # really the device-resident path, not the synchronous fallback
+                assert tr._last_schedule == {"lanes": "lanes", "batched": "batched-ragged"}[mode]
                 r = tr.read_scalars()
             out.append([r[k] for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt", "conv_measure")])
         res[mode] = (np.asarray(out), {k: v.detach().clone() for m in (tr.G, tr.D, tr.ASR) for k, v in m.state_dict().items()})
-    assert np.allclose(res["sync"][0], res["lanes"][0], rtol=2e-4), (res["sync"][0], res["lanes"][0])
-    for k, v in res["sync"][1].items():
-        if k in NOISE_PARAMS:
-            continue
-        assert rel_err(res["lanes"][1][k], v) < 1e-3, k
+    for mode in ("lanes", "batched"):
+        assert np.allclose(res["sync"][0], res[mode][0], rtol=2e-4), (mode, res["sync"][0], res[mode][0])
+        for k, v in res["sync"][1].items():
+            if k in NOISE_PARAMS:
+                continue
+            assert rel_err(res[mode][1][k], v) < 1e-3, (mode, k)
 
 
 def test_exchange_timeout_raises_with_layer_name(gpu):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak run of the device-resident step (GPU box): STEPS iterations of train_step_async at BASELINE config-2 sizes, switching
-between the batched-D schedule (equal padded lengths) and the two-lane schedule (ragged pair) every 25 steps, trainable A from
+between the batched-D schedule (equal padded lengths), its two-row-class form (ragged pair, clean T = 184) and the two-lane schedule
+(clean T = 120: below the length-ratio threshold) every 25 steps, trainable A from
 step 100 on, scalars read back every 25 steps (where a raised exchange-timeout word or a non-finite loss raises).
 Usage: python tools/soak.py [STEPS=400]"""
 import os
@@ -25,17 +26,19 @@ def main():
                                 allow_ASR_update_iter=100, schedule="fused")
     tr = Trainer(cfg, None, models=bench.build_models())
     ny, cl = bench.make_batches(0, dev)
-    cl_r = (cl[0][:, :, :184].contiguous(), None, None, None, torch.zeros(30, 1, 184, dtype=torch.uint8, device=dev))
-    cl_r[4].n_valid = 30 * 184
+    pairs = [cl]
+    for tc in (184, 120):
+        c_ = (cl[0][:, :, :tc].contiguous(), None, None, None, torch.zeros(30, 1, tc, dtype=torch.uint8, device=dev))
+        c_[4].n_valid = 30 * tc
+        pairs.append(c_)
     t0 = time.time()
     hist = []
     for it in range(steps):
-        ragged = (it // 25) % 2 == 1
-        tr.train_step_async(ny, cl_r if ragged else cl, it)
+        tr.train_step_async(ny, pairs[(it // 25) % 3], it)
         if (it + 1) % 25 == 0:
             r = tr.read_scalars()          # raises on an exchange timeout / divergence
-            hist.append((it + 1, "lanes" if ragged else "batched", r["l_adv_ny_G"], r["l_adv_cl"], r["l_ctc"], r["kt"]))
-            print("step %4d %-7s adv_ny %.4f adv_cl %.4f ctc %.4f kt %.4f" % hist[-1], flush=True)
+            hist.append((it + 1, tr._last_schedule, r["l_adv_ny_G"], r["l_adv_cl"], r["l_ctc"], r["kt"]))
+            print("step %4d %-14s adv_ny %.4f adv_cl %.4f ctc %.4f kt %.4f" % hist[-1], flush=True)
     torch.cuda.synchronize()
     assert not ops.rnn_timeout_flag()
     print("soak ok: %d steps in %.1f s (%.2f ms / step incl. read-backs); CTC %.3f -> %.3f" % (steps, time.time() - t0, 1e3 * (time.time() - t0) / steps, hist[0][4], hist[-1][4]))
