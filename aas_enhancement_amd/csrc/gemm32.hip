@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256, TMW == 64 ? 2 : 3) void gemm32_kernel(G32 p) {
     auto fetch = [&](Src& s, bool kc, unsigned dst, int64_t ld, int kdiv, int64_t wrap) {
         const float* g = (s.ok && s.k < kend) ? s.p : zero;
         glds16(g, dst);
+        if (p.flags & 1) return;      // ablation: every k-step refetches the tile's first one (sources stay L2-resident)
         s.k += TK;
         if (kc) {
             s.p += TK;

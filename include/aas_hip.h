@@ -33,7 +33,8 @@ int aas_device_cus(void);
  * trainer).  Ablation bits - results are WRONG when one is set (profiling, and the timeout test):
  *   persistent recurrent kernels: 1 skip the exchange loads, 2 skip the MFMAs, 4 skip the wait / poll, 8 skip the
  *     publish stores (consumers then run into their bounded-spin timeout), 64 record phase time stamps;
- *   GEMM kernels: 16 skip the MFMAs, 32 skip the stores, 64 skip the loads, 128 epilogue only.
+ *   GEMM kernels: 16 skip the MFMAs, 32 skip the stores, 64 skip the loads, 128 epilogue only, 1 (aas_gemm_f32's LDS-DMA kernel) every
+ *     k-step refetches the tile's first one (same instruction stream, L2-resident sources).
  * Kernel-selection bits (results unchanged): 32 plain first exchange load in the forward kernels, 256 all-gather
  *   BPTT instead of the reduce-scatter kernel, 512 16-unit slices, 8192 poll before streaming in the reduce-scatter
  *   BPTT, 1024 128x128 tiles instead of 256x256 and 2048 128x256 instead of 128x128 in aas_gemm_planes, 4096 plain
