@@ -84,6 +84,54 @@ def test_row_classes_match_one_launch_per_class(gpu, kind, H, I, Na, Nb, Ta, Tb,
         assert rel(a, b) < tol
 
 
+@pytest.mark.parametrize("kind,how", [("lstm", "chunks"), ("gru", "chunks"), ("lstm", "counter"), ("gru", "counter")])
+def test_row_classes_on_row_chunked_launches_and_the_counter_kernels(gpu, kind, how):
+    """The class boundary is a GLOBAL row index: a batch that a CU-capped launch processes in several row chunks (one kernel launch
+    per chunk), and the round-1 counter-based kernels (debug bit 134217728) that remain the fallback family."""
+    from aas_enhancement_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    H, I, Na, Nb, Ta, Tb = 96, 32, 70, 90, 21, 30
+    G = {"lstm": 4, "gru": 3}[kind]
+    g = torch.Generator().manual_seed(99)
+    w = [((torch.rand(s, generator=g) - 0.5) * 0.2).to(dev) for s in ((G * H, I), (G * H, H), (G * H, I), (G * H, H))]
+    xa, xb = torch.randn(Ta, Na, I, generator=g).to(dev), torch.randn(Tb, Nb, I, generator=g).to(dev)
+    T, N = max(Ta, Tb), Na + Nb
+    x = torch.randn(T, N, I, generator=g).to(dev)
+    x[:Ta, :Na], x[:Tb, Na:] = xa, xb
+    dy = torch.randn(T, N, H, generator=g).to(dev)
+    rs = torch.ones(N, device=dev)
+    rs._aas_row_len = (Na, Ta, Tb)
+    lib = _lib.lib()
+    try:
+        if how == "chunks":
+            ops.set_rnn_cu_limit(24)     # 6 unit slices x 2 directions x 2 row groups: the 160 rows take several launches
+        else:
+            lib.aas_set_debug_flags(134217728)
+        outs = []
+        for split in (True, False):
+            ws = [t.detach().clone().requires_grad_(True) for t in w]
+            if split:
+                a_, b_ = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+                ya, yb = _layer(kind, a_, ws), _layer(kind, b_, ws)
+                ((ya * dy[:Ta, :Na]).sum() + (yb * dy[:Tb, Na:]).sum()).backward()
+                outs.append((ya.detach(), yb.detach(), a_.grad, b_.grad, [t.grad for t in ws]))
+            else:
+                x_ = x.clone().requires_grad_(True)
+                y = _layer(kind, x_, ws, rs=rs)
+                y.backward(dy)
+                outs.append((y.detach()[:Ta, :Na], y.detach()[:Tb, Na:], x_.grad[:Ta, :Na], x_.grad[:Tb, Na:], [t.grad for t in ws]))
+                assert float(y.detach()[Ta:, :Na].abs().max()) == 0.0 and float(x_.grad[Ta:, :Na].abs().max()) == 0.0
+        torch.cuda.synchronize()
+    finally:
+        ops.set_rnn_cu_limit(0)
+        lib.aas_set_debug_flags(0)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+    for a, b in zip(outs[1][:4], outs[0][:4]):
+        assert rel(a, b) < 2e-5
+    for a, b in zip(outs[1][4], outs[0][4]):
+        assert rel(a, b) < 2e-5
+
+
 def test_row_classes_are_one_shot_and_validated(gpu):
     from aas_enhancement_amd import _lib, ops
     lib = _lib.lib()
