@@ -61,9 +61,13 @@ def rnn_timeout_flag(dev=None):
 
 
 def clear_rnn_timeout():
+    """Lower the sticky word after a reported exchange timeout.  The managed exchange buffers are handed back too: a launch that gave
+    up may have left its half in any state; they are poison-filled afresh at their next use (`_xchg_buf`)."""
     for k, b in _scratch.items():
         if k[0] == "sync":
             b.view(torch.int32)[1024:1025].zero_()
+        elif k[0] in ("xchg_fwd", "xchg_bwd"):
+            lib().aas_rnn_xchg_forget(ptr(b))
 
 
 def check_rnn_health(scalars=()):
