@@ -6,7 +6,6 @@ op being replaced (SeanNaren/warp-ctc binding, defaults): ``CTCLoss()(acts[T,N,C
 labels[sum L] int32 (no blanks), act_lens[N] int32, label_lens[N] int32) -> FloatTensor[1]`` = sum of
 per-utterance costs, blank index 0, differentiable wrt ``acts`` only, gradients zero for t >= act_len.
 """
-import torch
 import torch.nn as nn
 
 from . import ops

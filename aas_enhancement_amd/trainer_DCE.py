@@ -1,8 +1,6 @@
 """minimize_DCE trainer (reference Speech_enhancement_by_AAS/trainer_DCE.py; hot loop :111-127)."""
 import os
 
-import torch
-
 from .model import L1Loss_mask, stackedBRNN, supported_rnns
 from . import ops
 from .utils import AverageMeter, _get_variable_nograd, attach_n_valid

@@ -1,4 +1,4 @@
-import sys, torch, numpy as np
+import sys, torch
 sys.path.insert(0, ".")
 from aas_enhancement_amd import knobs, ops
 from tests.test_gpu_round5 import _layer_run
