@@ -158,6 +158,16 @@ extern "C" int aas_rnn_xchg_is_managed(void* xchg) {
     return g_xchg.count(xchg) ? 1 : 0;
 }
 
+bool aas_first_use_on_device(unsigned char* flags) {
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= AAS_MAX_DEV) return true;   // (unknown device: set the attribute every time)
+    std::lock_guard<std::mutex> lk(mu);
+    if (flags[dev]) return false;
+    flags[dev] = 1;
+    return true;
+}
+
 const char* aas_ablation_env(const char* name) {
     static const bool on = getenv("AAS_ABLATION") && atoi(getenv("AAS_ABLATION")) == 1;
     return on ? getenv(name) : nullptr;

@@ -20,6 +20,10 @@ int aas_precision_value();
 int aas_wgrad_wg_cap();                       // 0 = no cap on the grid of aas_gemm_planes_tn
 void aas_note_fwd_h_planes(int pitch_bytes);  // what the last forward recurrent launch left in its exchange buffer (0: nothing usable)
 int aas_rnn_row_classes_take(const char* who, int T, int N, int* n, int* t0, int* t1);   // one-shot (aas_set_rnn_row_classes); default: all rows live for T
+// Per-device "done once" flags (function attributes such as the raised dynamic-LDS limit belong to a device): true exactly once per
+// device for a given flag array, thread-safe.  flags: a static unsigned char[AAS_MAX_DEV] of the call site.
+constexpr int AAS_MAX_DEV = 64;
+bool aas_first_use_on_device(unsigned char* flags);
 int aas_rnn_launch_tag_value();  // >= 1: what a timed-out persistent launch leaves in its sticky error word
 // gemm32.hip: the LDS-DMA fp32 GEMM; -> 0 launched, 1 error, -1 not applicable to these operands (take the general kernel)
 int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,

@@ -239,12 +239,10 @@ int launch_planes(PG p, dim3 grid, hipStream_t s) {
         p.per = (p.tiles + 7) / 8;
         grid = dim3(8 * p.per);
     }
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_kernel<BM, BN, WM, WN, SWAP>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
-        attr_done = true;
-    }
+    static unsigned char attr_done[AAS_MAX_DEV];
+    if (aas_first_use_on_device(attr_done) &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_kernel<BM, BN, WM, WN, SWAP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return -1;
     hipLaunchKernelGGL((gemm_planes_kernel<BM, BN, WM, WN, SWAP>), grid, dim3(64 * WM * WN), LDS, s, p);
     return 0;
 }
