@@ -1470,6 +1470,14 @@ def birnn_layer(x, w_ih, w_hh, w_ih_r, w_hh_r, kind="lstm", residual=False, rs=N
 SYNC_BN = [None]   # a dist.DPContext: train-mode statistics are all-reduced over the ranks (SyncBN)
 
 
+def _direct_small(params):
+    """True when every one of `params` (nn.Parameters or None) has its .grad inside a dist.FlatBuffers gradient buffer: a backward
+    kernel with an accumulate flag can then add into it on the stream it runs on - what autograd's AccumulateGrad would do with one
+    more launch per parameter."""
+    return (DIRECT_WGRAD[0] and LINEAR_DIRECT[0]
+            and all(p_ is not None and getattr(p_, "_aas_flat_grad", False) and p_.grad is not None and p_.grad.is_contiguous() for p_ in params))
+
+
 class _BatchNormRows(torch.autograd.Function):
     """Train-mode BatchNorm over the rows of x[..., C] (+ fused LeakyReLU(slope)); updates running stats.
     With SYNC_BN set (data parallel, --sync_bn) the per-channel sums and the row count are all-reduced between the
@@ -1499,6 +1507,7 @@ class _BatchNormRows(torch.autograd.Function):
                                      ptr(running_mean), ptr(running_var), float(momentum), ptr(red), ptr(ctx.rows), ptr(nbt)), "aas_bn_apply")
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.slope = slope
+        ctx.params = (gamma, beta)      # the nn.Parameters themselves (direct accumulation into their flat-buffer .grad)
         return y
 
     @staticmethod
@@ -1508,12 +1517,15 @@ class _BatchNormRows(torch.autograd.Function):
         C = x.shape[-1]
         R = x.numel() // C
         dx = torch.empty_like(x)
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(beta)
+        # gamma / beta that live in a flat gradient buffer: the kernel's final reduce adds into .grad itself (no autograd accumulation launch)
+        direct = _direct_small(ctx.params) and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+        dgamma = ctx.params[0].grad if direct else torch.empty_like(gamma)
+        dbeta = ctx.params[1].grad if direct else torch.empty_like(beta)
+        acc = 1 if direct else 0
         if ctx.dp is None:
             wsd = _wsd(x.device, 2 * C)
             check(lib().aas_bn_bwd(stream(), ptr(x), ptr(dy), ptr(dx), R, C, ptr(gamma), ptr(beta), float(ctx.slope),
-                                   ptr(stats), ptr(dgamma), ptr(dbeta), 0, ptr(wsd)), "aas_bn_bwd")
+                                   ptr(stats), ptr(dgamma), ptr(dbeta), acc, ptr(wsd)), "aas_bn_bwd")
         else:
             loc = torch.empty(2 * C, device=x.device, dtype=torch.float64)
             check(lib().aas_bn_bwd_reduce(stream(), ptr(x), ptr(dy), R, C, ptr(gamma), ptr(beta), float(ctx.slope), ptr(stats),
@@ -1521,7 +1533,9 @@ class _BatchNormRows(torch.autograd.Function):
             glob = loc.clone()
             ctx.dp.reduce_scalars(glob)
             check(lib().aas_bn_bwd_apply(stream(), ptr(x), ptr(dy), ptr(dx), R, C, ptr(gamma), ptr(beta), float(ctx.slope),
-                                         ptr(stats), ptr(dgamma), ptr(dbeta), 0, ptr(glob), ptr(loc), ptr(ctx.rows)), "aas_bn_bwd_apply")
+                                         ptr(stats), ptr(dgamma), ptr(dbeta), acc, ptr(glob), ptr(loc), ptr(ctx.rows)), "aas_bn_bwd_apply")
+        if direct:
+            return dx, None, None, None, None, None, None, None, None
         return dx, (dgamma if ctx.needs_input_grad[1] else None), (dbeta if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
 
 
@@ -1612,6 +1626,7 @@ class _Conv1dCL(torch.autograd.Function):
         ctx.save_for_backward(x, W2)
         ctx.dims = (N, T, F, M, KW, T1, stride)
         ctx.has_b = b is not None
+        ctx.bias_param = b
         return y
 
     @staticmethod
@@ -1625,7 +1640,10 @@ class _Conv1dCL(torch.autograd.Function):
             gemm(TN, M, KW * F, N * T1, dy, M, x, stride * F, dW2, KW * F, kdivB=T1, kouterB=T * F)
             dW = _kf_to_w(dW2, F, KW)
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = colsum(dy.view(N * T1, M), N * T1, M)
+            if _direct_small((ctx.bias_param,)):     # straight into the flat-buffer .grad
+                check(lib().aas_colsum_f32(stream(), ptr(dy), N * T1, M, M, ptr(ctx.bias_param.grad), 1), "aas_colsum_f32")
+            else:
+                db = colsum(dy.view(N * T1, M), N * T1, M)
         dx = None
         if ctx.needs_input_grad[0]:
             dcol = torch.empty((N * T1, KW * F), device=x.device, dtype=torch.float32)
