@@ -851,6 +851,8 @@ class Trainer(ops.TrainerContext):
                     t_.record_stream(main)
             fused = getattr(self, "_fused", None) is not None and scales is not None and mask is None
             Tn, Tc = leaf.size(2), cl_inputs.size(2)
+            # (different padded lengths: only with the row classes the caller attached to rs - _batched_D_core)
+            assert Tn == Tc or getattr(rs, "_aas_row_len", None) == (leaf.size(0), Tn, Tc)
             if fused or Tn != Tc:
                 gD = self.D.forward_stages(None, wgrad_row_scale=rs, pair=(leaf, cl_inputs))
             else:
