@@ -163,3 +163,52 @@ def test_row_classes_are_one_shot_and_validated(gpu):
     with pytest.raises(NotImplementedError):
         rs._aas_row_len = (2, T, 5)
         ops.birnn_layer(x, w[0][:H], w[1][:H], w[2][:H], w[3][:H], kind="rnn", rs=rs)
+
+
+def test_row_classes_random_shapes_and_degenerate_classes(gpu):
+    """Seeded sweep over layer kinds, hidden sizes (all three forward kernel families), class sizes and lengths - including a class
+    of one frame, an empty first class and an empty second class - against one launch per class, fp32."""
+    import random
+    from aas_enhancement_amd import ops
+    dev = torch.device("cuda:0")
+    rnd = random.Random(20261003)
+    cases = [("lstm", 64, 3, 0, 9, 9), ("gru", 64, 0, 4, 7, 7), ("lstm", 500, 5, 7, 1, 12), ("gru", 256, 6, 2, 14, 1)]
+    for _ in range(14):
+        cases.append((rnd.choice(["lstm", "gru"]), rnd.choice([24, 40, 72, 128, 256, 320, 500]), rnd.randint(1, 24), rnd.randint(1, 24),
+                      rnd.randint(1, 40), rnd.randint(1, 40)))
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+    for ci, (kind, H, Na, Nb, Ta, Tb) in enumerate(cases):
+        if Ta == Tb and Na and Nb:
+            Tb += 1
+        I = 32
+        G = {"lstm": 4, "gru": 3}[kind]
+        g = torch.Generator().manual_seed(500 + ci)
+        w = [((torch.rand(s, generator=g) - 0.5) * (1.5 / H ** 0.5)).to(dev) for s in ((G * H, I), (G * H, H), (G * H, I), (G * H, H))]
+        T, N = max(Ta if Na else 0, Tb if Nb else 0), Na + Nb
+        x = torch.randn(T, N, I, generator=g).to(dev)
+        dy = torch.randn(T, N, H, generator=g).to(dev)
+        rs = torch.ones(N, device=dev)
+        rs._aas_row_len = (Na, Ta if Na else T, Tb if Nb else T)
+        ws = [t.clone().requires_grad_(True) for t in w]
+        xj = x.clone().requires_grad_(True)
+        y = _layer(kind, xj, ws, rs=rs)
+        y.backward(dy)
+        ref_w = [torch.zeros_like(t) for t in w]
+        for lo, n, Tc in ((0, Na, Ta), (Na, Nb, Tb)):
+            if n == 0:
+                continue
+            ws2 = [t.clone().requires_grad_(True) for t in w]
+            xs = x[:Tc, lo:lo + n].clone().requires_grad_(True)
+            ys = _layer(kind, xs, ws2)
+            ys.backward(dy[:Tc, lo:lo + n].contiguous())
+            torch.cuda.synchronize()
+            tag = (ci, kind, H, Na, Nb, Ta, Tb, lo)
+            assert rel(y.detach()[:Tc, lo:lo + n], ys.detach()) < 2e-5, tag
+            assert rel(xj.grad[:Tc, lo:lo + n], xs.grad) < 2e-5, tag
+            if Tc < T:
+                assert float(y.detach()[Tc:, lo:lo + n].abs().max()) == 0.0 and float(xj.grad[Tc:, lo:lo + n].abs().max()) == 0.0, tag
+            for a, b in zip(ref_w, ws2):
+                a += b.grad
+        for a, b in zip(ws, ref_w):
+            assert rel(a.grad, b) < 3e-5, (ci, kind, H, Na, Nb, Ta, Tb)
+    assert not ops.rnn_timeout_flag()
