@@ -32,7 +32,7 @@ _TABLE = {
     "INTERLEAVE": (True, _b),         # the two chains queued layer by layer in alternation
     "TWO_LANES": ("auto", _s),        # auto | 1 | 0: two-lane schedule (ragged noisy / clean pairs) vs batched D
     "RAGGED_BATCHED": (True, _b),     # ragged noisy / clean pair: ONE batched D pass with two row classes instead of the two-lane schedule
-    "RAGGED_MIN_RATIO": (0.8, float),  # ... when min(T) / max(T) is at least this (the batched pass runs max(T) steps for every row)
+    "RAGGED_MIN_RATIO": (0.65, float),  # ... when min(T) / max(T) is at least this (the batched pass runs max(T) steps for every row)
     "PAIR_BWD": ("auto", _s),         # auto | 0 | 1: one autograd call over both chains' losses
     "NEUTRAL_BWD": (True, _b),
     "BWD_FROM": ("neutral", _s),

@@ -548,8 +548,9 @@ class Trainer(ops.TrainerContext):
     def _ragged_batched_ok(self, inputs, cl_inputs):
         """A noisy / clean pair that differs only in its padded length T can take the batched-D schedule (knobs.RAGGED_BATCHED): D's
         recurrent launches carry two row classes.  Needs the interleaved device path and lstm / gru layers in D.  The batched pass
-        runs max(T) steps for every row, the two-lane schedule each batch's own: config 2 with noisy T = 200 measured 27.0 vs 28.8 ms
-        at clean T = 184 and 27.9 vs 26.8 at clean T = 120 (tools/ragged_bench.py), hence the length-ratio threshold."""
+        runs max(T) steps for every row, the two-lane schedule each batch's own: config 2 with noisy T = 200 measured 27.0-27.3 ms at
+        every clean T, against 28.8 / 27.9 / 27.5 / 27.3 / 26.9 ms on two lanes at clean T = 184 / 160 / 150 / 130 / 120
+        (tools/ragged_bench.py), hence the length-ratio threshold."""
         if not knobs.get("RAGGED_BATCHED") or str(knobs.get("TWO_LANES")) != "auto" or not self._interleave_ok():
             return False
         a, b = tuple(inputs.shape), tuple(cl_inputs.shape)
