@@ -8,6 +8,9 @@
                   reference's behaviour where G only gets the adversarial gradient)
   am_step      <- AM_training/train.py:297-349
   acoustic_step <- trainer_acoustic.py:120-142 (E + A, loss = CTC / N: no discriminator, no w_acoustic)
+  greedy_decoding / greedy_decoding_and_FSEGAN / greedy_decoding_and_AAS and the validation loops around them
+               <- trainer_DCE.py:130-190,209-250, trainer_FSEGAN.py:199-243,277-317, trainer_AAS.py:215-263,301-351
+                  (pinned by tests/golden/f13_validation.npz)
 
 Substitutions vs the reference source: .data[0] -> .item(); no
 .cuda(); bool mask; warpctc CTCLoss(prob, ...) -> F.ctc_loss(log_softmax(prob)),
@@ -176,3 +179,83 @@ def am_step(A, opt, batch):
     opt.step()
     v = loss.item()
     return dict(loss=v, is_inf=(v == math.inf or v == -math.inf), logits=out.detach())
+
+
+# ---- validation passes (the save_iter blocks of the trainers) -------------------------------------------------------------------
+class Meter:
+    """utils.py:35-51 AverageMeter."""
+
+    def __init__(self):
+        self.sum = self.count = self.avg = 0
+
+    def update(self, val, n=1):
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def greedy_decoding(G, A, labels, inputs, targets, input_percentages, target_sizes):
+    """trainer_DCE.py:209-250 (= step 1 of trainer_FSEGAN.py:277-306 and trainer_AAS.py:301-340): enhanced = G(inputs), prob =
+    A(enhanced) time-major, sizes = int(pct * T'), greedy strings vs the transcripts; wer = we / total_word and - sic - cer =
+    ce / total_word.  -> (wer, cer, total_word, total_char, enhanced, prob, sizes)."""
+    from . import decode_np as DN
+    split, offset = [], 0
+    for size in target_sizes.tolist():
+        split.append(targets[offset:offset + size].tolist())
+        offset += size
+    enhanced = G(inputs)
+    prob = A(enhanced).transpose(0, 1)
+    sizes = frame_sizes(input_percentages, prob.size(0))
+    decoded = DN.greedy_strings(prob.detach().numpy(), sizes.tolist(), labels)
+    refs = [DN.labels_to_string(s_, labels) for s_ in split]
+    we = ce = total_word = total_char = 0
+    for d_, r_ in zip(decoded, refs):
+        we += DN.wer(d_, r_)
+        ce += DN.cer(d_, r_)
+        total_word += len(r_.split())
+        total_char += len(r_)
+    return we / total_word, ce / total_word, total_word, total_char, enhanced, prob, sizes
+
+
+def greedy_decoding_and_FSEGAN(G, D, A, labels, mixture, cleans, targets, input_percentages, target_sizes, mask, w_adversarial):
+    """trainer_FSEGAN.py:277-317 -> (dce, l_adv_ny, nElement, wer, cer, total_word, total_char); D through forward_paired."""
+    wer, cer, nW, nC, enhanced, _, _ = greedy_decoding(G, A, labels, mixture, targets, input_percentages, target_sizes)
+    l_adv_ny, nElement = l1loss_mask(D.forward_paired(enhanced, mixture), enhanced, mask.bool())
+    l_adv_ny = l_adv_ny * w_adversarial
+    dce, nElement_ = l1loss_mask(enhanced, cleans, mask.bool())
+    assert nElement == nElement_
+    return dce, l_adv_ny, nElement, wer, cer, nW, nC
+
+
+def greedy_decoding_and_AAS(G, D, A, labels, inputs, targets, input_percentages, target_sizes, mask, w_adversarial, w_acoustic):
+    """trainer_AAS.py:301-351 -> (l_CTC, l_adv_ny, nElement, wer, cer, total_word, total_char)."""
+    wer, cer, nW, nC, enhanced, prob, sizes = greedy_decoding(G, A, labels, inputs, targets, input_percentages, target_sizes)
+    l_adv_ny, nElement = l1loss_mask(D(enhanced), enhanced, mask.bool())
+    l_adv_ny = l_adv_ny * w_adversarial
+    l_ctc = w_acoustic * ctc_sum(prob, targets, sizes, target_sizes) / inputs.size(0)
+    return l_ctc, l_adv_ny, nElement, wer, cer, nW, nC
+
+
+def dce_validation(G, A, labels, batches):
+    """trainer_DCE.py:137-153 / :163-179 over paired-collate batches (inputs, cleans, mask, targets, pct, target_sizes):
+    -> dict(dce, wer, cer) of the AverageMeters (dce weighted by nElement, wer by words, cer by characters)."""
+    m_dce, m_wer, m_cer = Meter(), Meter(), Meter()
+    with torch.no_grad():
+        for inputs, cleans, mask, targets, pct, tsz in batches:
+            dce, n_el = l1loss_mask(G(inputs), cleans, mask.bool())
+            m_dce.update(dce.item(), n_el)
+            wer, cer, nW, nC, _, _, _ = greedy_decoding(G, A, labels, inputs, targets, pct, tsz)
+            m_wer.update(wer, nW)
+            m_cer.update(cer, nC)
+    return dict(dce=m_dce.avg, wer=m_wer.avg, cer=m_cer.avg)
+
+
+def fsegan_validation(G, D, A, labels, batches, w_adversarial):
+    """trainer_FSEGAN.py:207-222 / :235-250 -> dict(dce, adv_ny, wer, cer)."""
+    m = dict(dce=Meter(), adv_ny=Meter(), wer=Meter(), cer=Meter())
+    with torch.no_grad():
+        for mixture, cleans, mask, targets, pct, tsz in batches:
+            dce, adv, n_el, wer, cer, nW, nC = greedy_decoding_and_FSEGAN(G, D, A, labels, mixture, cleans, targets, pct, tsz, mask, w_adversarial)
+            m["dce"].update(dce.item(), n_el); m["adv_ny"].update(adv.item(), n_el)
+            m["wer"].update(wer, nW); m["cer"].update(cer, nC)
+    return {k: v.avg for k, v in m.items()}

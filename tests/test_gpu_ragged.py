@@ -1,6 +1,7 @@
 """Row classes of different sequence length inside one persistent recurrent launch (aas_set_rnn_row_classes) and the batched
 discriminator pass over a ragged noisy / clean pair built on them (trainer_AAS._batched_D_core; the reference runs D twice,
-trainer_AAS.py:94-107).  Checked against what the library itself computes with one launch per class."""
+trainer_AAS.py:94-107).  The layer-level tests compare with what the library itself computes with one launch per class; the
+step-level tests at the end compare with the REFERENCE on pairs of different padded length (fixtures F1r / F3r)."""
 import numpy as np
 import pytest
 import torch
@@ -212,3 +213,150 @@ def test_row_classes_random_shapes_and_degenerate_classes(gpu):
         for a, b in zip(ws, ref_w):
             assert rel(a.grad, b) < 3e-5, (ci, kind, H, Na, Nb, Ta, Tb)
     assert not ops.rnn_timeout_flag()
+
+
+# ---- the ragged-pair STEP against the reference itself (F1r / F3r: T_noisy != T_clean) -------------------------------------------
+# Everything above compares the library with itself.  These compare with vectors generated from the reference's own modules through
+# the restated loop of trainer_AAS.py:131-194 on a noisy / clean pair of DIFFERENT padded length (tools/make_goldens.py: f1r, f3r):
+# the reference draws the two batches from two loaders (:136-138, :175-177), each padded to its own max T (loader_functions.py:47-73).
+REL_OUT, REL_LOSS = 1e-3, 1e-2
+
+
+def _check_all_grads(z, it, nets, tol):
+    """Every parameter gradient of `nets` (read from .grad = the flat buffers) against F1r's full tensors of iteration `it`."""
+    from tests.helpers import NOISE_PARAMS, rel_err
+    n = 0
+    for nm, m in nets:
+        for k, p in m.named_parameters():
+            if nm == "A" and k in NOISE_PARAMS:
+                continue
+            ref = z["it%d.grad.%s.%s" % (it, nm, k)]
+            assert p.grad is not None, (nm, k)
+            scale = max(float(np.abs(ref).max()), float(np.sqrt((ref.astype(np.float64) ** 2).sum() / ref.size)), 1e-30)
+            err = float((p.grad.detach().cpu().double() - torch.from_numpy(ref).double().reshape(p.shape)).abs().max()) / scale
+            assert err < tol, (it, nm, k, err)
+            n += 1
+    return n
+
+
+@pytest.mark.parametrize("schedule", ["fused", "as_executed"])
+def test_f1r_synchronous_step_on_ragged_pairs_vs_reference(gpu, precision, schedule):
+    """F1r through Trainer.train_step (what logging iterations run): 3 iterations, noisy padded 60 / clean padded 47, then the
+    clean batch the longer one, then 60 / 47 again - scalars, both gradient norms, enhanced, logits, every parameter gradient at
+    every iteration, the final parameters."""
+    from tests.helpers import NOISE_PARAMS, batch_from, load, rel_err
+    from tests.test_gpu_step import build_tiny, cfg
+    from aas_enhancement_amd.trainer_AAS import Trainer
+    z = load("f1r_aas_tiny_ragged_pair.npz")
+    tr = Trainer(cfg(lr=float(z["cfg_lr"]), schedule=schedule), None, models=build_tiny(z))
+    tr.kt = float(z["kt0"])
+    gt = 2e-3 if precision != 1 else 3e-2
+    for it in range(3):
+        ny, cl = batch_from(z, "it%d.ny." % it), batch_from(z, "it%d.cl." % it)
+        assert ny[0].shape[2] != cl[0].shape[2]
+        r = tr.train_step(ny, cl, it, log_norms=True)
+        for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt", "conv_measure"):
+            assert r[k] == pytest.approx(float(z["it%d.%s" % (it, k)]), rel=REL_LOSS), (it, k)
+        assert float(r["g_adv"]) == pytest.approx(float(z["it%d.g_adv" % it]), rel=REL_LOSS)
+        assert float(r["g_ctc_adv"]) == pytest.approx(float(z["it%d.g_ctc_adv" % it]), rel=REL_LOSS)
+        assert rel_err(r["enhanced"], z["it%d.enhanced" % it]) < REL_OUT
+        assert rel_err(r["prob"], z["it%d.logits_tnc" % it]) < REL_OUT
+        assert _check_all_grads(z, it, [("G", tr.G), ("D", tr.D), ("A", tr.ASR)], gt) > 60
+    for nm, m in (("G", tr.G), ("D", tr.D), ("A", tr.ASR)):
+        for k, v in m.state_dict().items():
+            if nm == "A" and k in NOISE_PARAMS:
+                continue
+            assert rel_err(v, z["final.%s.%s" % (nm, k)]) < 2e-3, (nm, k)
+
+
+@pytest.mark.parametrize("lanes,expect", [("auto", "batched-ragged"), ("1", "lanes")], ids=["batched_ragged", "twolanes"])
+@pytest.mark.parametrize("frozen", [True, False], ids=["frozenA", "trainableA"])
+def test_f1r_device_resident_step_on_ragged_pairs_vs_reference(gpu, precision, frozen, lanes, expect):
+    """F1r through train_step_async on BOTH device-resident schedules - the batched discriminator pass with two row classes of
+    different length in its recurrent launches (the default for ragged pairs) and the two-lane schedule - frozen / trainable A,
+    three arithmetic modes: scalars, enhanced, logits, the two gradients arriving at `enhanced` and every parameter gradient at
+    every iteration; with a trainable A the whole 3-iteration trajectory and the final parameters (a frozen A leaves the
+    reference's trajectory after iteration 1, where the reference's optimizer_asr first steps)."""
+    from tests.helpers import NOISE_PARAMS, batch_from, load, rel_err
+    from tests.test_gpu_step import build_tiny, cfg
+    from aas_enhancement_amd import knobs, ops
+    from aas_enhancement_amd.trainer_AAS import Trainer
+    z = load("f1r_aas_tiny_ragged_pair.npz")
+    gt = 2e-3 if precision != 1 else 3e-2
+    with knobs.override(TWO_LANES=lanes):
+        tr = Trainer(cfg(lr=float(z["cfg_lr"]), allow_ASR_update_iter=10 ** 9 if frozen else 0), None, models=build_tiny(z))
+        tr.kt = float(z["kt0"])
+        tr.keep_enh_grads = True
+        for it in range(2 if frozen else 3):
+            ny, cl = batch_from(z, "it%d.ny." % it), batch_from(z, "it%d.cl." % it)
+            r = tr.train_step_async(ny, cl, it)
+            assert tr._last_schedule == expect, tr._last_schedule
+            sc = tr.read_scalars()
+            for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt", "conv_measure"):
+                assert sc[k] == pytest.approx(float(z["it%d.%s" % (it, k)]), rel=REL_LOSS), (it, k)
+            assert rel_err(r["enhanced"], z["it%d.enhanced" % it]) < REL_OUT
+            assert rel_err(r["prob"], z["it%d.logits_tnc" % it]) < REL_OUT
+            nets = [("G", tr.G), ("D", tr.D)] + ([] if frozen else [("A", tr.ASR)])
+            assert _check_all_grads(z, it, nets, gt) >= 40
+            for nm, g in zip(("adv", "ctc"), tr._enh_grads):
+                assert rel_err(g, z["it%d.enh_grad.%s" % (it, nm)]) < gt, (it, nm)
+    assert not ops.rnn_timeout_flag()
+    if not frozen:
+        for nm, m in (("G", tr.G), ("D", tr.D), ("A", tr.ASR)):
+            for k, v in m.state_dict().items():
+                if nm == "A" and k in NOISE_PARAMS:
+                    continue
+                assert rel_err(v, z["final.%s.%s" % (nm, k)]) < 2e-3, (nm, k)
+
+
+def _f3r_batches():
+    from tests.test_gpu_round2 import _config2_batches
+    ny, cl = _config2_batches(0)
+    Tc = 184
+    return ny, (cl[0][:, :, :Tc].contiguous(), None, None, None, torch.zeros(cl[0].size(0), 1, Tc, dtype=torch.uint8))
+
+
+@pytest.mark.parametrize("lanes,expect", [("auto", "batched-ragged"), ("1", "lanes")], ids=["batched_ragged", "twolanes"])
+@pytest.mark.parametrize("frozen", [True, False], ids=["frozenA", "trainableA"])
+def test_f3r_config2_ragged_pair_timed_path_vs_reference(gpu, precision, frozen, lanes, expect):
+    """F3r: iteration 0 of config 2 with kt0 = 0.3, noisy T = 200 / clean T = 184 (the pair bench.py times as `ragged_pair*`),
+    through train_step_async on both schedules x frozen / trainable A x three modes: scalars, 256 enhanced / logit samples, EVERY
+    parameter gradient of E / D (/ A) as norm + 64 samples, the networks' total norms and the two gradients arriving at
+    `enhanced` - against the reference's own modules (trainer_AAS.py:136-181 with two batches of different padded length)."""
+    from tests.helpers import NOISE_PARAMS, load
+    from tests.test_gpu_round2 import _config2_models
+    from tests.test_gpu_round5 import _check_param_grads, _gtol, _sqnorm
+    from tests.test_gpu_step import cfg
+    from aas_enhancement_amd import knobs, ops
+    from aas_enhancement_amd.trainer_AAS import Trainer
+    z = load("f3r_aas_config2_ragged_pair.npz")
+    assert int(z["T"]) == 200 and int(z["T_clean"]) == 184
+    with knobs.override(TWO_LANES=lanes):
+        tr = Trainer(cfg(lr=float(z["lr"]), nFeat=80, rnn_size=500, allow_ASR_update_iter=10 ** 9 if frozen else 0), None, models=_config2_models())
+        tr.kt = float(z["kt0"])
+        tr.keep_enh_grads = True
+        ny, cl = _f3r_batches()
+        r = tr.train_step_async(ny, cl, 0)
+        assert tr._last_schedule == expect, tr._last_schedule
+        sc = tr.read_scalars()
+    torch.cuda.synchronize()
+    assert not ops.rnn_timeout_flag()
+    for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt", "conv_measure"):
+        assert sc[k] == pytest.approx(float(z["it0." + k]), rel=REL_LOSS), k
+    enh, prob = r["enhanced"].detach().reshape(-1), r["prob"].detach().reshape(-1)
+    e_got = enh[torch.from_numpy(z["it0.enh_idx"]).cuda()].cpu().numpy()
+    p_got = prob[torch.from_numpy(z["it0.logit_idx"]).cuda()].cpu().numpy()
+    assert np.abs(e_got - z["it0.enh_samples"]).max() < REL_OUT * np.abs(z["it0.enh_samples"]).max()
+    assert np.abs(p_got - z["it0.logit_samples"]).max() < REL_OUT * np.abs(z["it0.logit_samples"]).max()
+    nets = [("G", tr.G), ("D", tr.D)] + ([] if frozen else [("A", tr.ASR)])
+    n, worst = _check_param_grads(z, nets, "it0.", precision, skip=NOISE_PARAMS)
+    assert n >= 40 + (0 if frozen else 30), n
+    st, nt = _gtol(precision)
+    for nm, m in nets:
+        assert float(tr.get_gradient_norm(m).item()) == pytest.approx(float(z["it0.gradnorm_total." + nm]), rel=nt), nm
+    for nm, g in zip(("adv", "ctc"), tr._enh_grads):
+        ref_s = z["it0.enh_grad_samples." + nm]
+        got_s = g.detach().reshape(-1)[torch.from_numpy(z["it0.enh_grad_idx." + nm].astype(np.int64)).cuda()].cpu().numpy()
+        assert _sqnorm(g) == pytest.approx(float(z["it0.enh_grad_norm." + nm]), rel=nt), nm
+        assert np.abs(got_s - ref_s).max() < st * np.abs(ref_s).max(), nm
+    print("F3r worst parameter-gradient error", worst)

@@ -54,6 +54,40 @@ def test_aas_step_tiny_three_iterations():
             assert rel_err(v, z["final.%s.%s" % (nm, k)]) < 1e-5, (nm, k)
 
 
+def test_aas_step_tiny_ragged_pairs_three_iterations():
+    """F1r: the noisy and the clean batch of DIFFERENT padded length (trainer_AAS.py:136-138,175-177: two loaders), one iteration
+    with the clean batch the longer one - the oracle step against the reference's: scalars, outputs, every gradient at every
+    iteration, final parameters."""
+    z = load("f1r_aas_tiny_ragged_pair.npz")
+    G, D, A = _build_tiny()
+    for nm, m in (("G", G), ("D", D), ("A", A)):
+        load_sd(m, sub(z, "init.%s." % nm))
+    cfg = RS.StepConfig(lr=float(z["cfg_lr"]))
+    og, od, oa = RS.make_optim(G, cfg), RS.make_optim(D, cfg), RS.make_optim(A, cfg)
+    kt = float(z["kt0"])
+    seen = set()
+    for it in range(3):
+        ny = batch_from(z, "it%d.ny." % it)
+        cl = batch_from(z, "it%d.cl." % it)
+        seen.add(int(np.sign(ny[0].shape[2] - cl[0].shape[2])))
+        kt, sc = RS.aas_step(G, D, A, og, od, oa, ny, cl, cfg, kt, it)
+        for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "g_adv", "g_ctc_adv", "kt", "conv_measure"):
+            assert sc[k] == pytest.approx(float(z["it%d.%s" % (it, k)]), rel=1e-5), (it, k)
+        assert rel_err(sc["enhanced"], z["it%d.enhanced" % it]) < 1e-5
+        assert rel_err(sc["logits"], z["it%d.logits_tnc" % it]) < 1e-5
+        for nm, m in (("G", G), ("D", D), ("A", A)):
+            for k, p in m.named_parameters():
+                if nm == "A" and k in NOISE_PARAMS:      # (exactly zero in exact arithmetic: rounding noise on both sides)
+                    continue
+                assert grad_close(p.grad, z["it%d.grad.%s.%s" % (it, nm, k)]), (it, nm, k)
+    assert seen == {1, -1}      # both orders of the pair occur
+    for nm, m in (("G", G), ("D", D), ("A", A)):
+        for k, v in m.state_dict().items():
+            if nm == "A" and k in NOISE_PARAMS:
+                continue
+            assert rel_err(v, z["final.%s.%s" % (nm, k)]) < 1e-5, (nm, k)
+
+
 def test_aas_config2_gradients_with_live_D_step():
     """F3b at size on the CPU oracle: iteration 0 of config 2 with kt0 = 0.3 - the scalars and every parameter gradient (norm + 64
     samples) of E, D and A against the reference's (one oracle step: ~25 s on 4 threads).  Tolerance: the reference itself moves by
@@ -300,3 +334,71 @@ def test_lmfb_oracle_stft_against_scipy():
     # mel filter bank: rows are triangles with unit-area (Slaney) normalisation, centres increasing, no empty filter
     fb = lmfb_np.mel_basis(16000, 320, 80)
     assert (fb >= 0).all() and (fb.sum(1) > 0).all() and (np.diff(fb.argmax(1)) >= 0).all()
+
+
+def _f13_models(z):
+    G = RM.RefStackedBRNN(8, 8, 16, 4)
+    Dp = RM.RefStackedBRNN(16, 8, 16, 4)
+    Da = RM.RefStackedBRNN(8, 8, 16, 4)
+    A = RM.RefDeepSpeech(nn.GRU, LABELS, 12, 3, 11, 2, 8, 2, nFreq=8)
+    for nm, m in (("G", G), ("Dp", Dp), ("Da", Da), ("A", A)):
+        load_sd(m, sub(z, "init.%s." % nm))
+    G.eval()
+    return G, Dp, Da, A
+
+
+def f13_batches(z):
+    """The two validation batches of F13 in the paired collate layout (inputs, cleans, mask, targets, pct, target_sizes)."""
+    g = lambda k: torch.from_numpy(np.asarray(z[k]))
+    return [(g("b%d.inputs" % b), g("b%d.cleans" % b), g("b%d.mask" % b), g("b%d.targets" % b), g("b%d.pct" % b), g("b%d.target_sizes" % b))
+            for b in range(2)]
+
+
+def test_validation_passes_of_the_three_trainers():
+    """F13: greedy_decoding (+ DCE), greedy_decoding_and_FSEGAN and greedy_decoding_and_AAS of the oracle against the reference's
+    modules + decoder: decoded strings, the per-batch tuples and the AverageMeter results of the validation loops."""
+    from oracle import decode_np as DN
+    z = load("f13_validation.npz")
+    G, Dp, Da, A = _f13_models(z)
+    w_adv, w_ac = float(z["w_adversarial"]), float(z["w_acoustic"])
+    batches = f13_batches(z)
+    with torch.no_grad():
+        for b, (inputs, cleans, mask, targets, pct, tsz) in enumerate(batches):
+            p = "b%d." % b
+            wer, cer, nW, nC, enh, prob, sizes = RS.greedy_decoding(G, A, LABELS, inputs, targets, pct, tsz)
+            assert rel_err(enh, z[p + "enhanced"]) < 1e-5 and rel_err(prob, z[p + "logits_tnc"]) < 1e-4
+            assert sizes.tolist() == z[p + "sizes"].tolist()
+            dec = DN.greedy_strings(prob.numpy(), sizes.tolist(), LABELS)
+            for i, s_ in enumerate(dec):
+                assert s_ == bytes(z[p + "decoded%d" % i]).decode("utf8"), (b, i)
+            assert (wer, cer, nW, nC) == pytest.approx((float(z[p + "dce.wer"]), float(z[p + "dce.cer"]), int(z[p + "dce.nWord"]), int(z[p + "dce.nChar"])))
+            t = RS.greedy_decoding_and_FSEGAN(G, Dp, A, LABELS, inputs, cleans, targets, pct, tsz, mask, w_adv)
+            for k, v in zip(("dce", "l_adv_ny", "nElement", "wer", "cer", "total_word", "total_char"), t):
+                assert float(v) == pytest.approx(float(z[p + "fsegan." + k]), rel=1e-5), (b, k)
+            t = RS.greedy_decoding_and_AAS(G, Da, A, LABELS, inputs, targets, pct, tsz, mask, w_adv, w_ac)
+            for k, v in zip(("l_CTC", "l_adv_ny", "nElement", "wer", "cer", "total_word", "total_char"), t):
+                assert float(v) == pytest.approx(float(z[p + "aas." + k]), rel=1e-4), (b, k)
+    r = RS.dce_validation(G, A, LABELS, batches)
+    for k in ("dce", "wer", "cer"):
+        assert r[k] == pytest.approx(float(z["avg.dce." + k]), rel=1e-5), k
+    r = RS.fsegan_validation(G, Dp, A, LABELS, batches, w_adv)
+    for k in ("dce", "adv_ny", "wer", "cer"):
+        assert r[k] == pytest.approx(float(z["avg.fsegan." + k]), rel=1e-5), k
+
+
+def test_oracle_decoder_against_reference_decoder_vectors():
+    """oracle/decode_np.py against F8 (strings and distances from the reference's own decoder.py)."""
+    from oracle import decode_np as DN
+    z = load("f8_host_side.npz")
+    paths, sizes = z["decode.paths"], z["decode.sizes"]
+    onehot = np.zeros((paths.shape[1], paths.shape[0], len(LABELS)), np.float32)
+    for n in range(paths.shape[0]):
+        onehot[np.arange(paths.shape[1]), n, paths[n]] = 1.0
+    got = DN.greedy_strings(onehot, sizes.tolist(), LABELS)
+    for i, s_ in enumerate(got):
+        assert s_ == bytes(z["decode.str%d" % i]).decode("utf8"), i
+    for i in range(int(z["decode.npairs"])):
+        a, b = bytes(z["decode.pair%d.a" % i]).decode("utf8"), bytes(z["decode.pair%d.b" % i]).decode("utf8")
+        assert DN.wer(a, b) == int(z["decode.pair%d.wer" % i]) and DN.cer(a, b) == int(z["decode.pair%d.cer" % i]), i
+    for i in range(6):
+        assert DN.labels_to_string(z["decode.target%d" % i], LABELS) == bytes(z["decode.target_str%d" % i]).decode("utf8")

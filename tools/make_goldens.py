@@ -298,6 +298,91 @@ def f3b_config2_kt():
     np.savez_compressed(os.path.join(OUT, "f3b_aas_config2_kt.npz"), **out)
 
 
+def f1r_tiny_ragged_pair():
+    """F1r: F1's tiny models, 3 iterations, with the noisy and the clean batch of DIFFERENT padded length - what the reference's
+    two loaders deliver on every real iteration (trainer_AAS.py:136-138,175-177; each batch zero-padded to its own max T by
+    loader_functions.py:47-73).  Iteration 0 / 2: noisy padded 60 vs clean padded 47; iteration 1: the CLEAN batch is the longer
+    one (noisy 47 vs clean 60).  Full tensors; every parameter gradient of E / D / A at every iteration."""
+    Fdim, H, HA, M = 8, 16, 12, 8
+    G, D, A = build_aas(Fdim, H, HA, M, 5, seed=1000)
+    init = {}
+    for nm, m in (("G", G), ("D", D), ("A", A)):
+        for k, v in m.state_dict().items():
+            init[nm + "." + k] = v.clone().numpy()
+    cfg = dict(w_adversarial=1.0, w_acoustic=1.0, gamma=0.5, lambda_k=0.001, allow_ASR_update_iter=0)
+    lr = 1e-3
+    og, od, oa = adam(G, lr), adam(D, lr), adam(A, lr)
+    diff = REF.L1Loss_mask()
+    out = dict(cfg_lr=lr, **{"cfg_" + k: v for k, v in cfg.items()})
+    out.update({"init." + k: v for k, v in init.items()})
+    kt = 0.3
+    out["kt0"] = kt
+    lens = [([60, 50, 38], [47, 41, 33]), ([47, 41, 33], [60, 50, 38]), ([60, 52, 45], [47, 47, 30])]
+    for it in range(3):
+        ny = make_batch(3, Fdim, lens[it][0], 2500 + 100 * it, [4, 3, 2], 3500 + 10 * it)
+        cl = make_batch(3, Fdim, lens[it][1], 4500 + 100 * it)
+        eg = []
+        kt, sc, grads, enh, ae, prob, sizes = aas_iteration(G, D, A, og, od, oa, ny, cl, cfg, kt, it, diff, enh_grads=eg)
+        for k, v in ny.items():
+            out["it%d.ny.%s" % (it, k)] = v
+        for k, v in cl.items():
+            out["it%d.cl.%s" % (it, k)] = v
+        for k, v in sc.items():
+            out["it%d.%s" % (it, k)] = np.float64(v)
+        out["it%d.enhanced" % it] = enh
+        out["it%d.ae_ny_G" % it] = ae
+        out["it%d.logits_tnc" % it] = prob
+        out["it%d.sizes" % it] = sizes
+        out["it%d.enh_grad.adv" % it], out["it%d.enh_grad.ctc" % it] = eg[0], eg[1]
+        out.update({"it%d.grad.%s" % (it, k): v for k, v in grads.items()})
+    for nm, m in (("G", G), ("D", D), ("A", A)):
+        for k, v in m.state_dict().items():
+            out["final." + nm + "." + k] = v.clone().numpy()
+    np.savez_compressed(os.path.join(OUT, "f1r_aas_tiny_ragged_pair.npz"), **out)
+    print("F1r", {k: out[k] for k in out if k.startswith("it2.") and np.ndim(out[k]) == 0})
+
+
+def f3r_config2_ragged_pair():
+    """F3r: iteration 0 of config 2 with kt0 = 0.3 and a noisy / clean pair of different padded length: noisy T = 200, clean
+    T = 184 (F3b's clean batch cut to its first 184 frames: the pair bench.py times as `ragged_pair*`).  Same contents as F3b: all
+    scalars, 256 enhanced / logit samples, every E / D / A gradient as norm + 64 samples, totals, the two gradients arriving at
+    `enhanced`."""
+    Fdim, H, HA, M, N, T, L, Tc = 80, 500, 1000, 128, 30, 200, 20, 184
+    G, D, A = build_aas(Fdim, H, HA, M, 5, seed=9000)
+    cfg = dict(w_adversarial=1.0, w_acoustic=1.0, gamma=0.5, lambda_k=0.001, allow_ASR_update_iter=0)
+    og, od, oa = adam(G, 1e-5), adam(D, 1e-5), adam(A, 1e-5)
+    diff = REF.L1Loss_mask()
+    kt0 = 0.3
+    out = dict(weight_seed=9000, lr=1e-5, N=N, F=Fdim, T=T, T_clean=Tc, H=H, HA=HA, M=M, L=L, kt0=kt0, noisy_seed=123, clean_seed=124, label_seed=125)
+    ny = dict(inputs=prng.uniform(123, (N, Fdim, T), 0.0, 6.0), mask=np.zeros((N, 1, T), np.uint8), pct=np.ones(N, np.float32),
+              targets=prng.randint(125, (N * L,), 1, 28).astype(np.int32), target_sizes=np.full(N, L, np.int32))
+    cl = dict(inputs=np.ascontiguousarray(prng.uniform(124, (N, Fdim, T), 0.0, 6.0)[:, :, :Tc]), mask=np.zeros((N, 1, Tc), np.uint8))
+    eg = []
+    kt, sc, grads, enh, ae, prob, sizes = aas_iteration(G, D, A, og, od, oa, ny, cl, cfg, kt0, 0, diff, enh_grads=eg)
+    assert len(eg) == 2
+    for k, v in sc.items():
+        out["it0." + k] = np.float64(v)
+    ie, il = sample_idx(31, enh.shape, 256), sample_idx(41, prob.shape, 256)
+    out["it0.enh_idx"], out["it0.enh_samples"] = ie, enh.reshape(-1)[ie]
+    out["it0.logit_idx"], out["it0.logit_samples"] = il, prob.reshape(-1)[il]
+    tot = dict(G=0.0, D=0.0, A=0.0)
+    for k, g in grads.items():
+        ig = sample_idx(51, g.shape, min(64, g.size))
+        out["it0.gradsample_idx." + k] = ig
+        out["it0.gradsample." + k] = g.reshape(-1)[ig]
+        sq = float((g.astype(np.float64) ** 2).sum())
+        out["it0.gradnorm." + k] = float(np.sqrt(sq))
+        tot[k[0]] += sq
+    for nm in tot:
+        out["it0.gradnorm_total." + nm] = float(np.sqrt(tot[nm]))
+    for nm, g in (("adv", eg[0]), ("ctc", eg[1])):
+        ig = sample_idx(53, g.shape, 256)
+        out["it0.enh_grad_idx." + nm], out["it0.enh_grad_samples." + nm] = ig, g.reshape(-1)[ig]
+        out["it0.enh_grad_norm." + nm] = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+    print("F3r", sc, {k: out[k] for k in out if "total" in k or "enh_grad_norm" in k}, flush=True)
+    np.savez_compressed(os.path.join(OUT, "f3r_aas_config2_ragged_pair.npz"), **out)
+
+
 def f3c_thread_spread():
     """F3c: how far the reference's OWN fp32 result moves when only the CPU thread count changes (summation orders inside the
     BLAS / oneDNN kernels): iteration 0 of F3b (kt0 = 0.3) run with 8, 3 and 1 threads; per parameter the 64 gradient samples of F3b
@@ -833,6 +918,164 @@ def f12_cli_defaults():
     print("F12", len(am), "AM flags,", len(aas), "AAS flags")
 
 
+def _ref_decoder():
+    """The reference's AM_training/decoder.py GreedyDecoder (its `Levenshtein` import satisfied by a textbook edit distance, as in
+    F8).  `decode()` itself indexes a dict with tensor elements and fails under torch 2.x, so the callers below pass the
+    argmax path to `convert_to_strings(..., remove_repetitions=True)` as lists - the call decode() makes (:186-201)."""
+    import types as _types
+    if "Levenshtein" not in sys.modules:
+        lev = _types.ModuleType("Levenshtein")
+
+        def distance(a, b):
+            prev = list(range(len(b) + 1))
+            for i, ca in enumerate(a, 1):
+                cur = [i]
+                for j, cb in enumerate(b, 1):
+                    cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+                prev = cur
+            return prev[-1]
+        lev.distance = distance
+        sys.modules["Levenshtein"] = lev
+    if "/root/reference/AM_training" not in sys.path:
+        sys.path.insert(0, "/root/reference/AM_training")
+    import decoder as RDEC
+    return RDEC.GreedyDecoder(LABELS)
+
+
+def _ref_greedy(dec, G, A, inputs, targets, pct, target_sizes):
+    """Step 1 of the three validation functions (trainer_DCE.py:209-250, trainer_FSEGAN.py:277-306, trainer_AAS.py:301-340), line
+    by line: unflatten targets, enhanced = G(inputs), prob = ASR(enhanced) time-major, sizes = pct.mul_(T').int(), argmax decode,
+    per-utterance wer / cer sums; wer = we / total_word, cer = ce / total_word (sic)."""
+    split_targets, offset = [], 0
+    for size in target_sizes.tolist():
+        split_targets.append(targets[offset:offset + size].tolist())
+        offset += size
+    enhanced = G(inputs)
+    prob = A(enhanced)
+    prob = prob.transpose(0, 1)
+    Tn = prob.size(0)
+    sizes = pct.clone().mul_(int(Tn)).int()
+    _, max_probs = torch.max(prob.detach().transpose(0, 1), 2)
+    decoded = dec.convert_to_strings(max_probs.tolist(), sizes.tolist(), remove_repetitions=True)
+    target_strings = dec.convert_to_strings(split_targets)
+    we = ce = total_word = total_char = 0
+    for x in range(len(target_strings)):
+        decoding, reference = decoded[x][0], target_strings[x][0]
+        we += dec.wer(decoding, reference)
+        ce += dec.cer(decoding, reference)
+        total_word += len(reference.split())
+        total_char += len(reference)
+    return enhanced, prob, sizes, we / total_word, ce / total_word, total_word, total_char, [d[0] for d in decoded], [t_[0] for t_ in target_strings]
+
+
+class _Meter(object):       # utils.py:35-51 AverageMeter
+    def __init__(self):
+        self.sum = self.count = self.avg = 0
+
+    def update(self, val, n=1):
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def f13_validation():
+    """F13: the validation passes of the three trainers on the reference's own modules - `greedy_decoding` + DCE
+    (trainer_DCE.py:130-190,209-250), `greedy_decoding_and_FSEGAN` (trainer_FSEGAN.py:199-243,277-317, its
+    `assert(nElement == nElement_)` included; D through forward_paired) and `greedy_decoding_and_AAS` (trainer_AAS.py:215-263,
+    301-351) - over a two-batch validation set in the paired collate layout (loader_functions.py:76-105), with the AverageMeter
+    weighting of the loops.  G in eval mode, A left in train mode (the reference never calls ASR.eval()).  Tiny models, every
+    tensor; labels are word-like (spaces) so that WER is not degenerate."""
+    dec = _ref_decoder()
+    Fdim, H, HA, M = 8, 16, 12, 8
+    G = REF.stackedBRNN(I=Fdim, O=Fdim, H=H, L=4)
+    Dp = REF.stackedBRNN(I=2 * Fdim, O=Fdim, H=H, L=4)      # FSEGAN's discriminator (forward_paired)
+    Da = REF.stackedBRNN(I=Fdim, O=Fdim, H=H, L=4)          # AAS's
+    A = REF.DeepSpeech(rnn_type=nn.GRU, labels=LABELS, rnn_hidden_size=HA, rnn_layers=3, kernel_sz=11, stride=2, map=M, cnn_layers=2, nFreq=Fdim)
+    load_weights(G, 8401); load_weights(Dp, 8402); load_weights(Da, 8403); load_weights(A, 8404, conv_std=0.1)
+    with torch.no_grad():       # a wider output layer, so that the argmax path is not one symbol throughout
+        A.fc[0].module[1].weight.mul_(6.0)
+    out = {}
+    for nm, m in (("G", G), ("Dp", Dp), ("Da", Da), ("A", A)):
+        for k, v in m.state_dict().items():
+            out["init.%s.%s" % (nm, k)] = v.clone().numpy()
+    G.eval()
+    w_adv, w_ac = 0.01, 1.0
+    out["w_adversarial"], out["w_acoustic"] = w_adv, w_ac
+    batches = []
+    for b, (lens, lab_lens) in enumerate((([70, 64, 51], [7, 5, 6]), ([66, 40], [4, 8]))):
+        bt = make_batch(len(lens), Fdim, lens, 8500 + 100 * b, lab_lens, 8600 + 10 * b)
+        cl = make_batch(len(lens), Fdim, lens, 8700 + 100 * b)["inputs"]
+        # transcripts derived from what the models decode (the decode does not depend on them), perturbed: utterance 0 exact,
+        # utterance 1 with one character replaced, the others with their first word dropped - so WER / CER are neither 0 nor 1
+        with torch.no_grad():
+            _, _, _, _, _, _, _, dstr, _ = _ref_greedy(dec, G, A, t(bt["inputs"]), t(bt["targets"]), t(bt["pct"]), t(bt["target_sizes"]))
+        c2i = {c: i for i, c in enumerate(LABELS)}
+        tg, tl = [], []
+        for i, s_ in enumerate(dstr):
+            s_ = s_.strip() or "a"
+            if i == 1:
+                k_ = len(s_) // 2
+                s_ = s_[:k_] + ("q" if s_[k_] != "q" else "r") + s_[k_ + 1:]
+            elif i >= 2 and " " in s_:
+                s_ = s_.split(" ", 1)[1]
+            ids = [c2i[c] for c in s_]
+            tg.extend(ids); tl.append(len(ids))
+        bt["targets"], bt["target_sizes"] = np.asarray(tg, np.int32), np.asarray(tl, np.int32)
+        batches.append((bt, cl))
+        for k, v in bt.items():
+            out["b%d.%s" % (b, k)] = v
+        out["b%d.cleans" % b] = cl
+    diff = REF.L1Loss_mask()
+    m_dce, m_wer, m_cer = _Meter(), _Meter(), _Meter()
+    f_dce, f_adv, f_wer, f_cer = _Meter(), _Meter(), _Meter(), _Meter()
+    a_ctc, a_adv, a_wer, a_cer = _Meter(), _Meter(), _Meter(), _Meter()
+    with torch.no_grad():
+        for b, (bt, cl) in enumerate(batches):
+            inputs, cleans, mask = t(bt["inputs"]), t(cl), t(bt["mask"]).bool()
+            targets, pct, tsz = t(bt["targets"]), t(bt["pct"]), t(bt["target_sizes"])
+            p = "b%d." % b
+            # ---- minimize_DCE (trainer_DCE.py:137-153): DCE on G(inputs), then greedy_decoding
+            outputs = G(inputs)
+            dce, nEl = diff(outputs, cleans, mask)
+            m_dce.update(dce.item(), int(nEl))
+            enh, prob, sizes, wer, cer, nW, nC, dstr, tstr = _ref_greedy(dec, G, A, inputs, targets, pct, tsz)
+            m_wer.update(wer, nW); m_cer.update(cer, nC)
+            out[p + "dce.dce"], out[p + "dce.nElement"] = dce.item(), int(nEl)
+            out[p + "dce.wer"], out[p + "dce.cer"], out[p + "dce.nWord"], out[p + "dce.nChar"] = wer, cer, nW, nC
+            out[p + "enhanced"], out[p + "logits_tnc"], out[p + "sizes"] = enh.numpy(), prob.numpy(), sizes.numpy()
+            for i, (a_, b_) in enumerate(zip(dstr, tstr)):
+                out[p + "decoded%d" % i] = np.frombuffer(a_.encode("utf8"), np.uint8).copy()
+                out[p + "reference%d" % i] = np.frombuffer(b_.encode("utf8"), np.uint8).copy()
+            # ---- FSEGAN (trainer_FSEGAN.py:277-317)
+            enh, prob, sizes, wer, cer, nW, nC, _, _ = _ref_greedy(dec, G, A, inputs, targets, pct, tsz)
+            ae_ny = Dp.forward_paired(enh, inputs)
+            l_adv_ny, nElement = diff(ae_ny, enh, mask)
+            l_adv_ny = l_adv_ny * w_adv
+            dce2, nElement_ = diff(enh, cleans, mask)
+            assert (nElement == nElement_)
+            f_dce.update(dce2.item(), int(nElement)); f_adv.update(l_adv_ny.item(), int(nElement)); f_wer.update(wer, nW); f_cer.update(cer, nC)
+            for k, v in zip(("dce", "l_adv_ny", "nElement", "wer", "cer", "total_word", "total_char"),
+                            (dce2.item(), l_adv_ny.item(), int(nElement), wer, cer, nW, nC)):
+                out[p + "fsegan." + k] = v
+            # ---- AAS (trainer_AAS.py:301-351)
+            enh, prob, sizes, wer, cer, nW, nC, _, _ = _ref_greedy(dec, G, A, inputs, targets, pct, tsz)
+            ae_ny = Da(enh)
+            l_adv, nElement = diff(ae_ny, enh, mask)
+            l_adv = l_adv * w_adv
+            N = inputs.size(0)
+            l_ctc = w_ac * ctc_sum(prob, targets, sizes, tsz) / N
+            a_ctc.update(l_ctc.item(), N); a_adv.update(l_adv.item(), int(nElement)); a_wer.update(wer, nW); a_cer.update(cer, nC)
+            for k, v in zip(("l_CTC", "l_adv_ny", "nElement", "wer", "cer", "total_word", "total_char"),
+                            (l_ctc.item(), l_adv.item(), int(nElement), wer, cer, nW, nC)):
+                out[p + "aas." + k] = v
+    out.update({"avg.dce.dce": m_dce.avg, "avg.dce.wer": m_wer.avg, "avg.dce.cer": m_cer.avg,
+                "avg.fsegan.dce": f_dce.avg, "avg.fsegan.adv_ny": f_adv.avg, "avg.fsegan.wer": f_wer.avg, "avg.fsegan.cer": f_cer.avg,
+                "avg.aas.ctc": a_ctc.avg, "avg.aas.adv_ny": a_adv.avg, "avg.aas.wer": a_wer.avg, "avg.aas.cer": a_cer.avg})
+    np.savez_compressed(os.path.join(OUT, "f13_validation.npz"), **out)
+    print("F13", {k: v for k, v in out.items() if k.startswith("avg.")},
+          [bytes(out["b0.decoded%d" % i]).decode() for i in range(3)], [bytes(out["b0.reference%d" % i]).decode() for i in range(3)])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip F3 (config 2, minutes of CPU)")
@@ -841,11 +1084,13 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if a.only:
         table = dict(f1=f1_tiny, f2=f2_dce, f3=f3_config2, f4=f4_ops, f5=f5_fsegan_am, f6=f6_fsegan_config4,
-                     f7=f7_am_config5, f8=f8_host_side, f9=f9_rnn_kind, f10=f10_acoustic, f3b=f3b_config2_kt, f11=f11_am_model_ken, f12=f12_cli_defaults, f3c=f3c_thread_spread)
+                     f7=f7_am_config5, f8=f8_host_side, f9=f9_rnn_kind, f10=f10_acoustic, f3b=f3b_config2_kt, f11=f11_am_model_ken, f12=f12_cli_defaults, f3c=f3c_thread_spread,
+                     f1r=f1r_tiny_ragged_pair, f3r=f3r_config2_ragged_pair, f13=f13_validation)
         for k in a.only.split(","):
             table[k]()
         sys.exit(0)
     f1_tiny()
+    f1r_tiny_ragged_pair()
     f4_ops()
     f5_fsegan_am()
     f2_dce()
@@ -853,9 +1098,11 @@ if __name__ == "__main__":
     f9_rnn_kind()
     f11_am_model_ken()
     f12_cli_defaults()
+    f13_validation()
     if not a.skip_big:
         f3_config2()
         f3b_config2_kt()
+        f3r_config2_ragged_pair()
         f3c_thread_spread()
         f6_fsegan_config4()
         f7_am_config5()
