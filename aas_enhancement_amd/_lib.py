@@ -53,6 +53,7 @@ SIGNATURES = {
     "aas_split_planes_t": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
     "aas_split_planes_t2": [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp],
     "aas_transpose_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64],
+    "aas_transpose_add_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64],
     "aas_swap01_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "aas_add3_planes_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     "aas_add3_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64],
@@ -61,6 +62,9 @@ SIGNATURES = {
     "aas_leaky_relu_f32": [c_vp, c_vp, c_vp, c_vp, c_f32, c_i64],
     "aas_step_prologue": [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp],
     "aas_began_step_raw": [c_vp, c_vp, ctypes.c_double, ctypes.c_double, c_vp, c_int, ctypes.c_double, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double],
+    "aas_began_step_sums": [c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_vp],
+    "aas_loss_pack": [c_vp, c_vp, c_vp, c_int, c_vp],
+    "aas_scales_from_counts": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp],
     "aas_scale_dev_f32": [c_vp, c_vp, c_vp, c_vp, c_f32, c_i64],
     "aas_colsum_f32": [c_vp, c_vp, c_i64, c_int, c_i64, c_vp, c_int],
     "aas_sqsum_f32": [c_vp, c_vp, c_i64, c_vp],

@@ -117,49 +117,76 @@ class AMTrainer(ops.TrainerContext):
         N = inputs.size(0)
         t_out = self.model.output_length(inputs.size(2))
         sizes = input_percentages.clone().mul_(int(t_out)).int()
+        if not self.dp.active:
+            return self._device_step(inputs, targets, sizes, target_sizes, N)
         meta = self.criterion.prepare(targets, sizes, target_sizes, inputs.device)
-        if self.dp.active:
-            if getattr(self, "_aux", None) is None:
-                self._aux = ops.refresh_stream(inputs.device)
-            counts = DeviceCounts(self.dp, [N], inputs.device, self._aux)
+        if getattr(self, "_aux", None) is None:
+            self._aux = ops.refresh_stream(inputs.device)
+        counts = DeviceCounts(self.dp, [N], inputs.device, self._aux)
         ops.sync_wgrad()
         self.flat.zero_grad()
-        if self._reducer is not None:
-            self._reducer.begin()
-            ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
+        self._reducer.begin()
+        ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
         try:
             ops.set_rnn_cu_limit(_fwd_cus())
             out = self.model(inputs).transpose(0, 1)
             loss = self.criterion(out, targets, sizes, target_sizes, prepared=meta)
-            loss = loss * (1.0 / counts.get(0)).float() if self.dp.active else loss / N
+            loss = loss * (1.0 / counts.get(0)).float()
             ops.set_rnn_cu_limit(_bwd_cus())
             loss.backward()
             ops.sync_wgrad()
-            if self._reducer is not None:
-                self._reducer.flush(self.flat)
-                self._reducer.wait()
+            self._reducer.flush(self.flat)
+            self._reducer.wait()
         finally:
             ops.WGRAD_HOOK[0] = None
             ops.set_rnn_cu_limit(0)
         v = self.dp.reduce_scalars(loss.detach().reshape(1).clone())
         self.opt.step_dev()
+        return dict(loss_dev=v, handle=self._loss_to_host(v, 1.0), logits=out)
+
+    def _device_step(self, inputs, targets, sizes, target_sizes, N):
+        """The single-process step as library launches only: the CTC metadata goes up from a pinned staging ring, ONE prologue
+        launch zeroes the flat gradient buffer, the loss weight 1 / N (:319-320) rides in the CTC kernel's gradient scale (the
+        root is the vector of per-utterance costs), and the logged value is their raw sum, scaled where it is read."""
+        dev = inputs.device
+        meta = ops.ctc_prepare(targets, sizes, target_sizes, "cpu")
+        meta = dict(meta, meta=self._upload_small(meta["meta"], dev))
+        ops.sync_wgrad()
+        ops.step_prologue([self.flat.flat_g])
+        try:
+            ops.set_rnn_cu_limit(_fwd_cus())
+            out = self.model(inputs).transpose(0, 1)
+            costs = ops.ctc_scaled(out, self.criterion.blank, meta, 1.0 / N)
+            ops.set_rnn_cu_limit(_bwd_cus())
+            torch.autograd.backward([costs], [ops.unit_root(costs)])
+            ops.sync_wgrad()
+        finally:
+            ops.set_rnn_cu_limit(0)
+        self.opt.step_dev()
+        # the N per-utterance costs go to the host as they are (summed and scaled where the loss is read: no reduction launch)
+        return dict(costs_dev=costs.detach(), loss_scale=1.0 / N, handle=self._loss_to_host(costs.detach(), 1.0 / N), logits=out)
+
+    def _loss_to_host(self, v, scale):
+        """Asynchronous copy of a device loss scalar into a ring of four pinned slots -> the handle `read_loss` waits for."""
         ring = getattr(self, "_loss_ring", None)
         if ring is None:
-            ring = self._loss_ring = dict(i=0, slots=[[torch.zeros(1, dtype=torch.float32).pin_memory(), None] for _ in range(4)])
+            ring = self._loss_ring = dict(i=0, slots=[[torch.zeros(1, dtype=torch.float32).pin_memory(), None, 1.0] for _ in range(4)])
         slot = ring["slots"][ring["i"] % 4]
         ring["i"] += 1
         if slot[1] is not None:
             slot[1].synchronize()          # (the copy of four steps ago)
+        if slot[0].numel() != v.numel():
+            slot[0] = torch.zeros(v.numel(), dtype=torch.float32).pin_memory()
         slot[0].copy_(v.to(torch.float32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        slot[1] = ev
-        return dict(loss_dev=v, handle=slot, logits=out)
+        slot[1], slot[2] = ev, float(scale)
+        return slot
 
     def read_loss(self, handle):
         """-> (logged loss, is_inf) of a train_step_async; waits for that step's loss copy only."""
         handle[1].synchronize()
-        loss_value = float(handle[0][0])
+        loss_value = float(handle[0].sum(dtype=torch.float32)) * (handle[2] if len(handle) > 2 else 1.0)
         is_inf = loss_value in (float("inf"), float("-inf"))
         if not is_inf:
             ops.check_rnn_health((loss_value,))

@@ -1,5 +1,6 @@
 #include <stdarg.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -30,13 +31,39 @@ extern "C" int aas_device_cus(void) {
     return cus;
 }
 
-static int g_debug_flags = 0;
-int aas_debug_flags_value() { return g_debug_flags; }
+// ---- queue-time settings --------------------------------------------------------------------------------------------------------
+// Two levels.  (1) PROCESS settings (aas_set_precision, aas_set_debug_flags, aas_set_rnn_cu_limit, aas_set_rnn_launch_tag,
+// aas_set_gemm_max_steps, aas_set_wgrad_wg_cap): atomics, read when a launch is queued - fine for a single-threaded host.
+// (2) A LAUNCH SCOPE (aasLaunch, include/aas_hip.h): a caller-owned struct installed for the calling THREAD (aas_launch_scope) or
+// passed to one call (the *_ex entry points); every field that is set in it overrides the process setting for the launches this
+// thread queues while it is installed.  Nothing one thread sets through a scope is visible to another thread's launches.
+static thread_local aasLaunch* t_scope = nullptr;
+static std::atomic<int> g_debug_flags{0};
+int aas_debug_flags_value() { return (t_scope && t_scope->debug_flags >= 0) ? t_scope->debug_flags : g_debug_flags.load(std::memory_order_relaxed); }
 extern "C" int aas_set_debug_flags(int flags) {
-    g_debug_flags = flags;
+    g_debug_flags.store(flags, std::memory_order_relaxed);
     return 0;
 }
-extern "C" int aas_get_debug_flags(void) { return g_debug_flags; }
+extern "C" int aas_get_debug_flags(void) { return aas_debug_flags_value(); }
+extern "C" int aas_launch_scope(aasLaunch* l, aasLaunch** prev) {
+    if (l != nullptr && l->size != (int)sizeof(aasLaunch)) {
+        aas_set_error("aas_launch_scope: aasLaunch.size = %d, this library's is %d", l->size, (int)sizeof(aasLaunch));
+        return 1;
+    }
+    if (prev) *prev = t_scope;
+    t_scope = l;
+    return 0;
+}
+AasScopeGuard::AasScopeGuard(aasLaunch* l) : prev_(t_scope), on_(l != nullptr) { if (on_) t_scope = l; }
+AasScopeGuard::~AasScopeGuard() { if (on_) t_scope = prev_; }
+int aas_scope_check(const aasLaunch* l, const char* who) {
+    if (l != nullptr && l->size != (int)sizeof(aasLaunch)) {
+        aas_set_error("%s: aasLaunch.size = %d, this library's is %d", who, l->size, (int)sizeof(aasLaunch));
+        return 1;
+    }
+    return 0;
+}
+int aas_scope_gemm_max_steps() { return (t_scope && t_scope->gemm_max_steps >= 0) ? t_scope->gemm_max_steps : -1; }
 
 namespace {
 struct WsKey {
@@ -158,14 +185,19 @@ extern "C" int aas_rnn_xchg_is_managed(void* xchg) {
     return g_xchg.count(xchg) ? 1 : 0;
 }
 
-bool aas_first_use_on_device(unsigned char* flags) {
+int aas_raise_dynamic_lds_once(unsigned char* flags, const void* kernel, int bytes) {
     static std::mutex mu;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= AAS_MAX_DEV) return true;   // (unknown device: set the attribute every time)
-    std::lock_guard<std::mutex> lk(mu);
-    if (flags[dev]) return false;
-    flags[dev] = 1;
-    return true;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < AAS_MAX_DEV;   // (unknown device: set the attribute every time)
+    std::lock_guard<std::mutex> lk(mu);       // held across the attribute call: a second thread launches only after the limit is raised
+    if (known && flags[dev]) return 0;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        aas_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", bytes, hipGetErrorString(e));
+        return 2;                             // (not marked done: the next launch tries again)
+    }
+    if (known) flags[dev] = 1;
+    return 0;
 }
 
 const char* aas_ablation_env(const char* name) {
@@ -174,64 +206,91 @@ const char* aas_ablation_env(const char* name) {
 }
 
 // 0 (default) = fp32-input MFMA everywhere, the reference's arithmetic; 1 = split-bf16 (hi/lo, 3 MFMAs) fast mode
-static int g_precision = 0;
-int aas_precision_value() { return g_precision; }
+static std::atomic<int> g_precision{0};
+int aas_precision_value() { return (t_scope && t_scope->precision >= 0) ? t_scope->precision : g_precision.load(std::memory_order_relaxed); }
 extern "C" int aas_set_precision(int mode) {
     if (mode < 0 || mode > 2) {
         aas_set_error("aas_set_precision: mode must be 0 (fp32), 1 (split-bf16) or 2 (fp32-equivalent: fp32 recurrent products, six-product plane GEMMs)");
         return 1;
     }
-    g_precision = mode;
+    g_precision.store(mode, std::memory_order_relaxed);
     return 0;
 }
 
 // Upper bound on the CUs one persistent recurrent launch may occupy (0 = the whole device).  Two independent chains of
 // recurrent launches on two streams (discriminator and acoustic branch of the AAS step) each take half the chip.
-static int g_rnn_cu_limit = 0;
+static std::atomic<int> g_rnn_cu_limit{0};
 int aas_rnn_cus() {
     const int cus = aas_device_cus();
-    return (g_rnn_cu_limit > 0 && g_rnn_cu_limit < cus) ? g_rnn_cu_limit : cus;
+    const int lim = (t_scope && t_scope->rnn_cu_limit >= 0) ? t_scope->rnn_cu_limit : g_rnn_cu_limit.load(std::memory_order_relaxed);
+    return (lim > 0 && lim < cus) ? lim : cus;
 }
 extern "C" int aas_set_rnn_cu_limit(int cus) {
     if (cus < 0) {
         aas_set_error("aas_set_rnn_cu_limit: negative limit");
         return 1;
     }
-    g_rnn_cu_limit = cus;
+    g_rnn_cu_limit.store(cus, std::memory_order_relaxed);
     return 0;
 }
 
 // Identifies the persistent recurrent launches queued after the call: a launch that hits its bounded-spin timeout
 // stores this value (>= 1) in the sticky error word of its sync buffer, so the host can name the layer.
-static int g_rnn_tag = 1;
-int aas_rnn_launch_tag_value() { return g_rnn_tag; }
-static int g_wgrad_cap = 0;
-int aas_wgrad_wg_cap() { return g_wgrad_cap; }
-extern "C" int aas_set_wgrad_wg_cap(int workgroups) { g_wgrad_cap = workgroups < 0 ? 0 : workgroups; return 0; }
-static int g_fwd_h_pitch = 0;
-void aas_note_fwd_h_planes(int pitch_bytes) { g_fwd_h_pitch = pitch_bytes; }
-extern "C" int aas_rnn_last_fwd_h_pitch(void) { return g_fwd_h_pitch; }
-// Row classes of the NEXT forward recurrent launch (aas_lstm_fwd / aas_gru_fwd), consumed by it: batch rows [0, n_first) carry
-// sequences of T_first frames, rows [n_first, N) of T_rest frames, inside a launch of T = max of the two.  What the batched
+static std::atomic<int> g_rnn_tag{1};
+int aas_rnn_launch_tag_value() { return (t_scope && t_scope->rnn_tag >= 1) ? t_scope->rnn_tag : g_rnn_tag.load(std::memory_order_relaxed); }
+static std::atomic<int> g_wgrad_cap{0};
+int aas_wgrad_wg_cap() { return (t_scope && t_scope->wgrad_wg_cap >= 0) ? t_scope->wgrad_wg_cap : g_wgrad_cap.load(std::memory_order_relaxed); }
+extern "C" int aas_set_wgrad_wg_cap(int workgroups) { g_wgrad_cap.store(workgroups < 0 ? 0 : workgroups, std::memory_order_relaxed); return 0; }
+// What the last forward recurrent launch OF THIS THREAD left in its exchange buffer (per thread: the launch and the query that follows
+// it come from the same host thread); with a launch scope installed the value goes into the scope's fwd_h_pitch as well.
+static thread_local int t_fwd_h_pitch = 0;
+void aas_note_fwd_h_planes(int pitch_bytes) {
+    t_fwd_h_pitch = pitch_bytes;
+    if (t_scope) t_scope->fwd_h_pitch = pitch_bytes;
+}
+extern "C" int aas_rnn_last_fwd_h_pitch(void) { return t_fwd_h_pitch; }
+// Row classes of the NEXT forward recurrent launch of THIS THREAD (aas_lstm_fwd / aas_gru_fwd), consumed by it: batch rows [0, n_first)
+// carry sequences of T_first frames, rows [n_first, N) of T_rest frames, inside a launch of T = max of the two.  What the batched
 // discriminator pass over a noisy / clean pair of different padded lengths needs: the shorter class behaves exactly as in a launch
-// of its own (zero state before its first frame in either direction, zero output and no gradient beyond its last).
-static int g_cls_set = 0, g_cls_n = 0, g_cls_t0 = 0, g_cls_t1 = 0;
+// of its own (zero state before its first frame in either direction, zero output and no gradient beyond its last).  Per thread
+// (a launch queued by another host thread cannot consume them); a launch scope / the *_ex entry points carry them as fields instead.
+static thread_local int t_cls_set = 0, t_cls_n = 0, t_cls_t0 = 0, t_cls_t1 = 0;
 extern "C" int aas_set_rnn_row_classes(int n_first, int T_first, int T_rest) {
     if (n_first < 0 || T_first < 1 || T_rest < 1) {
         aas_set_error("aas_set_rnn_row_classes: n_first=%d T_first=%d T_rest=%d", n_first, T_first, T_rest);
         return 1;
     }
-    g_cls_set = 1; g_cls_n = n_first; g_cls_t0 = T_first; g_cls_t1 = T_rest;
+    t_cls_set = 1; t_cls_n = n_first; t_cls_t0 = T_first; t_cls_t1 = T_rest;
     return 0;
 }
 int aas_rnn_row_classes_take(const char* who, int T, int N, int* n, int* t0, int* t1) {
-    if (!g_cls_set) { *n = N; *t0 = T; *t1 = T; return 0; }
-    g_cls_set = 0;
-    if (g_cls_n > N || g_cls_t0 > T || g_cls_t1 > T || (g_cls_t0 != T && g_cls_t1 != T)) {
-        aas_set_error("%s: row classes (%d rows x %d frames, the rest x %d) do not fit a launch of N=%d T=%d", who, g_cls_n, g_cls_t0, g_cls_t1, N, T);
+    int cn, c0, c1;
+    if (t_scope && t_scope->cls_n_first >= 0) {          // the scope's classes win; they are consumed like the one-shot setting
+        cn = t_scope->cls_n_first; c0 = t_scope->cls_T_first; c1 = t_scope->cls_T_rest;
+        t_scope->cls_n_first = -1;
+        t_cls_set = 0;
+    } else if (t_cls_set) {
+        cn = t_cls_n; c0 = t_cls_t0; c1 = t_cls_t1;
+        t_cls_set = 0;
+    } else {
+        *n = N; *t0 = T; *t1 = T;
+        return 0;
+    }
+    if (cn > N || c0 < 1 || c1 < 1 || c0 > T || c1 > T || (c0 != T && c1 != T)) {
+        aas_set_error("%s: row classes (%d rows x %d frames, the rest x %d) do not fit a launch of N=%d T=%d", who, cn, c0, c1, N, T);
         return 1;
     }
-    *n = g_cls_n; *t0 = g_cls_t0; *t1 = g_cls_t1;
+    *n = cn; *t0 = c0; *t1 = c1;
+    return 0;
+}
+int aas_rnn_row_classes_reject(const char* who) {
+    const bool pending = t_cls_set || (t_scope && t_scope->cls_n_first >= 0);
+    t_cls_set = 0;
+    if (t_scope) t_scope->cls_n_first = -1;
+    if (pending) {
+        aas_set_error("%s: row classes are pending for this launch, which does not support them (lstm / gru forward launches only)", who);
+        return 1;
+    }
     return 0;
 }
 extern "C" int aas_set_rnn_launch_tag(int tag) {
@@ -239,6 +298,6 @@ extern "C" int aas_set_rnn_launch_tag(int tag) {
         aas_set_error("aas_set_rnn_launch_tag: tag must be >= 1");
         return 1;
     }
-    g_rnn_tag = tag;
+    g_rnn_tag.store(tag, std::memory_order_relaxed);
     return 0;
 }

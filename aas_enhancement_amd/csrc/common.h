@@ -23,7 +23,23 @@ int aas_rnn_row_classes_take(const char* who, int T, int N, int* n, int* t0, int
 // Per-device "done once" flags (function attributes such as the raised dynamic-LDS limit belong to a device): true exactly once per
 // device for a given flag array, thread-safe.  flags: a static unsigned char[AAS_MAX_DEV] of the call site.
 constexpr int AAS_MAX_DEV = 64;
-bool aas_first_use_on_device(unsigned char* flags);
+// Raise a kernel's dynamic-LDS limit once per device: the flag is set only AFTER hipFuncSetAttribute succeeded and the call holds a
+// mutex across it, so a failed call is retried by the next launch and no second thread launches before the limit is raised.
+// -> 0 ok (done now or earlier), 2 the attribute call failed (aas_last_error says why).
+int aas_raise_dynamic_lds_once(unsigned char* flags, const void* kernel, int bytes);
+int aas_rnn_row_classes_reject(const char* who);   // launches that cannot take row classes: consume + refuse a pending setting
+// RAII: install an aasLaunch scope for this thread for the duration of one call (the *_ex entry points); nullptr = leave as is
+struct AasScopeGuard {
+    explicit AasScopeGuard(aasLaunch* l);
+    ~AasScopeGuard();
+    AasScopeGuard(const AasScopeGuard&) = delete;
+    AasScopeGuard& operator=(const AasScopeGuard&) = delete;
+  private:
+    aasLaunch* prev_;
+    bool on_;
+};
+int aas_scope_check(const aasLaunch* l, const char* who);
+int aas_scope_gemm_max_steps();   // >= 0: the installed scope's lifetime cap of GEMM workgroups; -1: none installed / not set
 int aas_rnn_launch_tag_value();  // >= 1: what a timed-out persistent launch leaves in its sticky error word
 // gemm32.hip: the LDS-DMA fp32 GEMM; -> 0 launched, 1 error, -1 not applicable to these operands (take the general kernel)
 int aas_gemm32_try(hipStream_t s, int mode, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,

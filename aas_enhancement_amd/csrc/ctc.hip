@@ -263,8 +263,7 @@ extern "C" int aas_ctc_loss_async(aasStream_t stream, const float* activations, 
     const size_t wlds = (size_t)max_T * (64 * sizeof(double) + alphabet * sizeof(float) + sizeof(int)) + alphabet * sizeof(float);
     if (smax <= 64 && alphabet <= 64 && wlds <= 150 * 1024 && !(aas_debug_flags_value() & 16384)) {
         static unsigned char attr_done[AAS_MAX_DEV];
-        if (aas_first_use_on_device(attr_done))
-            AAS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        if (aas_raise_dynamic_lds_once(attr_done, reinterpret_cast<const void*>(&ctc_wave_kernel), 150 * 1024)) return 2;
         hipLaunchKernelGGL(ctc_wave_kernel, dim3(minibatch), dim3(64), wlds, (hipStream_t)stream, activations, gradients, d_labels,
                            d_label_offsets, d_label_lens, d_act_lens, alphabet, minibatch, max_T, costs, blank, grad_scale);
         AAS_LAUNCH_CHECK("aas_ctc_loss_async");

@@ -7,6 +7,7 @@ namespace {
 constexpr int MAXB = 2048;
 
 // ---- tiled transpose: out[b, c, r] = in[b, r, c] ------------------------------------------------
+template <bool ACC>
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         int R, int C, int64_t isb, int64_t isr, int64_t osb,
                                                         int64_t osc) {
@@ -25,7 +26,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         int c = c0 + ty + i * 4, r = r0 + tx;
-        if (r < R && c < C) op[(int64_t)c * osc + r] = tile[tx][ty + i * 4];
+        if (r < R && c < C) {
+            if (ACC) op[(int64_t)c * osc + r] += tile[tx][ty + i * 4];
+            else op[(int64_t)c * osc + r] = tile[tx][ty + i * 4];
+        }
     }
 }
 
@@ -214,8 +218,18 @@ extern "C" int aas_transpose_f32(aasStream_t stream, const float* in, float* out
     AAS_CHECK(in && out && B > 0 && R > 0 && C > 0, "aas_transpose_f32: bad args");
     AAS_CHECK(B <= 65535 && cdiv(R, 64) <= 65535, "aas_transpose_f32: grid too large");
     dim3 grid(cdiv(C, 64), cdiv(R, 64), B);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, R, C, isb, isr, osb, osc);
+    hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, out, R, C, isb, isr, osb, osc);
     AAS_LAUNCH_CHECK("aas_transpose_f32");
+    return 0;
+}
+
+extern "C" int aas_transpose_add_f32(aasStream_t stream, const float* in, float* out, int B, int R, int C, int64_t isb,
+                                     int64_t isr, int64_t osb, int64_t osc) {
+    AAS_CHECK(in && out && B > 0 && R > 0 && C > 0, "aas_transpose_add_f32: bad args");
+    AAS_CHECK(B <= 65535 && cdiv(R, 64) <= 65535, "aas_transpose_add_f32: grid too large");
+    dim3 grid(cdiv(C, 64), cdiv(R, 64), B);
+    hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, out, R, C, isb, isr, osb, osc);
+    AAS_LAUNCH_CHECK("aas_transpose_add_f32");
     return 0;
 }
 
@@ -415,6 +429,36 @@ __global__ void began_step_raw_kernel(const double* __restrict__ l1_sums, double
     out[4] += c * n_batch;
     out[5] += n_batch;
 }
+// The controller from THREE raw device sums - sums[0..1] and third[0] - (FSEGAN: the third logged loss is the DCE sum, not CTC costs; data parallel: the sums are
+// all-reduced first and the normalisers are device scalars): L_i = s_i * (d_scales ? d_scales[i] : 1) * sums[i]
+__global__ void began_step_sums_kernel(const double* __restrict__ sums, const double* __restrict__ third, double s0, double s1, double s2,
+                                       const float* __restrict__ d_scales,
+                                       double* __restrict__ kt, double* __restrict__ out, double gamma, double lambda_k, double n_batch,
+                                       const double* __restrict__ d_n_batch) {
+    const double f0 = d_scales ? (double)d_scales[0] : 1.0, f1 = d_scales ? (double)d_scales[1] : 1.0, f2 = d_scales ? (double)d_scales[2] : 1.0;
+    const double a = (double)(float)(sums[0] * s0 * f0), b = (double)(float)(sums[1] * s1 * f1), c = (double)(float)(third[0] * s2 * f2);
+    double k = kt[0] + lambda_k * (gamma * b - a);
+    k = k < 0.0 ? 0.0 : (k > 1.0 ? 1.0 : k);
+    kt[0] = k;
+    const double nb = d_n_batch ? d_n_batch[0] : n_batch;
+    out[0] = a; out[1] = b; out[2] = c; out[3] = k;
+    out[4] += c * nb;
+    out[5] += nb;
+}
+// [sum|D(E(x)) - E(x)|, sum|D(c) - c|, sum of the per-utterance CTC costs] as three doubles: what a data-parallel step all-reduces
+__global__ void loss_pack_kernel(const double* __restrict__ l1_sums, const float* __restrict__ costs, int n_costs, double* __restrict__ out3) {
+    float cs = 0.f;                                   // (fp32 running sum in utterance order, as began_step_raw_kernel)
+    for (int i = 0; i < n_costs; ++i) cs += costs[i];
+    out3[0] = l1_sums[0];
+    out3[1] = l1_sums[1];
+    out3[2] = (double)cs;
+}
+__global__ void scales_from_counts_kernel(const double* __restrict__ counts, int n, double w0, double w1, double w2, double w3, int i0, int i1,
+                                          int i2, int i3, float* __restrict__ out) {
+    const double w[4] = {w0, w1, w2, w3};
+    const int idx[4] = {i0, i1, i2, i3};
+    for (int i = 0; i < n; ++i) out[i] = (float)(w[i] / counts[idx[i]]);
+}
 }  // namespace
 
 extern "C" int aas_step_prologue(aasStream_t stream, int n, void* const* bufs, const size_t* bytes, float* rs, int n_neg, int n_one,
@@ -446,6 +490,38 @@ extern "C" int aas_began_step_raw(aasStream_t stream, const double* d_l1_sums, d
     hipLaunchKernelGGL(began_step_raw_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_l1_sums, scale_ny, scale_cl, d_ctc_costs, n_costs,
                        scale_ctc, d_kt, d_out6, gamma, lambda_k, n_batch);
     AAS_LAUNCH_CHECK("aas_began_step_raw");
+    return 0;
+}
+
+extern "C" int aas_began_step_sums(aasStream_t stream, const double* d_l1_sums, const double* d_third, double s0, double s1, double s2,
+                                   const float* d_scales3, double* d_kt, double* d_out6, double gamma, double lambda_k, double n_batch,
+                                   const double* d_n_batch) {
+    AAS_CHECK(d_l1_sums && d_third && d_kt && d_out6, "aas_began_step_sums: null pointer");
+    hipLaunchKernelGGL(began_step_sums_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_l1_sums, d_third, s0, s1, s2, d_scales3, d_kt, d_out6, gamma, lambda_k,
+                       n_batch, d_n_batch);
+    AAS_LAUNCH_CHECK("aas_began_step_sums");
+    return 0;
+}
+
+extern "C" int aas_loss_pack(aasStream_t stream, const double* d_l1_sums, const float* d_ctc_costs, int n_costs, double* d_out3) {
+    AAS_CHECK(d_l1_sums && d_out3 && n_costs >= 0 && (n_costs == 0 || d_ctc_costs), "aas_loss_pack: null pointer");
+    hipLaunchKernelGGL(loss_pack_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_l1_sums, d_ctc_costs, n_costs, d_out3);
+    AAS_LAUNCH_CHECK("aas_loss_pack");
+    return 0;
+}
+
+extern "C" int aas_scales_from_counts(aasStream_t stream, const double* d_counts, int n, const double* weights, const int* index, float* d_out) {
+    AAS_CHECK(d_counts && weights && index && d_out && n >= 1 && n <= 4, "aas_scales_from_counts: 1..4 scales");
+    double w[4] = {0, 0, 0, 0};
+    int ix[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        AAS_CHECK(index[i] >= 0, "aas_scales_from_counts: negative index");
+        w[i] = weights[i];
+        ix[i] = index[i];
+    }
+    hipLaunchKernelGGL(scales_from_counts_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_counts, n, w[0], w[1], w[2], w[3], ix[0], ix[1], ix[2],
+                       ix[3], d_out);
+    AAS_LAUNCH_CHECK("aas_scales_from_counts");
     return 0;
 }
 

@@ -459,6 +459,8 @@ extern "C" int aas_set_gemm_variant(int v) {
 }
 
 int aas_gemm_max_steps_value() {
+    const int scoped = aas_scope_gemm_max_steps();      // a launch scope installed for this thread (aasLaunch.gemm_max_steps)
+    if (scoped >= 0) return scoped;
     if (g_max_steps < 0) g_max_steps = aas_ablation_env("AAS_GEMM32_MAXSTEPS") ? atoi(aas_ablation_env("AAS_GEMM32_MAXSTEPS")) : 0;
     return g_max_steps;
 }

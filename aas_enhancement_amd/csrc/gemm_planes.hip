@@ -240,9 +240,7 @@ int launch_planes(PG p, dim3 grid, hipStream_t s) {
         grid = dim3(8 * p.per);
     }
     static unsigned char attr_done[AAS_MAX_DEV];
-    if (aas_first_use_on_device(attr_done) &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_kernel<BM, BN, WM, WN, SWAP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-        return -1;
+    if (aas_raise_dynamic_lds_once(attr_done, reinterpret_cast<const void*>(&gemm_planes_kernel<BM, BN, WM, WN, SWAP>), LDS)) return -1;
     hipLaunchKernelGGL((gemm_planes_kernel<BM, BN, WM, WN, SWAP>), grid, dim3(64 * WM * WN), LDS, s, p);
     return 0;
 }

@@ -305,9 +305,7 @@ int launch_tn(PTN& p, const int* h_M, const int* h_N, int count, hipStream_t s) 
     p.per = (tiles * ksplit + 7) / 8;
     constexpr int LDS = 2 * 32 * (BMC + BNC) * 4;
     static unsigned char attr_done[AAS_MAX_DEV];
-    if (aas_first_use_on_device(attr_done) &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_tn_kernel<BMC, BNC, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-        return -1;
+    if (aas_raise_dynamic_lds_once(attr_done, reinterpret_cast<const void*>(&gemm_planes_tn_kernel<BMC, BNC, WM, WN>), LDS)) return -1;
     int grid = 8 * p.per;
     const int cap = aas_wgrad_wg_cap();     // > 0: at most this many workgroups (a multiple of 8), each walking several tiles
     if (cap > 0 && grid > cap) grid = cap < 8 ? 8 : cap / 8 * 8;

@@ -279,8 +279,7 @@ extern "C" int aas_lmfb320_fwd(aasStream_t stream, const float* wave, const int*
     p.mel_w = mel_w; p.out = out; p.N = N; p.S = S; p.T = 1 + S / HOP; p.n_mels = n_mels; p.tiles_per_utt = cdiv(p.T, TF);
     const size_t lds = 2 * (size_t)TF * A_STRIDE + sizeof(float) * (NSAMP + TF * P_STRIDE + WIN + (size_t)n_mels * MAXW) + sizeof(int) * 2 * n_mels;
     static unsigned char attr_done[AAS_MAX_DEV];
-    if (aas_first_use_on_device(attr_done))
-        AAS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lmfb320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    if (aas_raise_dynamic_lds_once(attr_done, reinterpret_cast<const void*>(&lmfb320_kernel), 96 * 1024)) return 2;
     AAS_CHECK(lds <= 96 * 1024, "aas_lmfb320_fwd: LDS budget exceeded");
     const int total = N * p.tiles_per_utt;
     const int cus = aas_device_cus();

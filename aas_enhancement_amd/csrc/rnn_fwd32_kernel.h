@@ -375,6 +375,8 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
     const int Hp = p.P * 32;
     const int ks = cdiv(Hp, 256);
     if (ks > 4) return -1;
+    // (coverage is decided BEFORE the exchange buffer is planned: a plan commits the buffer's bookkeeping for a launch that follows)
+    if (LSTM && ks > 2) return -1;      // 128 gate columns x more than 512 k do not fit the register file
     const int64_t xbytes = (int64_t)2 * p.T * p.N * (Hp / 32) * 128;
     if (xbytes >= 0x7fffffffLL) return -1;
     int rpg = 16;
@@ -414,7 +416,7 @@ int run_fwd32(const char* name, RnnP p, hipStream_t s) {
                 if (EX && rpg <= 8 && !(p.flags & 268435456)) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0, EX, EX ? 2 : 0>), grid, block, 0, s, p);
                 else hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0, EX>), grid, block, 0, s, p);
             }
-            else return -1;   // 128 gate columns x more than 512 k do not fit the register file
+            else return -1;   // (not reached: refused above, before the exchange buffer was planned)
         } else {
             if (ks == 1) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 1, 0, EX>), grid, block, 0, s, p);
             else if (ks == 2) hipLaunchKernelGGL((rnn_fwd32_kernel<MODE, 2, 0, EX>), grid, block, 0, s, p);

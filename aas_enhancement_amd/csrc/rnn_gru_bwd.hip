@@ -19,3 +19,10 @@ extern "C" int aas_gru_bwd_planes(aasStream_t stream, int T, int N, int H, const
     p.sync = (unsigned*)sync; p.xchg = (unsigned*)xchg;
     return run_bwd_any<GRU_BWD>("aas_gru_bwd_planes", p, (hipStream_t)stream);
 }
+
+extern "C" int aas_gru_bwd_ex(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
+                              const float* hout, const float* gact, float* dgx, float* dgh, void* sync, void* xchg, aasLaunch* launch) {
+    if (aas_scope_check(launch, "aas_gru_bwd_ex")) return 1;
+    AasScopeGuard guard(launch);
+    return aas_gru_bwd(stream, T, N, H, dy, w_hh, w_hh_rev, hout, gact, dgx, dgh, sync, xchg);
+}

@@ -11,3 +11,9 @@ extern "C" int aas_gru_fwd(aasStream_t stream, int T, int N, int H, const float*
     return run_fwd_any<GRU_FWD>("aas_gru_fwd", p, (hipStream_t)stream);
 }
 
+extern "C" int aas_gru_fwd_ex(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh, const float* w_hh_rev, float* hout,
+                              float* gact, void* sync, void* xchg, aasLaunch* launch) {
+    if (aas_scope_check(launch, "aas_gru_fwd_ex")) return 1;
+    AasScopeGuard guard(launch);
+    return aas_gru_fwd(stream, T, N, H, pre, w_hh, w_hh_rev, hout, gact, sync, xchg);
+}

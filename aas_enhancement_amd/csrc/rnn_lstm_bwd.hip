@@ -31,3 +31,10 @@ extern "C" int aas_lstm_bwd_planes(aasStream_t stream, int T, int N, int H, cons
     p.sync = (unsigned*)sync; p.xchg = (unsigned*)xchg;
     return run_bwd_any<LSTM_BWD>("aas_lstm_bwd_planes", p, (hipStream_t)stream);
 }
+
+extern "C" int aas_lstm_bwd_ex(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
+                               const float* gact, const float* cst, float* dgates, void* sync, void* xchg, aasLaunch* launch) {
+    if (aas_scope_check(launch, "aas_lstm_bwd_ex")) return 1;
+    AasScopeGuard guard(launch);
+    return aas_lstm_bwd(stream, T, N, H, dy, w_hh, w_hh_rev, gact, cst, dgates, sync, xchg);
+}

@@ -21,3 +21,12 @@ extern "C" int aas_lstm_fwd(aasStream_t stream, int T, int N, int H, const float
     return run_fwd_any<LSTM_FWD>("aas_lstm_fwd", p, (hipStream_t)stream);
 }
 
+// The same launch with its parameters as an ARGUMENT (include/aas_hip.h: aasLaunch): row classes, CU budget, launch tag, kernel-
+// selection bits and arithmetic mode come from *launch for this call only; launch->fwd_h_pitch receives what aas_rnn_last_fwd_h_pitch()
+// would report.  Nothing process-wide is read for a field that is set, nothing process-wide is written.
+extern "C" int aas_lstm_fwd_ex(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh, const float* w_hh_rev, float* hout,
+                               float* gact, float* cst, void* sync, void* xchg, aasLaunch* launch) {
+    if (aas_scope_check(launch, "aas_lstm_fwd_ex")) return 1;
+    AasScopeGuard guard(launch);
+    return aas_lstm_fwd(stream, T, N, H, pre, w_hh, w_hh_rev, hout, gact, cst, sync, xchg);
+}

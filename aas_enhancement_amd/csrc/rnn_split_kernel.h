@@ -701,6 +701,18 @@ int launch_split_mt(const RnnP& p, int ks_need, hipStream_t s) {
     }
 }
 
+// Which (MODE, EX, row tiles, k slices) launch_split_mt has a kernel for - asked BEFORE anything is planned or poisoned for the launch.
+template <int MODE, bool EX>
+constexpr bool split_covers(int mt, int ks_need) {
+    constexpr bool FWD = (MODE == LSTM_FWD || MODE == GRU_FWD);
+    if (ks_need <= 4) return true;
+    if (MODE == LSTM_FWD) return false;
+    if (ks_need <= 8) return true;
+    if (FWD || EX) return false;
+    if (ks_need <= 16) return true;
+    return mt == 1 && ks_need <= 24;
+}
+
 // Same chunking of the batch as run() in rnn_kernel.h; falls back to the counter-based fp32 kernel (returns -1)
 // when the shape is outside the instantiated kernels.  EX: exact-fp32 products (forward modes only).
 template <int MODE, bool EX = false>
@@ -723,6 +735,9 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
     if (xbytes >= 0x7fffffffLL) return -1;
     int mt, rpg;
     pick_groups(p.P, p.N, cus, mt, rpg);
+    // no kernel of this family for the shape: say so before the exchange buffer's bookkeeping is committed to a launch (aas_xchg_plan)
+    // or the buffer is poisoned for one - the caller runs another kernel on the whole buffer
+    if (!split_covers<MODE, EX>(mt, ks_need)) return -1;
     p.rpg = rpg;
     const int qmax = cus / (p.P * 2) < 1 ? 1 : cus / (p.P * 2);
     if (FWD) aas_note_fwd_h_planes((!EX && p.N <= qmax * rpg) ? ((kxp + 31) / 32) * 128 : 0);   // (chunked launches re-poison the buffer)
@@ -746,8 +761,9 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
         int rc = (mt == 1) ? launch_split_mt<MODE, 1, EX>(p, ks_need, s) : launch_split_mt<MODE, 2, EX>(p, ks_need, s);
         p.xchg = xchg0;
         if (rc != 0) {
-            // (no kernel of this family covers the shape: the caller runs another one on the whole buffer.  A managed half that was
-            //  planned but not used stays poisoned: nothing was written.)
+            // (not reached: split_covers() refused the shape above.  Should a kernel table and split_covers ever disagree, the
+            //  buffer's management is dropped so that the next launch poisons it afresh instead of trusting stale bookkeeping.)
+            if (plan.managed) aas_rnn_xchg_forget(xchg0);
             return -1;
         }
         AAS_LAUNCH_CHECK(name);

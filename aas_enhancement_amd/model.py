@@ -167,18 +167,20 @@ class stackedBRNN(nn.Module):
         self.first_linear = _PointwiseConv(I, H)
         self.final_linear = _PointwiseConv(H, O)
 
-    def _trunk(self, input, rs=None):
-        h = ops.layout(input, "nct_tnc")                                  # [N,I,T] -> [T,N,I]
+    def _trunk(self, input, rs=None, tnc=None):
+        h = tnc if tnc is not None else ops.layout(input, "nct_tnc")      # [N,I,T] -> [T,N,I]
         h = ops.linear_rows(h, self.first_linear.weight, self.first_linear.bias, rs)
         for l in range(1, self.L + 1):
             h = getattr(self, "rnn%d" % l)(h, residual=True, wgrad_row_scale=rs)   # BRNN(h) + h
         return h
 
-    def forward(self, input, wgrad_row_scale=None):
+    def forward(self, input, wgrad_row_scale=None, tnc=None):
         """`wgrad_row_scale` [N] (extension, default None = reference behaviour): per-utterance weights applied to
         the PARAMETER gradients only (input gradients are unaffected) - lets D(enhanced) and D(clean) share one
-        batched pass while the enhanced half's parameter gradients carry the BEGAN factor (-kt)."""
-        h = self._trunk(input, wgrad_row_scale)
+        batched pass while the enhanced half's parameter gradients carry the BEGAN factor (-kt).
+        `tnc` (extension): the input already laid down time-major [T, N, I] (`input` is then ignored) - a caller that
+        assembles a batch from several tensors writes it in that layout directly (ops.layout_paired_cat)."""
+        h = self._trunk(input, wgrad_row_scale, tnc)
         out = ops.linear_rows(h, self.final_linear.weight, self.final_linear.bias, wgrad_row_scale)
         return ops.layout(out, "tnc_nct")                                 # [T,N,O] -> [N,O,T]
 

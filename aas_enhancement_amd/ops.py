@@ -243,6 +243,29 @@ class TrainerContext(object):
                     refresh_weight_planes(net)
 
 
+    def _upload_small(self, host, dev):
+        """Asynchronous H2D copy of a small host tensor through a ring of REUSED pinned staging buffers (a fresh
+        pin_memory() per step costs a pinned allocation, and the copy from pageable memory would block the host)."""
+        ring = getattr(self, "_pin_ring", None)
+        if ring is None:
+            ring = self._pin_ring = dict(i=0, slots=[None] * 8)
+        k = ring["i"] % len(ring["slots"])
+        ring["i"] += 1
+        slot = ring["slots"][k]
+        n = host.numel()
+        if slot is None or slot[0].numel() < n or slot[0].dtype != host.dtype:
+            slot = [torch.empty(max(256, 2 * n), dtype=host.dtype).pin_memory(), None]
+            ring["slots"][k] = slot
+        elif slot[1] is not None:
+            slot[1].synchronize()        # the copy that last used this staging buffer (8 uploads ago) has long finished
+        slot[0][:n].copy_(host.reshape(-1))
+        out = slot[0][:n].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        slot[1] = ev
+        return out
+
+
 def set_rnn_cu_limit(cus):
     """Cap the CUs of every persistent recurrent launch queued from now on (0 = whole device)."""
     check(lib().aas_set_rnn_cu_limit(int(cus)), "aas_set_rnn_cu_limit")
@@ -776,6 +799,39 @@ class _LayoutCatNCT(torch.autograd.Function):
 
 def layout_cat_nct_tnc(a, b):
     return _LayoutCatNCT.apply(a, b)
+
+
+class _LayoutPairedCat(torch.autograd.Function):
+    """The FSEGAN discriminator's batched input in one step: rows [0, N) = (leaf | mixture), rows [N, 2N) = (cleans | mixture) -
+    `forward_paired` (model.py:233-238: cat along the feature axis) for both halves of the batch - laid down time-major
+    [T, 2N, 2F] by four transposing launches, without the three concatenated copies and the transpose of the result.  Only
+    `leaf` receives a gradient."""
+
+    @staticmethod
+    def forward(ctx, leaf, mixture, cleans):
+        require_cuda(leaf, mixture, cleans)
+        leaf, mixture, cleans = _c(leaf), _c(mixture), _c(cleans)
+        N, F, T = leaf.shape
+        assert tuple(mixture.shape) == (N, F, T) and tuple(cleans.shape) == (N, F, T)
+        out = torch.empty((T, 2 * N, 2 * F), device=leaf.device, dtype=torch.float32)
+        base = out.data_ptr()
+        for src, n0, c0 in ((leaf, 0, 0), (mixture, 0, F), (cleans, N, 0), (mixture, N, F)):
+            check(lib().aas_transpose_f32(stream(), ptr(src), base + 4 * (n0 * 2 * F + c0), N, F, T, F * T, T, 2 * F, 2 * N * 2 * F), "aas_transpose_f32")
+        ctx.dims = (N, F, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        N, F, T = ctx.dims
+        ga = torch.empty((N, F, T), device=g.device, dtype=torch.float32)
+        # rows n < N, channels c < F of g [T, 2N, 2F] back to [N, F, T]
+        check(lib().aas_transpose_f32(stream(), ptr(g), ptr(ga), N, T, F, 2 * F, 2 * N * 2 * F, F * T, T), "aas_transpose_f32")
+        return ga, None, None
+
+
+def layout_paired_cat(leaf, mixture, cleans):
+    return _LayoutPairedCat.apply(leaf, mixture, cleans)
 
 
 # --------------------------------------------------------------------------------------- linear
@@ -1626,7 +1682,7 @@ class _Conv1dCL(torch.autograd.Function):
         ctx.save_for_backward(x, W2)
         ctx.dims = (N, T, F, M, KW, T1, stride)
         ctx.has_b = b is not None
-        ctx.bias_param = b
+        ctx.bias_param, ctx.weight_param = b, W
         return y
 
     @staticmethod
@@ -1638,7 +1694,11 @@ class _Conv1dCL(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dW2 = torch.empty((M, KW * F), device=x.device, dtype=torch.float32)
             gemm(TN, M, KW * F, N * T1, dy, M, x, stride * F, dW2, KW * F, kdivB=T1, kouterB=T * F)
-            dW = _kf_to_w(dW2, F, KW)
+            if _direct_small((ctx.weight_param,)) and tuple(ctx.weight_param.grad.shape) == (M, F, KW):
+                # [M, KW*F] -> ADDED into the flat-buffer .grad in the module's [M, F, KW] layout (no autograd accumulation launch)
+                check(lib().aas_transpose_add_f32(stream(), ptr(dW2), ptr(ctx.weight_param.grad), M, KW, F, KW * F, F, F * KW, KW), "aas_transpose_add_f32")
+            else:
+                dW = _kf_to_w(dW2, F, KW)
         if ctx.has_b and ctx.needs_input_grad[2]:
             if _direct_small((ctx.bias_param,)):     # straight into the flat-buffer .grad
                 check(lib().aas_colsum_f32(stream(), ptr(dy), N * T1, M, M, ptr(ctx.bias_param.grad), 1), "aas_colsum_f32")
@@ -1742,6 +1802,64 @@ class _L1Pair(torch.autograd.Function):
 
 def l1_pair(ae, leaf, clean, s_ny, s_cl, acc, target_grad=None):
     return _L1Pair.apply(ae, leaf, clean, s_ny, s_cl, acc, target_grad)
+
+
+class _L1Scaled(torch.autograd.Function):
+    """ONE masked-L1 sum (model.py:23-31) with its 1 / nElement (or weight / nElement) folded into the backward launch:
+    acc[0] += sum|a - b| (acc: fp64, zeroed by the step prologue; a plain output buffer, not an autograd tensor); the returned
+    root is an UNINITIALISED fp64 scalar that only anchors the backward pass (read the loss from `acc`).  Backward writes
+    scale * sign(a - b) for `a` (and its negative for `b` when that needs a gradient) without a scaling launch in between."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale, acc, grad_out=None):
+        """grad_out (a list, optional): the gradient wrt `a` is appended to it instead of being returned to autograd - the caller
+        adds it where it sums the gradients arriving at that tensor anyway (no autograd accumulation launch)."""
+        require_cuda(a, b)
+        a, b = _c(a), _c(b)
+        assert acc.dtype == torch.float64 and acc.numel() >= 1
+        check(lib().aas_l1_fwd(stream(), ptr(a), ptr(b), a.numel(), ptr(acc)), "aas_l1_fwd")
+        ctx.save_for_backward(a, b)
+        ctx.scale, ctx.grad_out = scale, grad_out
+        return torch.empty((1,), device=a.device, dtype=torch.float64)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        gs = None if getattr(g, "_aas_unit", False) else _c(g.to(torch.float32))
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        sc = ctx.scale
+        if torch.is_tensor(sc):       # a device scalar (data parallel: 1 / global nElement): it rides as the kernel's device factor
+            gs = _c(sc.reshape(1).to(torch.float32)) if gs is None else _c((gs * sc).reshape(1).to(torch.float32))
+            sc = 1.0
+        check(lib().aas_l1_bwd(stream(), ptr(a), ptr(b), a.numel(), float(sc), ptr(gs), ptr(ga), ptr(gb), 0), "aas_l1_bwd")
+        if ctx.grad_out is not None and ga is not None:
+            ctx.grad_out.append(ga)
+            ga = None
+        return ga, gb, None, None, None
+
+
+def l1_scaled(a, b, scale, acc, grad_out=None):
+    return _L1Scaled.apply(a, b, scale, acc, grad_out)
+
+
+class StepResult(dict):
+    """What a device-resident training step hands back: device tensors, plus log scalars that are only FORMED when somebody reads
+    them (`r["dce"]` = raw device sum x its normaliser) - a step that nobody logs queues no launch for them."""
+
+    def __init__(self, *a, lazy=None, **k):
+        super().__init__(*a, **k)
+        self._lazy = dict(lazy or {})
+
+    def __missing__(self, key):
+        fn = self._lazy.get(key)
+        if fn is None:
+            raise KeyError(key)
+        v = self[key] = fn()
+        return v
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
 
 
 def ctc_prepare(labels, act_lens, label_lens, device):  # device may be "cpu": the caller uploads `meta` itself
@@ -1853,6 +1971,26 @@ def step_prologue(bufs, rs=None, n_neg=0, n_one=0, kt=None):
 def began_step_raw(l1_acc, s_ny, s_cl, costs, s_ctc, d_kt, d_out6, gamma, lambda_k, n_batch):
     check(lib().aas_began_step_raw(stream(), ptr(l1_acc), float(s_ny), float(s_cl), ptr(costs), int(costs.numel()), float(s_ctc), ptr(d_kt),
                                    ptr(d_out6), float(gamma), float(lambda_k), float(n_batch)), "aas_began_step_raw")
+
+
+def began_step_sums(l1_sums, third, s0, s1, s2, d_kt, d_out6, gamma, lambda_k, n_batch, d_scales3=None, d_n_batch=None):
+    """include/aas_hip.h: aas_began_step_sums - the controller from the raw device sums l1_sums[2], third[1] (optionally
+    device-resident scales / N)."""
+    check(lib().aas_began_step_sums(stream(), ptr(l1_sums), ptr(third), float(s0), float(s1), float(s2), ptr(d_scales3), ptr(d_kt), ptr(d_out6), float(gamma),
+                                    float(lambda_k), float(n_batch), ptr(d_n_batch)), "aas_began_step_sums")
+
+
+def loss_pack(l1_acc, costs, out3):
+    check(lib().aas_loss_pack(stream(), ptr(l1_acc), ptr(costs), int(costs.numel()) if costs is not None else 0, ptr(out3)), "aas_loss_pack")
+
+
+def scales_from_counts(counts, weights, index, out):
+    """out[i] = weights[i] / counts[index[i]] on the device (include/aas_hip.h: aas_scales_from_counts)."""
+    import ctypes
+    n = len(weights)
+    w = (ctypes.c_double * n)(*[float(x) for x in weights])
+    ix = (ctypes.c_int * n)(*[int(x) for x in index])
+    check(lib().aas_scales_from_counts(stream(), ptr(counts), n, w, ix, ptr(out)), "aas_scales_from_counts")
 
 
 # --------------------------------------------------------------------------------------- reductions / optimiser

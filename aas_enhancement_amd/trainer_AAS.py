@@ -11,18 +11,14 @@ Schedules (results identical, SURVEY.md 3.1 / 8a "verified algebraic identities"
     are (-kt) x the G-step's D-parameter gradients that the reference computes and then discards at
     :152, so no second D forward/backward is run.
 """
-import os
-import random
-from glob import glob
-from shutil import copyfile
-
 import torch
 
 from . import knobs, ops
 from .ctc import CTCLoss
 from .decoder import GreedyDecoder
-from .model import DeepSpeech, L1Loss_mask, stackedBRNN, supported_rnns
-from .utils import AverageMeter, _get_variable_nograd, _get_variable_volatile, attach_n_valid
+from .model import L1Loss_mask, stackedBRNN, supported_rnns
+from .utils import _get_variable_nograd, _get_variable_volatile, attach_n_valid
+from .validation import ValidationMixin
 
 
 class _LazyScales(object):
@@ -51,7 +47,7 @@ class _LazyScales(object):
         return self.cnt[i]
 
 
-class Trainer(ops.TrainerContext):
+class Trainer(ops.TrainerContext, ValidationMixin):
     def __init__(self, config, data_loader=None, models=None):
         self.config = config
         self.data_loader = data_loader
@@ -60,15 +56,12 @@ class Trainer(ops.TrainerContext):
         self.batch_size = config.batch_size
         self.schedule = getattr(config, "schedule", "fused")
         self.diffLoss = L1Loss_mask()
-        self.valmin_iter = 0
         self.model_dir = "logs/" + str(config.expnum)
-        self.savename_G = self.savename_D = self.savename_ASR = ""
         self.kt = 0  # BEGAN proportional controller state (:47)
         self.lb = config.lambda_k
         self.gamma = config.gamma
         self.conv_measure = 0
-        for m in ("ctc_tr", "ctc_tr_local", "ctc_val", "adv_ny_tr", "adv_ny_val", "wer_tr", "wer_val", "cer_tr", "cer_val"):
-            setattr(self, m, AverageMeter())
+        self._init_validation_state(("ctc_tr", "ctc_tr_local", "ctc_val", "adv_ny_tr", "adv_ny_val", "wer_tr", "wer_val", "cer_tr", "cer_val"))
         self.CTCLoss = CTCLoss()
         self.decoder = GreedyDecoder(data_loader.labels) if data_loader is not None and getattr(data_loader, "labels", None) else None
         if models is not None:
@@ -80,10 +73,7 @@ class Trainer(ops.TrainerContext):
             self.G.cuda(); self.D.cuda(); self.ASR.cuda()
         if len(getattr(config, "load_path", "")) > 0:
             self.load_model()
-        self.logFile = None
-        if config.mode == "train" and getattr(config, "write_log", True) and int(os.environ.get("RANK", "0")) == 0:
-            os.makedirs(self.model_dir, exist_ok=True)
-            self.logFile = open(self.model_dir + "/log.txt", "w")
+        self._open_log()
         self._opts = None
         self._flat = None
         self.dp = None
@@ -100,22 +90,9 @@ class Trainer(ops.TrainerContext):
         c = self.config
         self.G = stackedBRNN(I=c.nFeat, H=c.rnn_size, L=c.rnn_layers, rnn_type=supported_rnns[c.rnn_type])
         self.D = stackedBRNN(I=c.nFeat, H=c.rnn_size, L=c.rnn_layers, rnn_type=supported_rnns[c.rnn_type])
-        print("load pre-trained ASR model")
-        package_ASR = torch.load(c.ASR_path, map_location=lambda storage, loc: storage)
-        self.ASR = DeepSpeech.load_model_package(package_ASR)
+        self.ASR = self.load_asr_package()
 
-    def load_model(self):
-        print("[*] Load models from {}...".format(self.config.load_path))
-        postfix = "_valmin"
-        paths = sorted(glob(os.path.join(self.config.load_path, "G{}*.pth".format(postfix))))
-        if len(paths) == 0:
-            raise AssertionError("checkpoint not avilable")
-        idxes = [int(os.path.basename(p.split(".")[0].split("_")[-1])) for p in paths]
-        if self.config.start_iter <= 0:
-            self.config.start_iter = max(idxes)
-        self.G.load_state_dict(torch.load("{}/G{}_{}.pth".format(self.config.load_path, postfix, self.config.start_iter),
-                                          map_location=lambda storage, loc: storage))
-        print("[*] Model loaded")
+    # load_model (:98-123): ValidationMixin.load_model - G from `<load_path>/G_valmin_<iter>.pth`, newest when start_iter <= 0
 
     # ------------------------------------------------------------------------------------------
     def asr_frozen(self):
@@ -689,28 +666,6 @@ class Trainer(ops.TrainerContext):
         self._host_ahead = False
         return dict(enhanced=enhanced, prob=prob, scalars=self._g_out)
 
-    def _upload_small(self, host, dev):
-        """Asynchronous H2D copy of a small host tensor through a ring of REUSED pinned staging buffers (a fresh
-        pin_memory() per step costs a pinned allocation, and the copy from pageable memory would block the host)."""
-        ring = getattr(self, "_pin_ring", None)
-        if ring is None:
-            ring = self._pin_ring = dict(i=0, slots=[None] * 8)
-        k = ring["i"] % len(ring["slots"])
-        ring["i"] += 1
-        slot = ring["slots"][k]
-        n = host.numel()
-        if slot is None or slot[0].numel() < n or slot[0].dtype != host.dtype:
-            slot = [torch.empty(max(256, 2 * n), dtype=host.dtype).pin_memory(), None]
-            ring["slots"][k] = slot
-        elif slot[1] is not None:
-            slot[1].synchronize()        # the copy that last used this staging buffer (8 uploads ago) has long finished
-        slot[0][:n].copy_(host.reshape(-1))
-        out = slot[0][:n].to(dev, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        slot[1] = ev
-        return out
-
     def read_scalars(self):
         """One D2H copy of (l_adv_ny_G, l_adv_cl, l_ctc, kt) of the last train_step_async; updates the host-side kt and the
         running CTC average, and (it is a synchronisation point) raises if a persistent kernel timed out or the run diverged."""
@@ -1030,27 +985,17 @@ class Trainer(ops.TrainerContext):
             if (iter + 1) % c.save_iter == 0:
                 if getattr(self, "_kt_dev_live", False):
                     self.read_scalars()
-                if rank0:   # every rank holds identical parameters: rank 0 validates and writes the checkpoints
-                    # A stays in train mode during validation (as in the reference), so with --sync_bn its BatchNorm would
-                    # issue all-reduces that no other rank matches: rank-0-only validation uses local statistics
-                    armed, ops.SYNC_BN[0] = ops.SYNC_BN[0], None
-                    try:
-                        self.validate_and_checkpoint(iter)
-                    finally:
-                        ops.SYNC_BN[0] = armed
-                if self.dp.active:
-                    self.dp.barrier()   # host-side (gloo side group): no pending RCCL work while rank 0 validates, however long
-                    # A stays in train mode during validation (as in the reference), so rank 0's BatchNorm running statistics moved
-                    # while the other ranks' did not: hand every rank rank 0's buffers - the ranks are replicas again, buffers included
-                    self.dp.broadcast_buffers(self.ASR, src=0)
+                # rank 0 validates and writes the checkpoints; A stays in train mode during validation (as in the reference), so
+                # its BatchNorm running statistics move on rank 0 only: every rank then takes rank 0's (ValidationMixin)
+                self._save_iter_block(iter)
 
     # ---- validation + checkpoint lifecycle (:215-297) -----------------------------------------
     @ops.with_trainer_precision
     def validate_and_checkpoint(self, iter):
         c = self.config
         self.G.eval()
-        for name, dl, ctc_m, adv_m, wer_m, cer_m in (("training subset", "trsub", self.ctc_tr, self.adv_ny_tr, self.wer_tr, self.cer_tr),
-                                                     ("validation", "val", self.ctc_val, self.adv_ny_val, self.wer_val, self.cer_val)):
+        for (name, dl), (ctc_m, adv_m, wer_m, cer_m) in zip(self._validation_sets(), ((self.ctc_tr, self.adv_ny_tr, self.wer_tr, self.cer_tr),
+                                                                                      (self.ctc_val, self.adv_ny_val, self.wer_val, self.cer_val))):
             for m in (ctc_m, adv_m, wer_m, cer_m):
                 m.reset()
             for _ in range(self.data_loader.num_batches(dl)):
@@ -1059,29 +1004,11 @@ class Trainer(ops.TrainerContext):
                     ctc, adv_ny, nElement, wer, cer, nWord, nChar = self.greedy_decoding_and_AAS(d[0], d[1], d[2], d[3], d[4])
                 ctc_m.update(float(ctc), d[0].size(0)); adv_m.update(float(adv_ny), nElement)
                 wer_m.update(wer, nWord); cer_m.update(cer, nChar)
-            s = "[{}/{}] ({}) CTC: {:.7f}, WER: {:.7f}, CER: {:.7f}".format(iter, c.max_iter, name, ctc_m.avg, wer_m.avg * 100, cer_m.avg * 100)
-            print(s)
-            if self.logFile:
-                self.logFile.write(s + "\n"); self.logFile.flush()
+            self._log("[{}/{}] ({}) CTC: {:.7f}, WER: {:.7f}, CER: {:.7f}".format(iter, c.max_iter, name, ctc_m.avg, wer_m.avg * 100, cer_m.avg * 100), flush=True)
         self.G.train()
-        os.makedirs(self.model_dir, exist_ok=True)
-        if len(self.savename_G) > 0 and os.path.exists(self.savename_G):
-            os.remove(self.savename_G)
-        self.savename_G = "{}/G_{}.pth".format(self.model_dir, iter)
-        torch.save(self.G.state_dict(), self.savename_G)
-        if len(self.savename_ASR) > 0 and os.path.exists(self.savename_ASR):
-            os.remove(self.savename_ASR)
-        self.savename_ASR = "{}/ASR_{}.pth".format(self.model_dir, iter)
-        torch.save(self.ASR.state_dict(), self.savename_ASR)
-        if self.G.loss_stop > self.wer_val.avg:
-            self.G.loss_stop = self.wer_val.avg
-            for tag, cur in (("G", self.savename_G), ("ASR", self.savename_ASR)):
-                prev = "{}/{}_valmin_{}.pth".format(self.model_dir, tag, self.valmin_iter)
-                if os.path.exists(prev):
-                    os.remove(prev)
-                print("save model for this checkpoint")
-                copyfile(cur, "{}/{}_valmin_{}.pth".format(self.model_dir, tag, iter))
-            self.valmin_iter = iter
+        self._save_rotating("G", self.G, iter)
+        self._save_rotating("ASR", self.ASR, iter)
+        self._keep_if_best(iter, self.wer_val.avg, ("G", "ASR"))
 
     @ops.with_trainer_precision
     def greedy_decoding_and_AAS(self, inputs, targets, input_percentages, target_sizes, mask, transcript_prob=0.001):
@@ -1090,26 +1017,8 @@ class Trainer(ops.TrainerContext):
         attach_n_valid(mask) if not mask.is_cuda else None
         mask = _get_variable_volatile(mask)
         N = inputs.size(0)
-        split_targets, offset = [], 0
-        for size in target_sizes:
-            split_targets.append(targets[offset:offset + int(size)])
-            offset += int(size)
         enhanced = self.G(inputs)
-        prob = self.ASR(enhanced).transpose(0, 1)
-        T = prob.size(0)
-        sizes = input_percentages.clone().mul_(int(T)).int()
-        decoded_output, _ = self.decoder.decode(prob.detach(), sizes)
-        target_strings = self.decoder.convert_to_strings(split_targets)
-        we = ce = total_word = total_char = 0
-        for x in range(len(target_strings)):
-            decoding, reference = decoded_output[x][0], target_strings[x][0]
-            nChar, nWord = len(reference), len(reference.split())
-            we_i, ce_i = self.decoder.wer(decoding, reference), self.decoder.cer(decoding, reference)
-            we += we_i; ce += ce_i; total_word += nWord; total_char += nChar
-            if random.uniform(0, 1) < transcript_prob:
-                print("reference = " + reference); print("decoding = " + decoding)
-        wer = we / max(total_word, 1)
-        cer = ce / max(total_word, 1)
+        prob, sizes, wer, cer, total_word, total_char = self._greedy_pass(enhanced, targets, input_percentages, target_sizes, transcript_prob)
         ae_ny = self.D(enhanced)
         l_adv_ny, nElement = self.diffLoss(ae_ny, enhanced, mask)
         l_adv_ny = l_adv_ny * self.config.w_adversarial

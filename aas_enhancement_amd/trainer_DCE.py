@@ -90,12 +90,16 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
         try:
             ops.sync_wgrad()
-            if getattr(self, "_l1_acc", None) is None:
-                self._l1_acc = torch.zeros(1, device=inputs.device, dtype=torch.float64)
-            ops.step_prologue([self._flat.flat_g, self._l1_acc])      # ONE launch: zero the flat gradient buffer and the loss sum
+            # the loss root is a RAW device sum in a ring of eight accumulators (a caller may read a step's loss up to seven
+            # steps later); ONE prologue launch zeroes the flat gradient buffer and this step's accumulator
+            if getattr(self, "_l1_ring", None) is None:
+                self._l1_ring, self._l1_i = torch.zeros(16, device=inputs.device, dtype=torch.float64), 0   # (16-byte slots)
+            self._l1_i = (self._l1_i + 1) % 8
+            acc = self._l1_ring[2 * self._l1_i:2 * self._l1_i + 1]
+            ops.step_prologue([self._flat.flat_g, acc])
             outputs = self.G(inputs)
-            dce = ops.l1_scaled(outputs, cleans, 1.0 / nElement, self._l1_acc.detach())
-            torch.autograd.backward([dce], [ops.unit_root(dce)])
+            root = ops.l1_scaled(outputs, cleans, 1.0 / nElement, acc)
+            torch.autograd.backward([root], [ops.unit_root(root)])
             ops.sync_wgrad()   # the recurrent layers' weight gradients accumulate into the flat buffer on a side stream
             if dp.active:
                 self._reducer.flush(self._flat)
@@ -104,10 +108,16 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             ops.WGRAD_HOOK[0] = None
         self._opt.step_dev()
         ops.refresh_weight_planes(self.G)
-        dce = dce.detach() / nElement         # (the root is the raw L1 sum; its 1 / nElement rides in the backward launch)
-        if dp.active:
-            dce = dp.reduce_scalars(dce.reshape(1).clone()).reshape(())
-        return dict(dce=dce.reshape(()).to(torch.float32), nElement=nElement, outputs=outputs)
+        raw = acc
+
+        def dce():     # formed when a log line (or a test) reads it: L = sum / nElement (the GLOBAL sum when data parallel)
+            v = raw.clone()
+            if dp.active:
+                v = dp.reduce_scalars(v)
+            return (v / nElement).reshape(()).to(torch.float32)
+        if dp.active:   # (a collective: every rank forms it every step)
+            return ops.StepResult(dce=dce(), nElement=nElement, outputs=outputs)
+        return ops.StepResult(nElement=nElement, outputs=outputs, lazy=dict(dce=dce))
 
     def train(self):
         """:111-207"""

@@ -1,4 +1,7 @@
-"""FSEGAN trainer (reference Speech_enhancement_by_AAS/trainer_FSEGAN.py; hot loop :128-182).
+"""FSEGAN trainer on the MI355X HIP path - same API as the reference's Speech_enhancement_by_AAS/trainer_FSEGAN.py
+(`Trainer.__init__ / build_model / load_model / train / zero_grad_all / greedy_decoding_and_FSEGAN`; hot loop :128-182, the save_iter
+block with validation through the pre-trained acoustic model and the `G_<iter>.pth` / `G_valmin_<iter>.pth` lifecycle :199-275,
+`greedy_decoding_and_FSEGAN` :277-317).
 
 The reference file is unrunnable as written.  This builds the INTENDED step:
 nFeat_in = nFeat_out = nFeat, D = stackedBRNN(I=2*nFeat, O=nFeat) fed through ``forward_paired``
@@ -6,47 +9,62 @@ everywhere (the reference's ``self.D(cleans, mixture)`` at :167 has the wrong ar
 term IS back-propagated (G loss = dce + w_adversarial * adv).  ``config.fsegan_as_written=True``
 keeps the reference's behaviour of only logging the DCE term (:161-163).
 """
-import os
-
 import torch
 
 from . import ops
+from .decoder import GreedyDecoder
 from .model import L1Loss_mask, stackedBRNN, supported_rnns
-from .utils import AverageMeter, _get_variable_nograd, attach_n_valid
+from .utils import _get_variable_nograd, _get_variable_volatile, attach_n_valid
+from .validation import ValidationMixin
 
 
-class Trainer(ops.TrainerContext):
+class Trainer(ops.TrainerContext, ValidationMixin):
     def __init__(self, config, data_loader=None, models=None):
+        """models: (G, D) or (G, D, ASR) - networks built by the caller (tests / bench); None -> build_model() (:85-94)."""
         self._init_context()   # arithmetic mode + launch settings this trainer runs in (ops.TrainerContext)
         self.config, self.data_loader = config, data_loader
         self.lr, self.beta1, self.beta2 = config.lr, config.beta1, config.beta2
+        self.optimizer = getattr(config, "optimizer", "adam")
+        self.batch_size = config.batch_size
         self.diffLoss = L1Loss_mask()
         self.model_dir = "logs/" + str(config.expnum)
         self.kt, self.lb, self.gamma = 0, config.lambda_k, config.gamma
-        self.dce_tr_local = AverageMeter()
+        self.conv_measure = 0
+        self._init_validation_state(("dce_tr", "dce_tr_local", "dce_val", "adv_ny_tr", "adv_ny_val", "wer_tr", "wer_val", "cer_tr", "cer_val"))
+        self.decoder = GreedyDecoder(data_loader.labels) if data_loader is not None and getattr(data_loader, "labels", None) else None
         self.as_written = getattr(config, "fsegan_as_written", False)
+        self.ASR = None
         if models is not None:
-            self.G, self.D = models
+            self.G, self.D = models[0], models[1]
+            if len(models) > 2:
+                self.ASR = models[2]
         else:
             self.build_model()
+        self.G.loss_stop = 100000
         if config.gpu >= 0:
             self.G.cuda(); self.D.cuda()
-        self.logFile = None
-        if config.mode == "train" and getattr(config, "write_log", True) and int(os.environ.get("RANK", "0")) == 0:
-            os.makedirs(self.model_dir, exist_ok=True)
-            self.logFile = open(self.model_dir + "/log.txt", "w")
+            if self.ASR is not None:
+                self.ASR.cuda()
+        if len(getattr(config, "load_path", "")) > 0:
+            self.load_model()
+        self._open_log()
         self._opts = None
         self._flat = None
         self.dp = None
 
     def zero_grad_all(self):
         self.G.zero_grad(); self.D.zero_grad()
+        if self.ASR is not None:
+            self.ASR.zero_grad()
 
     def build_model(self):
+        """:85-94 with nFeat_in = nFeat_out = nFeat and nFeat_D = 2 * nFeat (config.py defines none of the three: SURVEY 0.13)."""
         c = self.config
         rt = supported_rnns[c.rnn_type]
+        print("initialize enhancement & discriminator model")
         self.G = stackedBRNN(I=c.nFeat, O=c.nFeat, H=c.rnn_size, L=c.rnn_layers, rnn_type=rt)
         self.D = stackedBRNN(I=2 * c.nFeat, O=c.nFeat, H=c.rnn_size, L=c.rnn_layers, rnn_type=rt)
+        self.ASR = self.load_asr_package()
 
     def make_optimizers(self):
         """Adam(amsgrad) per network on flat parameter / gradient buffers (one fused launch each); the recurrent layers'
@@ -57,6 +75,10 @@ class Trainer(ops.TrainerContext):
         self.dp = getattr(self, "dp", None) or DPContext.from_env()
         for name, m in (("G", self.G), ("D", self.D)):
             ops.name_layers(m, name)
+        if self.ASR is not None:
+            ops.name_layers(self.ASR, "ASR")
+            for p in self.ASR.parameters():      # A only decodes in this trainer: no gradient ever reaches it
+                p.requires_grad_(False)
         self._flat = {"G": FlatBuffers(self.G), "D": FlatBuffers(self.D)}
         mk = lambda f: FlatAdam(f, lr=c.lr, betas=(self.beta1, self.beta2), amsgrad=True)
         self._opts = (mk(self._flat["G"]), mk(self._flat["D"]))
@@ -86,15 +108,15 @@ class Trainer(ops.TrainerContext):
         return _get_variable_nograd(data_list[0]), _get_variable_nograd(data_list[1]), _get_variable_nograd(mask)
 
     def _forward_backward(self, mixture, cleans, rs, s_adv, s_dce):
-        """The fused pass shared by both step forms.  D(enhanced | mixture) and D(clean | mixture) share ONE batched pass of 2N
-        rows, the D-step parameter gradients of the enhanced half are (-kt) x its G-step ones (per-utterance weights `rs` on the
-        weight-gradient products only), and E is back-propagated once with d(adv)/d(enhanced) + d(dce)/d(enhanced).
+        """The fused pass shared by both step forms (data parallel: the autograd-scaled form).  D(enhanced | mixture) and
+        D(clean | mixture) share ONE batched pass of 2N rows, the D-step parameter gradients of the enhanced half are (-kt) x its
+        G-step ones (per-utterance weights `rs` on the weight-gradient products only), and E is back-propagated once with
+        d(adv)/d(enhanced) + d(dce)/d(enhanced).
         s_adv = w_adversarial / nElement, s_dce = 1 / nElement (python floats, or device scalars when data parallel)."""
         N = mixture.size(0)
         enhanced = self.G(mixture)
         leaf = enhanced.detach().requires_grad_(True)
-        paired = torch.cat([torch.cat([leaf, mixture], 1), torch.cat([cleans, mixture], 1)], 0)   # forward_paired x 2 (model.py:233-238)
-        ae = self.D(paired, wgrad_row_scale=rs)
+        ae = self.D(None, wgrad_row_scale=rs, tnc=ops.layout_paired_cat(leaf, mixture, cleans))   # forward_paired x 2 (model.py:233-238)
         l_adv_ny_G = ops.l1_sum(ae[:N], leaf) * s_adv
         l_adv_cl = ops.l1_sum(ae[N:], cleans) * s_adv
         dce = ops.l1_sum(leaf, cleans) * s_dce
@@ -107,16 +129,76 @@ class Trainer(ops.TrainerContext):
         enhanced.backward(leaf.grad)
         return enhanced, l_adv_ny_G, l_adv_cl, dce
 
+    def _device_step(self, mixture, cleans, nElement):
+        """The single-process step as library launches only (no torch glue): ONE prologue launch zeroes the flat gradient buffers
+        and the three loss sums and writes the discriminator's per-utterance weights [-kt] * N + [1] * N; the batched D input is
+        laid down time-major directly; the three L1 losses are raw device sums whose weights ride in their backward launches;
+        the controller consumes the raw sums (aas_began_step_sums).  -> enhanced."""
+        c = self.config
+        N, dev = mixture.size(0), mixture.device
+        if getattr(self, "_sums", None) is None or self._rs_pair.numel() != 2 * N:
+            self._sums = torch.zeros(2, device=dev, dtype=torch.float64)       # raw L1 sums [adv_ny, adv_cl]
+            self._sum3 = torch.zeros(2, device=dev, dtype=torch.float64)       # [dce, -] (a 16-byte block of its own)
+            self._rs_pair = torch.empty(2 * N, device=dev, dtype=torch.float32)
+        ops.sync_wgrad()
+        ops.step_prologue([f.flat_g for f in self._flat.values()] + [self._sums, self._sum3], self._rs_pair, N, N, self._kt_dev)
+        rs = self._rs_pair.detach()
+        rs._aas_classes = [(0, N, rs[0:1]), (N, N, None)]   # the two utterance classes and their weights (device scalars)
+        s_adv, s_dce = c.w_adversarial / nElement, 1.0 / nElement
+        enhanced = self.G(mixture)
+        leaf = enhanced.detach().requires_grad_(True)
+        ae = self.D(None, wgrad_row_scale=rs, tnc=ops.layout_paired_cat(leaf, mixture, cleans))
+        tgrad = []
+        l_pair = ops.l1_pair(ae, leaf, cleans, s_adv, s_adv, self._sums.detach(), tgrad)
+        l_dce = ops.l1_scaled(leaf, cleans, s_dce, self._sum3, tgrad)
+        roots = [l_pair] if self.as_written else [l_pair, l_dce]     # (:161-163: the reference only logs the DCE term)
+        torch.autograd.backward(roots, [ops.unit_root(r_) for r_ in roots])
+        # the gradients arriving at `enhanced`: through D's input, as the target of the adversarial L1, from the DCE term
+        parts = [leaf.grad] + tgrad
+        gsum = ops.add3(parts[0], parts[1], parts[2] if len(parts) > 2 else None)
+        enhanced.backward(gsum)
+        ops.sync_wgrad()
+        return enhanced
+
+    def _ensure_dev_state(self, dev):
+        if getattr(self, "_kt_dev", None) is None:
+            self._kt_dev = torch.zeros(1, device=dev, dtype=torch.float64)
+            self._g_out = torch.zeros(6, device=dev, dtype=torch.float64)
+            self._kt_ev = None
+            self._kt_dev_live = False
+        if not self._kt_dev_live:
+            self._kt_dev.fill_(float(self.kt))     # (the host copy is the current one: a synchronous step / a checkpoint advanced it)
+        self._kt_dev_live = True
+
     @ops.with_trainer_precision
     def train_step(self, data_list, iter=0):
-        """:128-182 (intended semantics), host-synchronous: returns the scalars of the log lines (and the gradient
-        norm of G).  Data parallel: `data_list` is this rank's shard; the losses are normalised by the GLOBAL nElement, so the
-        SUM all-reduce of the flat gradient buffers gives the single-process gradients."""
-        c = self.config
+        """:128-182 (intended semantics), host-synchronous: the same launches as `train_step_async` plus the gradient
+        norm of G before the update and ONE read-back; returns the scalars of the log lines.  Data parallel: `data_list` is this
+        rank's shard; the losses are normalised by the GLOBAL nElement, so the SUM all-reduce of the flat gradient buffers gives
+        the single-process gradients."""
         if self._opts is None:
             self.make_optimizers()
+        if self.dp.active:
+            return self._train_step_dp_sync(data_list, iter)
         optimizer_g, optimizer_d = self._opts
-        dp = self.dp
+        mixture, cleans, mask = self._batch(data_list)
+        nElement = mask.n_valid
+        self._ensure_dev_state(mixture.device)
+        enhanced = self._device_step(mixture, cleans, nElement)
+        g_norm = self.get_gradient_norm(self.G)
+        optimizer_g.step_dev(); optimizer_d.step_dev()
+        ops.refresh_weight_planes(self.G); ops.refresh_weight_planes(self.D)
+        c = self.config
+        ops.began_step_sums(self._sums, self._sum3, c.w_adversarial / nElement, c.w_adversarial / nElement, 1.0 / nElement, self._kt_dev, self._g_out,
+                            self.gamma, self.lb, float(nElement))
+        r = self.read_scalars()
+        r.update(g_norm=float(g_norm), enhanced=enhanced)
+        return r
+
+    def _train_step_dp_sync(self, data_list, iter):
+        """The host-synchronous step under data parallelism (global nElement from the host-side count exchange)."""
+        c, dp = self.config, self.dp
+        optimizer_g, optimizer_d = self._opts
         if getattr(self, "_kt_dev_live", False):
             self.read_scalars()
         ops.sync_wgrad()
@@ -124,22 +206,20 @@ class Trainer(ops.TrainerContext):
             f.zero_grad()
         mixture, cleans, mask = self._batch(data_list)
         N = mixture.size(0)
-        nElement = getattr(mask, "n_valid", None)
-        if nElement is None:
-            nElement = int(mask.numel()) - int(mask.sum().item())
-        if dp.active:
-            (nElement,) = dp.global_counts([nElement])
+        (nElement,) = dp.global_counts([mask.n_valid])
         rs = torch.empty(2 * N, device=mixture.device, dtype=torch.float32)
         rs[:N] = -float(self.kt)
         rs[N:] = 1.0
         rs._aas_classes = [(0, N, rs[0:1]), (N, N, None)]   # the two utterance classes and their weights (ops.gemm_planes_tn)
-        if self._reducer is not None:
-            self._reducer.begin()
-        enhanced, l_adv_ny_G, l_adv_cl, dce = self._forward_backward(mixture, cleans, rs, c.w_adversarial / nElement, 1.0 / nElement)
-        ops.sync_wgrad()
-        if dp.active:
+        self._reducer.begin()
+        ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
+        try:
+            enhanced, l_adv_ny_G, l_adv_cl, dce = self._forward_backward(mixture, cleans, rs, c.w_adversarial / nElement, 1.0 / nElement)
+            ops.sync_wgrad()
             self._reducer.flush(self._flat["G"])
             self._reducer.wait()
+        finally:
+            ops.WGRAD_HOOK[0] = None
         g_norm = self.get_gradient_norm(self.G)
         optimizer_g.step(); optimizer_d.step()
         ops.refresh_weight_planes(self.G); ops.refresh_weight_planes(self.D)
@@ -157,43 +237,39 @@ class Trainer(ops.TrainerContext):
     # ---- the same step without a host synchronisation (what train() queues on iterations that print nothing) -----------
     @ops.with_trainer_precision
     def train_step_async(self, data_list, iter=0):
-        """train_step queued WITHOUT reading anything back: kt, the Adam bias corrections, the loss scalars and the running DCE
-        average of the log line stay on the device (`aas_began_step`, `FlatAdam.step_dev`), so the host queues step i+1 while
-        the GPU runs step i.  `read_scalars()` (one D2H copy) returns the last step's losses and updates the host-side kt.
-        Data parallel: the global nElement is all-reduced on the utility stream and kept on the device, the gradient buffers
-        are all-reduced bucket by bucket behind the weight-gradient products (dist.BucketReducer), and kt is advanced from the
-        all-reduced loss scalars - still no host synchronisation."""
+        """train_step queued WITHOUT reading anything back: kt, the Adam bias corrections, the loss sums and the running DCE
+        average of the log line stay on the device (`aas_began_step_sums`, `FlatAdam.step_dev`), so the host queues step i+1
+        while the GPU runs step i.  `read_scalars()` (one D2H copy) returns the last step's losses and updates the host-side kt.
+        Single process: library launches only (`_device_step`).  Data parallel: the global nElement is all-reduced on the utility
+        stream and kept on the device, the gradient buffers are all-reduced bucket by bucket behind the weight-gradient products
+        (dist.BucketReducer), and kt is advanced from the all-reduced loss scalars - still no host synchronisation."""
         c = self.config
         if self._opts is None:
             self.make_optimizers()
         optimizer_g, optimizer_d = self._opts
         dp = self.dp
         mixture, cleans, mask = self._batch(data_list)
-        nElement = getattr(mask, "n_valid", None)
-        if nElement is None:     # a device mask without a host-side count: the synchronous form counts it
-            return self.train_step(data_list, iter)
+        nElement = mask.n_valid
         N, dev = mixture.size(0), mixture.device
-        if getattr(self, "_kt_dev", None) is None:
-            self._kt_dev = torch.zeros(1, device=dev, dtype=torch.float64)
-            self._g_out = torch.zeros(6, device=dev, dtype=torch.float64)
-            self._kt_ev = None
-        if not getattr(self, "_kt_dev_live", False):
-            self._kt_dev.fill_(float(self.kt))
-        self._kt_dev_live = True
+        self._ensure_dev_state(dev)
+        if not dp.active:
+            enhanced = self._device_step(mixture, cleans, nElement)
+            optimizer_g.step_dev(); optimizer_d.step_dev()
+            ops.refresh_weight_planes(self.G); ops.refresh_weight_planes(self.D)
+            # controller (:175-179) + the log scalars in one tiny launch from the raw sums; slot 2 carries the DCE term
+            ops.began_step_sums(self._sums, self._sum3, c.w_adversarial / nElement, c.w_adversarial / nElement, 1.0 / nElement, self._kt_dev, self._g_out,
+                                self.gamma, self.lb, float(nElement))
+            return dict(enhanced=enhanced, scalars=self._g_out)
         ops.sync_wgrad()
         for f in self._flat.values():
             f.flat_g.zero_()
         aux = ops.refresh_stream(dev)
-        if dp.active:
-            from .dist import DeviceCounts
-            cnt = DeviceCounts(dp, [nElement], dev, aux)
-            n_glob = cnt.get(0)
-            s_adv, s_dce = (c.w_adversarial / n_glob).float(), (1.0 / n_glob).float()
-            self._reducer.begin()
-            ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
-        else:
-            n_glob = float(nElement)
-            s_adv, s_dce = c.w_adversarial / nElement, 1.0 / nElement
+        from .dist import DeviceCounts
+        cnt = DeviceCounts(dp, [nElement], dev, aux)
+        n_glob = cnt.get(0)
+        s_adv, s_dce = (c.w_adversarial / n_glob).float(), (1.0 / n_glob).float()
+        self._reducer.begin()
+        ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
         if self._kt_ev is not None:
             torch.cuda.current_stream().wait_event(self._kt_ev)
         rs = torch.empty(2 * N, device=dev, dtype=torch.float32)
@@ -203,30 +279,26 @@ class Trainer(ops.TrainerContext):
         try:
             enhanced, l_adv_ny_G, l_adv_cl, dce = self._forward_backward(mixture, cleans, rs, s_adv, s_dce)
             ops.sync_wgrad()
-            if dp.active:
-                self._reducer.flush(self._flat["G"])
-                self._reducer.wait()
+            self._reducer.flush(self._flat["G"])
+            self._reducer.wait()
         finally:
             ops.WGRAD_HOOK[0] = None
         optimizer_g.step_dev(); optimizer_d.step_dev()
         ops.refresh_weight_planes(self.G); ops.refresh_weight_planes(self.D)
-        if not dp.active:   # controller (:175-179) + the log scalars in one tiny launch; slot 2 carries the DCE term
-            ops.began_step(l_adv_ny_G, l_adv_cl, dce, self._kt_dev, self._g_out, self.gamma, self.lb, n_glob)
-        else:
-            main = torch.cuda.current_stream()
-            packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), dce.detach().reshape(())]).double()
-            aux.wait_stream(main)
-            with torch.cuda.stream(aux):
-                dp.reduce_scalars(packed)
-                bal = self.gamma * packed[1] - packed[0]
-                self._kt_dev.copy_(torch.clamp(self._kt_dev + self.lb * bal, 0.0, 1.0))
-                self._g_out[:3].copy_(packed)
-                self._g_out[3:4].copy_(self._kt_dev)
-                self._g_out[4:5].add_(packed[2] * n_glob)
-                self._g_out[5:6].add_(n_glob)
-                self._kt_ev = torch.cuda.Event()
-                self._kt_ev.record(aux)
-            packed.record_stream(aux)
+        main = torch.cuda.current_stream()
+        packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), dce.detach().reshape(())]).double()
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            dp.reduce_scalars(packed)
+            bal = self.gamma * packed[1] - packed[0]
+            self._kt_dev.copy_(torch.clamp(self._kt_dev + self.lb * bal, 0.0, 1.0))
+            self._g_out[:3].copy_(packed)
+            self._g_out[3:4].copy_(self._kt_dev)
+            self._g_out[4:5].add_(packed[2] * n_glob)
+            self._g_out[5:6].add_(n_glob)
+            self._kt_ev = torch.cuda.Event()
+            self._kt_ev.record(aux)
+        packed.record_stream(aux)
         return dict(enhanced=enhanced, scalars=self._g_out)
 
     def read_scalars(self):
@@ -267,6 +339,51 @@ class Trainer(ops.TrainerContext):
                 if self.logFile:
                     self.logFile.flush()
                 self.dce_tr_local.reset()
+            if (iter + 1) % c.save_iter == 0:
+                if getattr(self, "_kt_dev_live", False):
+                    self.read_scalars()
+                self._save_iter_block(iter)
+
+    # ---- validation + checkpoint lifecycle (:199-275) -------------------------------------------------------------------------
+    @ops.with_trainer_precision
+    def validate_and_checkpoint(self, iter):
+        c = self.config
+        if self.ASR is None or self.decoder is None:
+            raise RuntimeError("FSEGAN validation decodes through the pre-trained acoustic model: --ASR_path (build_model) or "
+                               "models=(G, D, ASR), and a data loader with `labels`, are needed")
+        self.G.eval()
+        for (name, dl), (dce_m, adv_m, wer_m, cer_m) in zip(self._validation_sets(), ((self.dce_tr, self.adv_ny_tr, self.wer_tr, self.cer_tr),
+                                                                                      (self.dce_val, self.adv_ny_val, self.wer_val, self.cer_val))):
+            for m in (dce_m, adv_m, wer_m, cer_m):
+                m.reset()
+            for _ in range(self.data_loader.num_batches(dl)):
+                d = self.data_loader.next(cl_ny="ny", type=dl)
+                with torch.no_grad():
+                    dce, adv_ny, nElement, wer, cer, nWord, nChar = self.greedy_decoding_and_FSEGAN(d[0], d[1], d[3], d[4], d[5], d[2])
+                dce_m.update(float(dce), nElement); adv_m.update(float(adv_ny), nElement)
+                wer_m.update(wer, nWord); cer_m.update(cer, nChar)
+            # (sic: the reference labels the DCE average "CTC" in these two lines, :225,:252)
+            self._log("[{}/{}] ({}) CTC: {:.7f}, WER: {:.7f}, CER: {:.7f}".format(iter, c.max_iter, name, dce_m.avg, wer_m.avg * 100, cer_m.avg * 100))
+        if self.logFile:
+            self.logFile.flush()
+        self.G.train()   # end of validation
+        self._save_rotating("G", self.G, iter)
+        self._keep_if_best(iter, self.wer_val.avg, ("G",))
+
+    @ops.with_trainer_precision
+    def greedy_decoding_and_FSEGAN(self, mixture, cleans, targets, input_percentages, target_sizes, mask, transcript_prob=0.001):
+        """:277-317 -> (dce, l_adv_ny, nElement, wer, cer, total_word, total_char); D through forward_paired (its :297 too)."""
+        mixture, cleans = _get_variable_volatile(mixture), _get_variable_volatile(cleans)
+        attach_n_valid(mask) if not mask.is_cuda else None
+        mask = _get_variable_volatile(mask)
+        enhanced = self.G(mixture)
+        _, _, wer, cer, total_word, total_char = self._greedy_pass(enhanced, targets, input_percentages, target_sizes, transcript_prob)
+        ae_ny = self.D.forward_paired(enhanced, mixture)
+        l_adv_ny, nElement = self.diffLoss(ae_ny, enhanced, mask)
+        l_adv_ny = l_adv_ny * self.config.w_adversarial
+        dce, nElement_ = self.diffLoss(enhanced, cleans, mask)
+        assert (nElement == nElement_)
+        return dce, l_adv_ny, nElement, wer, cer, total_word, total_char
 
 
 def _shard_paired(dp, data):

@@ -17,14 +17,12 @@ from .trainer_AAS import Trainer as _AASTrainer
 
 class Trainer(_AASTrainer):
     def build_model(self):
-        from .model import DeepSpeech, stackedBRNN, supported_rnns
+        from .model import stackedBRNN, supported_rnns
         c = self.config
         print("initialize enhancement model")
         self.G = stackedBRNN(I=c.nFeat, H=c.rnn_size, L=c.rnn_layers, rnn_type=supported_rnns[c.rnn_type])
         self.D = _NoNet()
-        print("load pre-trained ASR model")
-        package_ASR = torch.load(c.ASR_path, map_location=lambda storage, loc: storage)
-        self.ASR = DeepSpeech.load_model_package(package_ASR)
+        self.ASR = self.load_asr_package()
 
     def __init__(self, config, data_loader=None, models=None):
         if models is not None and len(models) == 2:   # (E, A): the shared plumbing iterates G, D, ASR - D is an empty stand-in
@@ -124,26 +122,50 @@ class Trainer(_AASTrainer):
         meta = ops.ctc_prepare(targets, sizes, target_sizes, "cpu")
         meta = dict(meta, meta=self._upload_small(meta["meta"], dev))
         if getattr(self, "_acc", None) is None:
-            self._acc = torch.zeros(3, device=dev, dtype=torch.float64)      # last loss, sum(loss * N), sum(N)
-        if self.dp.active:
-            from .dist import DeviceCounts
-            cnt = DeviceCounts(self.dp, [N], dev, ops.refresh_stream(dev))
-            n_dev = cnt.get(0)
-            scale = (1.0 / n_dev).float()
-        else:
-            n_dev, scale = float(N), 1.0 / N
+            self._acc = torch.zeros(6, device=dev, dtype=torch.float64)      # aas_began_step* layout: [-, -, last loss, -, sum(loss * N), sum(N)]
+            self._no_l1 = torch.zeros(2, device=dev, dtype=torch.float64)
+            self._no_kt = torch.zeros(1, device=dev, dtype=torch.float64)
+        if not self.dp.active:
+            # library launches only: one prologue launch zeroes the flat gradient buffers, the loss weight 1 / N rides in the CTC
+            # kernel's gradient scale, and the log accumulators are advanced from the raw per-utterance costs by the controller
+            # launch (its adversarial inputs are zero here: this trainer has no discriminator)
+            c = self.config
+            optimizer_g, optimizer_asr, _ = self._opts
+            asr_steps = optimizer_asr is not None and iter > c.allow_ASR_update_iter
+            ops.sync_wgrad()
+            ops.step_prologue([f.flat_g for f in self._flat.values()])
+            try:
+                ops.set_rnn_cu_limit(0)
+                enhanced = self.G(inputs)
+                prob = self.ASR(enhanced).transpose(0, 1)
+                costs = ops.ctc_scaled(prob, self.CTCLoss.blank, meta, 1.0 / N)
+                ops.set_rnn_cu_limit(knobs.get("AC_BWD_CUS"))
+                torch.autograd.backward([costs], [ops.unit_root(costs)])
+            finally:
+                ops.set_rnn_cu_limit(0)
+            ops.sync_wgrad()
+            optimizer_g.step_dev()
+            if asr_steps:
+                optimizer_asr.step_dev()
+                ops.refresh_weight_planes(self.ASR)
+            ops.refresh_weight_planes(self.G)
+            ops.began_step_raw(self._no_l1, 0.0, 0.0, costs.detach(), 1.0 / N, self._no_kt, self._acc, 0.0, 0.0, float(N))
+            self._acc_live = True
+            return dict(enhanced=enhanced, prob=prob, scalars=self._acc)
+        from .dist import DeviceCounts
+        cnt = DeviceCounts(self.dp, [N], dev, ops.refresh_stream(dev))
+        n_dev = cnt.get(0)
+        scale = (1.0 / n_dev).float()
         enhanced, prob, l_CTC, asr_steps = self._core(inputs, meta, scale, iter)
         self._opts[0].step_dev()
         if asr_steps:
             self._opts[1].step_dev()
             ops.refresh_weight_planes(self.ASR)
         ops.refresh_weight_planes(self.G)
-        l = l_CTC.detach().reshape(1).double()
-        if self.dp.active:
-            l = self.dp.reduce_scalars(l)     # every rank's loss is already divided by the global N
-        self._acc[0:1].copy_(l)
-        self._acc[1:2].add_(l * n_dev)
-        self._acc[2:3].add_(n_dev)
+        l = self.dp.reduce_scalars(l_CTC.detach().reshape(1).double())     # every rank's loss is already divided by the global N
+        self._acc[2:3].copy_(l)
+        self._acc[4:5].add_(l * n_dev)
+        self._acc[5:6].add_(n_dev)
         self._acc_live = True
         return dict(enhanced=enhanced, prob=prob, scalars=self._acc)
 
@@ -152,8 +174,8 @@ class Trainer(_AASTrainer):
         point - raises if a persistent kernel timed out or the run diverged."""
         if getattr(self, "_acc", None) is None:      # only synchronous train_step calls so far: nothing queued to read back
             return dict(l_ctc=getattr(self, "_last_sync_l_ctc", None))
-        l_ctc, s, n = self._acc.tolist()
-        self._acc[1:3].zero_()
+        _, _, l_ctc, _, s, n = self._acc.tolist()
+        self._acc[4:6].zero_()
         self._acc_live = False
         ops.check_rnn_health((l_ctc,))
         if n > 0:
@@ -188,43 +210,18 @@ class Trainer(_AASTrainer):
             if (iter + 1) % c.save_iter == 0:
                 if getattr(self, "_acc_live", False):
                     self.read_scalars()
-                if rank0:
-                    armed, ops.SYNC_BN[0] = ops.SYNC_BN[0], None
-                    try:
-                        self.validate_and_checkpoint(iter)
-                    finally:
-                        ops.SYNC_BN[0] = armed
-                if self.dp.active:
-                    self.dp.barrier()
-                    self.dp.broadcast_buffers(self.ASR, src=0)      # (rank 0's validation moved A's BatchNorm running statistics)
+                self._save_iter_block(iter)      # (rank 0 validates; rank 0's BatchNorm buffers of A to every rank afterwards)
 
     @ops.with_trainer_precision
     def greedy_decoding_and_AAS(self, inputs, targets, input_percentages, target_sizes, mask, transcript_prob=0.001):
         """Validation pass of trainer_acoustic.py:203-245: CTC and WER / CER only (the adversarial entries read 0)."""
-        import random
-
         from .utils import _get_variable_volatile
         inputs = _get_variable_volatile(inputs)
         N = inputs.size(0)
-        split_targets, offset = [], 0
-        for size in target_sizes:
-            split_targets.append(targets[offset:offset + int(size)])
-            offset += int(size)
         enhanced = self.G(inputs)
-        prob = self.ASR(enhanced).transpose(0, 1)
-        T = prob.size(0)
-        sizes = input_percentages.clone().mul_(int(T)).int()
-        decoded_output, _ = self.decoder.decode(prob.detach(), sizes)
-        target_strings = self.decoder.convert_to_strings(split_targets)
-        we = ce = total_word = total_char = 0
-        for x in range(len(target_strings)):
-            decoding, reference = decoded_output[x][0], target_strings[x][0]
-            we += self.decoder.wer(decoding, reference); ce += self.decoder.cer(decoding, reference)
-            total_word += len(reference.split()); total_char += len(reference)
-            if random.uniform(0, 1) < transcript_prob:
-                print("reference = " + reference); print("decoding = " + decoding)
+        prob, sizes, wer, cer, total_word, total_char = self._greedy_pass(enhanced, targets, input_percentages, target_sizes, transcript_prob)
         l_CTC = self.CTCLoss(prob, targets, sizes, target_sizes) / N
-        return l_CTC, 0.0, 1, we / max(total_word, 1), ce / max(total_word, 1), total_word, total_char
+        return l_CTC, 0.0, 1, wer, cer, total_word, total_char
 
 
 class _NoNet(torch.nn.Module):

@@ -25,12 +25,41 @@ extern "C" {
 
 typedef void* aasStream_t;
 
+/* ---------------------------------------------------------------- launch parameters -----------
+ * Queue-time settings exist at two levels.
+ * (1) PROCESS settings - aas_set_precision, aas_set_debug_flags, aas_set_rnn_cu_limit, aas_set_rnn_launch_tag, aas_set_gemm_max_steps,
+ *     aas_set_wgrad_wg_cap: what a single-threaded host (the reference trainer is one) needs; read when a launch is queued.
+ * (2) An aasLaunch: the same settings as a caller-owned struct, plus the row classes of a forward recurrent launch and the h-plane
+ *     pitch it reports.  Either passed to ONE call (aas_lstm_fwd_ex / aas_gru_fwd_ex / aas_lstm_bwd_ex / aas_gru_bwd_ex) or installed
+ *     for the calling THREAD with aas_launch_scope(): every launch that thread queues while it is installed - through any entry point
+ *     of this header - takes each field that is set from the struct and only the unset ones from the process settings.  The struct
+ *     stays the caller's: it may change fields between calls (e.g. the CU budget per phase of a training step) without another call
+ *     into the library.  Two host threads with a struct each - two trainers, a training and a validation model, autograd's backward
+ *     thread and the thread that queued the forward pass - cannot consume or overwrite each other's parameters.
+ *     aas_enhancement_amd/ops.py: LaunchState wraps one per trainer. */
+typedef struct aasLaunch {
+    int size;            /* sizeof(aasLaunch): checked, so that the struct can grow */
+    int precision;       /* 0 / 1 / 2 as aas_set_precision; -1 = the process setting */
+    int debug_flags;     /* as aas_set_debug_flags; -1 = the process setting */
+    int rnn_cu_limit;    /* CUs a persistent recurrent launch may occupy, 0 = the whole device; -1 = the process setting */
+    int rnn_tag;         /* >= 1: tag of the persistent recurrent launches (sticky error word); 0 = the process setting */
+    int gemm_max_steps;  /* as aas_set_gemm_max_steps, 0 = no cap; -1 = the process setting */
+    int wgrad_wg_cap;    /* as aas_set_wgrad_wg_cap; -1 = the process setting */
+    int cls_n_first;     /* row classes of the NEXT forward recurrent launch under this struct (see aas_set_rnn_row_classes): rows */
+    int cls_T_first;     /*   [0, cls_n_first) x cls_T_first frames, the rest x cls_T_rest; cls_n_first = -1: none.  The launch that */
+    int cls_T_rest;      /*   takes them sets cls_n_first back to -1. */
+    int fwd_h_pitch;     /* OUT: what aas_rnn_last_fwd_h_pitch() reports for the last forward recurrent launch under this struct */
+} aasLaunch;
+/* Install `l` (NULL: none) as the calling thread's launch scope; *prev (when prev != NULL) receives the one installed before, to be
+ * put back with a second call.  The struct must outlive its installation. */
+int aas_launch_scope(aasLaunch* l, aasLaunch** prev);
+
 int aas_version(void);
 const char* aas_last_error(void);
 /* number of CUs of the current device (persistent recurrent kernels size their grids from it) */
 int aas_device_cus(void);
-/* Debug / A-B bits (process-wide, read when a launch is queued; one host thread per process, like the reference
- * trainer).  Ablation bits - results are WRONG when one is set (profiling, and the timeout test):
+/* Debug / A-B bits (process setting, read when a launch is queued; per thread / per call: aasLaunch.debug_flags).
+ * Ablation bits - results are WRONG when one is set (profiling, and the timeout test):
  *   persistent recurrent kernels: 1 skip the exchange loads, 2 skip the MFMAs, 4 skip the wait / poll, 8 skip the
  *     publish stores (consumers then run into their bounded-spin timeout), 64 record phase time stamps;
  *   GEMM kernels: 16 skip the MFMAs, 32 skip the stores, 64 skip the loads, 128 epilogue only, 1 (aas_gemm_f32's LDS-DMA kernel) every
@@ -57,7 +86,9 @@ int aas_get_debug_flags(void);
  * up after ~0.5 s and stores the tag of its launch in a sticky error word at byte 4096 of the launch's `sync` buffer
  * (never cleared by the library): the host reads it at its next synchronisation point and names the layer. */
 int aas_set_rnn_launch_tag(int tag);
-/* Row classes of the NEXT aas_lstm_fwd / aas_gru_fwd launch (consumed by it; not by aas_rnn_fwd): batch rows [0, n_first) hold
+/* Row classes of the calling thread's NEXT aas_lstm_fwd / aas_gru_fwd launch (consumed by it; aas_rnn_fwd refuses them and drops
+ * them).  Kept for one round beside the argument form - aasLaunch.cls_* through aas_lstm_fwd_ex / aas_gru_fwd_ex - which is what
+ * the host side of this repository uses; the pending setting is thread-local.  Batch rows [0, n_first) hold
  * sequences of T_first frames, rows [n_first, N) of T_rest frames, in a launch of T = max(T_first, T_rest) whose input is anything
  * (e.g. zero padding) beyond a row's length.  The shorter class gets exactly what a launch of its own would give it: zero state
  * in front of its first frame in either direction, h = 0 beyond its last, and - through the stored gate values - zero gate
@@ -76,7 +107,7 @@ int aas_set_rnn_row_classes(int n_first, int T_first, int T_rest);
 int aas_rnn_xchg_prepare(aasStream_t stream, void* xchg, size_t bytes);
 int aas_rnn_xchg_forget(void* xchg);
 int aas_rnn_xchg_is_managed(void* xchg);   /* 1 while the buffer is managed (a fallen-back buffer may be prepared again) */
-/* > 0 when the LAST aas_lstm_fwd / aas_gru_fwd call left h_t of every time step but each direction's last one in its
+/* (Argument form: aasLaunch.fwd_h_pitch.)  > 0 when the calling thread's LAST aas_lstm_fwd / aas_gru_fwd call left h_t of every time step but each direction's last one in its
  * exchange buffer as operand planes (rows [2][T][N], this many bytes per row, interleaved hi | lo per 32 units, pad units
  * zero; the unpublished rows stay poisoned = NaN): the B operand of that layer's recurrent weight-gradient product
  * (aas_gemm_planes_tn).  0: fp32 kernels ran, or the batch was processed in several launches. */
@@ -208,6 +239,11 @@ int aas_split_planes_t2(aasStream_t stream, const float* src, int64_t ld, int64_
  * contiguous).  Replaces the .transpose() chains at model.py:222,227,328,331. */
 int aas_transpose_f32(aasStream_t stream, const float* in, float* out, int B, int R, int C,
                       int64_t isb, int64_t isr, int64_t osb, int64_t osc);
+/* out[b, c, r] += in[b, r, c], same addressing: a weight gradient computed in the GEMM's [M, KW*F] layout ADDED into the parameter's
+ * .grad in the module's [M, F, KW] layout (nn.Conv1d weight, model.py:289,297) - what autograd's gradient accumulation would do
+ * with a transposed copy and an add. */
+int aas_transpose_add_f32(aasStream_t stream, const float* in, float* out, int B, int R, int C,
+                          int64_t isb, int64_t isr, int64_t osb, int64_t osc);
 /* out[b, a, :] = in[a, b, :]  ([A,B,C] -> [B,A,C], C contiguous): N,T,C <-> T,N,C (model.py:328,331) */
 int aas_swap01_f32(aasStream_t stream, const float* in, float* out, int A, int B, int C);
 /* out = a + b (+ c if c != NULL), n elements.  Direction sum + residual (model.py:85,104,223-226). */
@@ -294,6 +330,19 @@ int aas_gru_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const
 int aas_gru_bwd(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh,
                 const float* w_hh_rev, const float* hout, const float* gact, float* dgx, float* dgh, void* sync,
                 void* xchg);
+
+/* The four launches with their parameters as an ARGUMENT: *launch carries the row classes of the forward launch (consumed by it),
+ * the CU budget, the launch tag, the kernel-selection bits and the arithmetic mode FOR THIS CALL (unset fields: the process
+ * settings) and receives fwd_h_pitch; nothing process-wide is written.  launch = NULL: exactly the plain entry point.  What
+ * nn.LSTM / nn.GRU's per-call arguments are to the reference (model.py:73-74,94-95,102-104): no state between calls. */
+int aas_lstm_fwd_ex(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh, const float* w_hh_rev, float* hout,
+                    float* gact, float* cst, void* sync, void* xchg, aasLaunch* launch);
+int aas_lstm_bwd_ex(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
+                    const float* gact, const float* cst, float* dgates, void* sync, void* xchg, aasLaunch* launch);
+int aas_gru_fwd_ex(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh, const float* w_hh_rev, float* hout,
+                   float* gact, void* sync, void* xchg, aasLaunch* launch);
+int aas_gru_bwd_ex(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
+                   const float* hout, const float* gact, float* dgx, float* dgh, void* sync, void* xchg, aasLaunch* launch);
 
 /* ---------------------------------------------------------------- batch norm (train mode) -----
  * Rows-by-channels BatchNorm with batch statistics (nn.BatchNorm1d in train mode: model.py:72,82
@@ -424,6 +473,19 @@ int aas_began_step(aasStream_t stream, const float* d_l_adv_ny_G, const float* d
  * L_ctc = scale_ctc * sum(costs) (w_acoustic / N, :168); each rounded to fp32 as the tensors of the reference are. */
 int aas_began_step_raw(aasStream_t stream, const double* d_l1_sums, double scale_ny, double scale_cl, const float* d_ctc_costs, int n_costs,
                        double scale_ctc, double* d_kt, double* d_out6, double gamma, double lambda_k, double n_batch);
+/* The controller from THREE raw device sums (trainer_FSEGAN.py:175-179: the third logged loss is the DCE sum; data parallel: the sums
+ * all-reduced over the ranks and the normalisers device scalars): L_0 = s0 f_0 d_l1_sums[0] (noisy adversarial), L_1 = s1 f_1 d_l1_sums[1]
+ * (clean adversarial), L_2 = s2 f_2 d_third[0] (the third loss), f_i = d_scales3 ? d_scales3[i] : 1; n_batch from d_n_batch[0] when that is
+ * not NULL.  d_out6 as aas_began_step. */
+int aas_began_step_sums(aasStream_t stream, const double* d_l1_sums, const double* d_third, double s0, double s1, double s2,
+                        const float* d_scales3, double* d_kt, double* d_out6, double gamma, double lambda_k, double n_batch,
+                        const double* d_n_batch);
+/* d_out3 = [d_l1_sums[0], d_l1_sums[1], sum(d_ctc_costs[0 .. n_costs))]: the three raw loss sums of an AAS step (trainer_AAS.py:146-177) in
+ * one buffer - what a data-parallel step all-reduces before the controller (aas_began_step_sums). */
+int aas_loss_pack(aasStream_t stream, const double* d_l1_sums, const float* d_ctc_costs, int n_costs, double* d_out3);
+/* d_out[i] = (float)(weights[i] / d_counts[index[i]]), i < n <= 4: the loss normalisers (w_adversarial / nElement, w_acoustic / N:
+ * model.py:30, trainer_AAS.py:147,168,177) from device-resident (all-reduced) counts, in one launch; weights / index are host arrays. */
+int aas_scales_from_counts(aasStream_t stream, const double* d_counts, int n, const double* weights, const int* index, float* d_out);
 /* Start of a training step in ONE launch: zero up to 8 device buffers (16-byte aligned; the flat gradient buffers = zero_grad_all,
  * trainer_AAS.py:134, and the loss accumulators) and, when rs != NULL, write the per-utterance weights of the batched
  * [enhanced; clean] discriminator pass: rs[0 .. n_neg) = -(float) d_kt[0] (the D-step factor, :156-160), rs[n_neg .. n_neg + n_one) = 1. */
