@@ -29,6 +29,11 @@ SIGNATURES = {
     "aas_rnn_xchg_forget": [c_vp],
     "aas_rnn_xchg_is_managed": [c_vp],
     "aas_release_retired_workspaces": [],
+    "aas_launch_scope": [c_vp, c_vp],
+    "aas_lstm_fwd_ex": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "aas_lstm_bwd_ex": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "aas_gru_fwd_ex": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "aas_gru_bwd_ex": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "aas_set_precision": [c_int],
     "aas_set_rnn_launch_tag": [c_int],
     "aas_set_rnn_row_classes": [c_int, c_int, c_int],

@@ -58,7 +58,7 @@ class AMTrainer(ops.TrainerContext):
         self.dp = dp or DPContext.from_env()
         self._reducer = BucketReducer(self.dp, [self.flat]) if self.dp.active else None
         # data parallel: BatchNorm statistics over the GLOBAL batch (default: local-batch statistics per rank)
-        ops.SYNC_BN[0] = self.dp if (self.dp.active and sync_bn) else None
+        self.launch.sync_bn = self.dp if (self.dp.active and sync_bn) else None
         self.decoder = GreedyDecoder(labels if labels is not None else DeepSpeech.get_labels(model))
         self.losses = AverageMeter()
 
@@ -79,7 +79,7 @@ class AMTrainer(ops.TrainerContext):
         self.flat.zero_grad()
         if self._reducer is not None:
             self._reducer.begin()
-            ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
+            self.launch.wgrad_hook = self._reducer.on_wgrad
         try:
             out = self.model(inputs).transpose(0, 1)
             loss = self.criterion(out, targets, sizes, target_sizes, prepared=meta)
@@ -91,7 +91,7 @@ class AMTrainer(ops.TrainerContext):
                 self._reducer.flush(self.flat)
                 self._reducer.wait()
         finally:
-            ops.WGRAD_HOOK[0] = None
+            self.launch.wgrad_hook = None
             ops.set_rnn_cu_limit(0)
         v = self.dp.reduce_scalars(loss.detach().reshape(1).clone())
         loss_value = float(v)                                  # host read-back: a synchronisation point
@@ -126,7 +126,7 @@ class AMTrainer(ops.TrainerContext):
         ops.sync_wgrad()
         self.flat.zero_grad()
         self._reducer.begin()
-        ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
+        self.launch.wgrad_hook = self._reducer.on_wgrad
         try:
             ops.set_rnn_cu_limit(_fwd_cus())
             out = self.model(inputs).transpose(0, 1)
@@ -138,7 +138,7 @@ class AMTrainer(ops.TrainerContext):
             self._reducer.flush(self.flat)
             self._reducer.wait()
         finally:
-            ops.WGRAD_HOOK[0] = None
+            self.launch.wgrad_hook = None
             ops.set_rnn_cu_limit(0)
         v = self.dp.reduce_scalars(loss.detach().reshape(1).clone())
         self.opt.step_dev()

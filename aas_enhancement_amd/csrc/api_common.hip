@@ -63,6 +63,10 @@ int aas_scope_check(const aasLaunch* l, const char* who) {
     }
     return 0;
 }
+std::recursive_mutex& aas_rnn_launch_mutex() {
+    static std::recursive_mutex mu;
+    return mu;
+}
 int aas_scope_gemm_max_steps() { return (t_scope && t_scope->gemm_max_steps >= 0) ? t_scope->gemm_max_steps : -1; }
 
 namespace {

@@ -1,6 +1,7 @@
 // Shared host/device helpers for libaas_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -39,6 +40,11 @@ struct AasScopeGuard {
     bool on_;
 };
 int aas_scope_check(const aasLaunch* l, const char* who);
+// Held by every persistent recurrent entry point from its first bookkeeping step (exchange-buffer plan, sync-buffer use) until its
+// kernels are queued: with two host threads launching onto one stream / one managed exchange buffer, the order in which the buffer's
+// halves were planned is then the order in which the launches sit in the stream.  Recursive: the *_ex forms call the plain ones.
+std::recursive_mutex& aas_rnn_launch_mutex();
+#define AAS_RNN_LAUNCH_LOCK() std::lock_guard<std::recursive_mutex> aas_rnn_lock__(aas_rnn_launch_mutex())
 int aas_scope_gemm_max_steps();   // >= 0: the installed scope's lifetime cap of GEMM workgroups; -1: none installed / not set
 int aas_rnn_launch_tag_value();  // >= 1: what a timed-out persistent launch leaves in its sticky error word
 // gemm32.hip: the LDS-DMA fp32 GEMM; -> 0 launched, 1 error, -1 not applicable to these operands (take the general kernel)

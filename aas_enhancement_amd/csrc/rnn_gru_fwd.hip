@@ -2,6 +2,7 @@
 
 extern "C" int aas_gru_fwd(aasStream_t stream, int T, int N, int H, const float* pre, const float* w_hh, const float* w_hh_rev, float* hout,
                            float* gact, void* sync, void* xchg) {
+    AAS_RNN_LAUNCH_LOCK();
     RnnP p = {};
     // (first: the one-shot setting is consumed by THIS call whatever happens next)
     if (aas_rnn_row_classes_take("aas_gru_fwd", T, N, &p.cls_n, &p.cls_t0, &p.cls_t1)) return 1;

@@ -14,8 +14,20 @@ from ._lib import check, lib, ptr, require_cuda, stream
 NT, NN, TN = 0, 1, 2
 
 _scratch = {}
+_scratch_lock = __import__("threading").RLock()     # two trainers in two host threads may size the same stream's scratch at once
 
 
+def _locked(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with _scratch_lock:
+            return fn(*a, **k)
+    return wrapped
+
+
+@_locked
 def _sync_buf(dev):
     """zero-initialised arrival-counter scratch for the persistent RNN kernels (per device+stream)."""
     key = ("sync", dev, torch.cuda.current_stream().cuda_stream)
@@ -84,6 +96,7 @@ def check_rnn_health(scalars=()):
         raise FloatingPointError("training diverged: non-finite loss scalars %r" % (list(scalars),))
 
 
+@_locked
 def _xchg_buf(dev, T, N, H, G, kind="any"):
     """Exchange scratch of the persistent RNN kernels, per device + stream (+ kind), grown on demand.
     kind "fwd" / "bwd": a MANAGED buffer (include/aas_hip.h: aas_rnn_xchg_prepare) - twice the size a launch needs, poison-filled
@@ -116,6 +129,7 @@ def _xchg_buf(dev, T, N, H, G, kind="any"):
     return b
 
 
+@_locked
 def _wsd(dev, n):
     key = ("wsd", dev, torch.cuda.current_stream().cuda_stream)
     b = _scratch.get(key)
@@ -129,7 +143,111 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-_precision = [int(__import__('os').environ.get('AAS_PRECISION', '0'))]
+# ---- launch state: the queue-time settings of ONE trainer (or of the process, when none is installed) --------------------------------
+import ctypes as _ct
+import threading as _threading
+
+
+class _CLaunch(_ct.Structure):
+    """include/aas_hip.h: aasLaunch"""
+    _fields_ = [(n, _ct.c_int) for n in ("size", "precision", "debug_flags", "rnn_cu_limit", "rnn_tag", "gemm_max_steps", "wgrad_wg_cap",
+                                        "cls_n_first", "cls_T_first", "cls_T_rest", "fwd_h_pitch")]
+
+
+def _new_claunch():
+    return _CLaunch(_ct.sizeof(_CLaunch), -1, -1, -1, 0, -1, -1, -1, 0, 0, 0)
+
+
+class LaunchState(object):
+    """Everything the library and this module read when a launch is QUEUED, owned by one trainer: the arithmetic mode, the lifetime
+    cap of GEMM workgroups, the kernel-selection (debug) bits, the CU budget of the persistent recurrent launches, and the host-side
+    switches of a training step - held-back weight-gradient products (`defer_wgrad`, `defer_lids`, the queue `deferred`), the
+    data-parallel hook run behind a layer's weight-gradient products (`wgrad_hook`), the SyncBN context (`sync_bn`).
+
+    `c` is an `aasLaunch` (include/aas_hip.h).  `launch_state(st)` installs the state for the calling THREAD - in this module
+    (`state()`) and in the library (`aas_launch_scope`) - and puts the previous one back; the trainers' entry points run under it
+    (`with_trainer_precision`), and every autograd function below records the state its forward ran under and runs its backward
+    under the same one, on whichever thread autograd executes it.  The recurrent launches receive the struct as an argument
+    (`aas_*_ex`).  So two trainers in one process - in one thread or in two - never queue a launch under each other's settings;
+    nothing here is a process-wide cell that one call sets and a later call consumes.  An unset field (None / -1) falls through to
+    the process setting (`ops.set_precision`, `aas_set_debug_flags`, ...), which is what code outside any trainer sees."""
+
+    def __init__(self, gemm_max_steps=None, debug_flags=None, precision=None):
+        self.c = _new_claunch()
+        self.gemm_max_steps, self.debug_flags, self.precision = gemm_max_steps, debug_flags, precision
+        self.defer_wgrad, self.defer_lids, self.deferred = False, set(), []
+        self.wgrad_hook = None      # callable(list of .grad views) run on the side stream after a layer's products are queued
+        self.sync_bn = None         # a dist.DPContext: train-mode BatchNorm statistics are all-reduced over the ranks (SyncBN, SURVEY 8e)
+
+    def _field(name):   # noqa: N805  (a property per struct field: None <-> "unset")
+        unset = 0 if name == "rnn_tag" else -1
+        return property(lambda self: (None if getattr(self.c, name) == unset else getattr(self.c, name)),
+                        lambda self, v: setattr(self.c, name, unset if v is None else int(v)))
+    gemm_max_steps, debug_flags, precision, rnn_cu_limit = _field("gemm_max_steps"), _field("debug_flags"), _field("precision"), _field("rnn_cu_limit")
+    del _field
+
+
+_PROCESS = LaunchState()     # "no trainer installed": every field unset - the process settings apply
+_process_precision = [int(__import__('os').environ.get('AAS_PRECISION', '0'))]
+_tls = _threading.local()
+
+
+def state():
+    """The LaunchState installed for this thread (`launch_state`), else the process-level one."""
+    return getattr(_tls, "state", None) or _PROCESS
+
+
+def _launch_arg(tag, row_len=None):
+    """-> ctypes reference to the aasLaunch a recurrent launch is called with: the installed state's struct, or this thread's scratch
+    struct (all settings unset: the process settings apply) - with the launch tag and the row classes of THIS launch filled in."""
+    st = state()
+    if st is _PROCESS:
+        c = getattr(_tls, "scratch", None)
+        if c is None:
+            c = _tls.scratch = _new_claunch()
+    else:
+        c = st.c
+    c.rnn_tag = int(tag)
+    if row_len is not None:
+        c.cls_n_first, c.cls_T_first, c.cls_T_rest = int(row_len[0]), int(row_len[1]), int(row_len[2])
+    else:
+        c.cls_n_first = -1
+    return c
+
+
+class launch_state(object):
+    """`with launch_state(st):` - install `st` for this thread (None / the process-level state: nothing installed), previous one back
+    on exit.  Re-entrant; cheap (two library calls)."""
+
+    def __init__(self, st):
+        self.st = None if st is _PROCESS else st
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "state", None)
+        if self.st is not self.prev:
+            _tls.state = self.st
+            check(lib().aas_launch_scope(_ct.byref(self.st.c) if self.st is not None else None, None), "aas_launch_scope")
+        return self
+
+    def __exit__(self, *exc):
+        if self.st is not self.prev:
+            _tls.state = self.prev
+            lib().aas_launch_scope(_ct.byref(self.prev.c) if self.prev is not None else None, None)
+        return False
+
+
+class _PrecisionCell(object):
+    """`_precision[0]`: the arithmetic mode launches are queued in right now, on this thread (the installed state's, else the process's)."""
+
+    def __getitem__(self, i):
+        p = state().precision
+        return _process_precision[0] if p is None else p
+
+    def __setitem__(self, i, v):
+        set_precision(v)
+
+
+_precision = _PrecisionCell()
 
 
 def set_precision(mode):
@@ -141,9 +259,17 @@ def set_precision(mode):
     budget); 2 = fp32-EQUIVALENT: small GEMMs and recurrent products as in mode 0, EXCEPT the 500-unit LSTM's BPTT, which runs the
     six-product bf16 kernel; the large GEMMs as six bf16 products of three-term operands (all 24 operand bits, dropped cross terms
     <= 2^-25: `gemm_planes6`).  `--precision` of main.py / am_train.py and the AAS_PRECISION environment variable select it for a whole
-    run; a trainer keeps the mode it was built in (`Trainer.precision`, `ops.precision`)."""
-    check(lib().aas_set_precision(int(mode)), "aas_set_precision")
-    _precision[0] = int(mode)
+    run; a trainer keeps the mode it was built in (`Trainer.precision`, `ops.precision`).  Inside an installed LaunchState the call
+    changes THAT state only; outside, the process setting."""
+    mode = int(mode)
+    if mode not in (0, 1, 2):
+        raise RuntimeError("set_precision: mode must be 0 (fp32), 1 (split-bf16) or 2 (fp32-equivalent), got %r" % (mode,))
+    st = state()
+    if st is _PROCESS:
+        check(lib().aas_set_precision(mode), "aas_set_precision")
+        _process_precision[0] = mode
+    else:
+        st.precision = mode
 
 
 def get_precision():
@@ -160,66 +286,67 @@ class precision(object):
         self.mode = mode
 
     def __enter__(self):
-        self.prev = _precision[0]
+        self.st = state()
+        self.prev = self.st.precision if self.st is not _PROCESS else _process_precision[0]
         if self.mode is not None and int(self.mode) != self.prev:
             set_precision(self.mode)
         return self
 
     def __exit__(self, *exc):
-        if _precision[0] != self.prev:
-            set_precision(self.prev)
-        return False
-
-
-class LaunchState(object):
-    """The library's queue-time settings that belong to ONE trainer (beside its arithmetic mode): the lifetime cap of its GEMM
-    workgroups and the kernel-selection (debug) bits.  The library keeps them process-wide and reads them when a launch is queued;
-    a trainer's entry points run under `launch_state(self.launch)`, which installs its values and puts the previous ones back - so a
-    validation model and a training model in one process, or two trainers built with different settings, never queue a launch under
-    each other's.  (The CU budget of the persistent launches and the launch tag are set per phase / per launch inside a step and
-    never outlive it.)  None = leave the library's current value alone."""
-    __slots__ = ("gemm_max_steps", "debug_flags")
-
-    def __init__(self, gemm_max_steps=None, debug_flags=None):
-        self.gemm_max_steps, self.debug_flags = gemm_max_steps, debug_flags
-
-
-class launch_state(object):
-    def __init__(self, st):
-        self.st = st
-
-    def __enter__(self):
-        self.prev = None
-        st = self.st
-        if st is not None and (st.gemm_max_steps is not None or st.debug_flags is not None):
-            L = lib()
-            self.prev = (int(L.aas_get_gemm_max_steps()), int(L.aas_get_debug_flags()))
-            if st.gemm_max_steps is not None and int(st.gemm_max_steps) != self.prev[0]:
-                L.aas_set_gemm_max_steps(int(st.gemm_max_steps))
-            if st.debug_flags is not None and int(st.debug_flags) != self.prev[1]:
-                L.aas_set_debug_flags(int(st.debug_flags))
-        return self
-
-    def __exit__(self, *exc):
-        if self.prev is not None:
-            L = lib()
-            if int(L.aas_get_gemm_max_steps()) != self.prev[0]:
-                L.aas_set_gemm_max_steps(self.prev[0])
-            if int(L.aas_get_debug_flags()) != self.prev[1]:
-                L.aas_set_debug_flags(self.prev[1])
+        if self.st is _PROCESS:
+            if _process_precision[0] != self.prev:
+                set_precision(self.prev)
+        else:
+            self.st.precision = self.prev
         return False
 
 
 def with_trainer_precision(fn):
-    """Decorator for trainer entry points: run under the trainer's own arithmetic mode (`self.precision`) and launch settings
-    (`self.launch`, a LaunchState)."""
+    """Decorator for trainer entry points: run under the trainer's own launch state (`self.launch`, a LaunchState) in its own
+    arithmetic mode (`self.precision`)."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(self, *a, **k):
-        with precision(getattr(self, "precision", None)), launch_state(getattr(self, "launch", None)):
+        with launch_state(getattr(self, "launch", None)):      # (the state carries the trainer's arithmetic mode: TrainerContext.precision)
             return fn(self, *a, **k)
     return wrapped
+
+
+def _scoped(cls):
+    """Class decorator for the autograd functions of this module: forward records the LaunchState it ran under, backward runs under
+    the same one - autograd executes backward nodes on its own thread, where nothing is installed."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *a, **k):
+        ctx.launch = state()
+        return fwd(ctx, *a, **k)
+
+    def backward(ctx, *g):
+        st = ctx.launch
+        if st is state():
+            return bwd(ctx, *g)
+        with launch_state(st):
+            return bwd(ctx, *g)
+    forward.__doc__, backward.__doc__ = fwd.__doc__, bwd.__doc__
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
+class RowWeights(object):
+    """Per-utterance parameters of a batched pass, as ONE explicit argument (`wgrad_row_scale=` of the modules, `rs=` of the layer
+    ops): `w` - a device vector [N] of weights applied to the PARAMETER gradients only (None: all ones); `classes` - the utterance
+    classes [(first row, rows, weight as a device scalar or None), ...] the vector consists of, for the weight-gradient products that
+    run once per class with the weight as their alpha; `row_len` = (n_first, T_first, T_rest) - two row classes of different sequence
+    length inside the recurrent launches (ragged noisy / clean pair, include/aas_hip.h: aasLaunch.cls_*)."""
+    __slots__ = ("w", "classes", "row_len")
+
+    def __init__(self, w=None, classes=None, row_len=None):
+        self.w, self.classes, self.row_len = w, classes, (tuple(int(v) for v in row_len) if row_len is not None else None)
+
+    @staticmethod
+    def of(x):
+        return x if (x is None or isinstance(x, RowWeights)) else RowWeights(x)
 
 
 class TrainerContext(object):
@@ -227,8 +354,28 @@ class TrainerContext(object):
     one way to switch the mode that also refreshes the cached weight operand planes of its networks."""
 
     def _init_context(self):
-        self.precision = get_precision()
-        self.launch = LaunchState()
+        self.launch = LaunchState(precision=get_precision())     # the mode in force when the trainer is built
+
+    @property
+    def launch(self):
+        """This trainer's LaunchState (every entry point runs under it)."""
+        return self._launch
+
+    @launch.setter
+    def launch(self, st):
+        old = getattr(self, "_launch", None)
+        if old is not None and st.precision is None:      # a replacement state that names no arithmetic mode keeps the trainer's
+            st.precision = old.precision
+        self._launch = st
+
+    @property
+    def precision(self):
+        """The arithmetic mode this trainer runs in (a field of its launch state)."""
+        return self.launch.precision
+
+    @precision.setter
+    def precision(self, mode):
+        self.launch.precision = int(mode)
 
     def _context_networks(self):
         return [m for m in (getattr(self, n, None) for n in ("G", "D", "ASR", "model")) if m is not None]
@@ -237,7 +384,7 @@ class TrainerContext(object):
         """Switch this trainer to another arithmetic mode (0 fp32 / 1 split-bf16 / 2 fp32-equivalent) and bring the cached weight
         operand planes of its networks up to date for it, off the critical path."""
         self.precision = int(mode)
-        with precision(self.precision):
+        with launch_state(self.launch):
             for net in self._context_networks():
                 if any(True for _ in net.parameters()):
                     refresh_weight_planes(net)
@@ -267,13 +414,24 @@ class TrainerContext(object):
 
 
 def set_rnn_cu_limit(cus):
-    """Cap the CUs of every persistent recurrent launch queued from now on (0 = whole device)."""
-    check(lib().aas_set_rnn_cu_limit(int(cus)), "aas_set_rnn_cu_limit")
+    """Cap the CUs of every persistent recurrent launch queued from now on under the installed launch state (0 / None = whole
+    device); without one: the process setting."""
+    st = state()
+    if st is _PROCESS:
+        check(lib().aas_set_rnn_cu_limit(int(cus or 0)), "aas_set_rnn_cu_limit")
+    else:
+        if cus is not None and int(cus) < 0:
+            raise RuntimeError("set_rnn_cu_limit: negative limit")
+        st.rnn_cu_limit = int(cus or 0)
 
 
 def set_wgrad_cap(workgroups):
     """Grid cap of the row-major weight-gradient GEMMs queued from now on (0 = none); include/aas_hip.h: aas_set_wgrad_wg_cap."""
-    lib().aas_set_wgrad_wg_cap(int(workgroups))
+    st = state()
+    if st is _PROCESS:
+        lib().aas_set_wgrad_wg_cap(int(workgroups))
+    else:
+        st.c.wgrad_wg_cap = max(0, int(workgroups))
 
 
 def device_cus():
@@ -287,7 +445,7 @@ def device_cus():
 # layer's persistent BPTT launch instead of sitting on the backward critical path.  sync_wgrad() joins.
 DIRECT_WGRAD = [True]    # kill switch; the path is taken only for parameters re-homed by dist.FlatBuffers (_aas_flat_grad)
 LINEAR_DIRECT = [knobs.get("LINEAR_DIRECT")]   # pointwise linear layers take the same side-stream path
-WGRAD_HOOK = [None]      # callable(list of .grad views) run on the side stream after a layer's products are queued
+# (LaunchState.wgrad_hook: callable(list of .grad views) run on the side stream after a layer's products are queued)
 _SKIP_WGRAD = [knobs.get("SKIP_WGRAD")]   # timing experiment only (knobs.py): never set in a product run
 _wgrad_streams = {}
 
@@ -383,14 +541,15 @@ def wgrad_stream(dev):
 # A trainer may hold back the weight-gradient products of a backward pass (DEFER_WGRAD) and release them later with
 # flush_deferred_wgrad(): the products are HBM-heavy and, queued beside a latency-bound BPTT chain that is on the step's
 # critical path, they slow its cross-CU exchange (D's BPTT launches at N=60: 0.96 ms alone, up to 1.9 ms beside them).
-DEFER_WGRAD = [False]
-DEFER_LIDS = set()       # layer ids (model.py: _aas_layer_id) whose products are held back even when DEFER_WGRAD is off
-_deferred = []
+# LaunchState.defer_wgrad / .defer_lids (layer ids - model.py: _aas_layer_id - whose products are held back even when defer_wgrad is
+# off) / .deferred (the queue).
 
 
 def flush_deferred_wgrad():
-    """Queue the held-back weight-gradient products (on the weight-gradient stream, in the order they were produced)."""
-    todo, _deferred[:] = list(_deferred), []
+    """Queue the held-back weight-gradient products of the installed launch state (on the weight-gradient stream, in the order they
+    were produced)."""
+    st = state()
+    todo, st.deferred[:] = list(st.deferred), []
     for fn in todo:
         fn()
 
@@ -408,18 +567,22 @@ class _wgrad_gemm_cap(object):
 
     def __enter__(self):
         cap = knobs.get("WGRAD_MAXSTEPS")
-        self.prev = None
+        self.st = None
         if cap is not None:
-            self.prev = int(lib().aas_get_gemm_max_steps())
-            if self.prev != int(cap):
+            st = state()
+            if st is _PROCESS:
+                self.prev = int(lib().aas_get_gemm_max_steps())
                 lib().aas_set_gemm_max_steps(int(cap))
             else:
-                self.prev = None
+                self.prev, st.gemm_max_steps = st.gemm_max_steps, int(cap)
+            self.st = st
         return self
 
     def __exit__(self, *exc):
-        if self.prev is not None:
+        if self.st is _PROCESS:
             lib().aas_set_gemm_max_steps(self.prev)
+        elif self.st is not None:
+            self.st.gemm_max_steps = self.prev
         return False
 
 
@@ -746,6 +909,7 @@ def swap01(x):  # [A,B,C] -> [B,A,C]
     return out
 
 
+@_scoped
 class _Layout(torch.autograd.Function):
     """Differentiable layout change; backward applies the inverse permutation."""
     FWD = {"nct_tnc": nct_to_tnc, "tnc_nct": tnc_to_nct, "nct_ntc": nct_to_ntc, "ntc_nct": ntc_to_nct, "swap01": swap01}
@@ -766,6 +930,7 @@ def layout(x, kind):
     return _Layout.apply(x, kind)
 
 
+@_scoped
 class _LayoutCatNCT(torch.autograd.Function):
     """[a ; b] along the batch axis and [N,C,T] -> [T,N,C] in one step: two transposing launches straight into the halves of the
     time-major tensor instead of a concatenated copy and a transpose of it (the batched [enhanced; clean] discriminator input).
@@ -801,6 +966,7 @@ def layout_cat_nct_tnc(a, b):
     return _LayoutCatNCT.apply(a, b)
 
 
+@_scoped
 class _LayoutPairedCat(torch.autograd.Function):
     """The FSEGAN discriminator's batched input in one step: rows [0, N) = (leaf | mixture), rows [N, 2N) = (cleans | mixture) -
     `forward_paired` (model.py:233-238: cat along the feature axis) for both halves of the batch - laid down time-major
@@ -835,6 +1001,7 @@ def layout_paired_cat(leaf, mixture, cleans):
 
 
 # --------------------------------------------------------------------------------------- linear
+@_scoped
 class _LinearRows(torch.autograd.Function):
     """y[..., N] = x[..., K] W[N,K]^T (+ b) on the flattened leading dims."""
 
@@ -847,7 +1014,8 @@ class _LinearRows(torch.autograd.Function):
         y = linear_fwd(x2, W2, _c(b) if b is not None else None)
         ctx.save_for_backward(x2, W2)
         ctx.params = (W, b)          # the nn.Parameters themselves (direct accumulation into their flat-buffer .grad)
-        ctx.rs, ctx.nb = rs, (x.shape[1] if x.dim() == 3 else 1)
+        rs = RowWeights.of(rs)
+        ctx.rs, ctx.nb = (rs.w if rs is not None else None), (x.shape[1] if x.dim() == 3 else 1)
         ctx.wshape = W.shape
         ctx.has_b = b is not None
         ctx.xshape = x.shape
@@ -887,8 +1055,8 @@ class _LinearRows(torch.autograd.Function):
                         check(lib().aas_colsum_f32(stream(), ptr(g2), R_, N_, N_, ptr(gb), 1), "aas_colsum_f32")
             for t_ in (gy2, x2):
                 t_.record_stream(side)
-            if DEFER_WGRAD[0]:
-                _deferred.append(run)
+            if state().defer_wgrad:
+                state().deferred.append(run)
             else:
                 run()
             return (dx.view(ctx.xshape) if dx is not None else None), None, None, None
@@ -1086,7 +1254,7 @@ TN_WGRAD = [knobs.get("TN_WGRAD")]   # weight-gradient products from row-major p
 
 def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None, row_len=None):
     """x [T,N,I] -> (hout[2,T,N,H], gact, cst).  row_len = (n_first, T_first, T_rest): two row classes of different sequence length
-    in one launch (aas_set_rnn_row_classes; lstm / gru).  keep: a dict that receives what the layer's weight-gradient products can
+    in one launch (aasLaunch.cls_*; lstm / gru).  keep: a dict that receives what the layer's weight-gradient products can
     reuse: 'xp' = the input's operand planes, 'hx' / 'hpitch' = the forward launch's exchange buffer (h_t as planes)."""
     T, N, I = x.shape
     G = _GATES[kind]
@@ -1132,30 +1300,41 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None, row_len=No
     else:
         xchg = _xchg_buf(dev, T, N, H, G, "fwd" if (_precision[0] != 1 and knobs.get("MANAGED_XCHG")) else "any")
     rflops = 2.0 * 2 * T * N * H * G * H  # both directions, T steps of [N,H]x[H,G*H]
-    lib().aas_set_rnn_launch_tag(2 * lid if lid else 1)
-    if row_len is not None:
-        if kind == "rnn":
-            raise NotImplementedError("row classes of different length: lstm / gru layers only")
-        check(lib().aas_set_rnn_row_classes(int(row_len[0]), int(row_len[1]), int(row_len[2])), "aas_set_rnn_row_classes")
+    tag = 2 * lid if lid else 1
     if kind == "rnn":
+        if row_len is not None:
+            raise NotImplementedError("row classes of different length: lstm / gru layers only")
+        _set_tag(tag)
         with _timed("rnn", "rnn_fwd[N=%d,H=%d]" % (N, H), rflops, T):
             check(lib().aas_rnn_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync)), "aas_rnn_fwd")
         return hout, gact, None
+    # the launch parameters travel as an ARGUMENT (include/aas_hip.h: aasLaunch): tag, row classes, and - from the installed state -
+    # CU budget, kernel-selection bits, arithmetic mode; the h-plane pitch comes back in the same struct
+    la = _launch_arg(tag, row_len)
     if kind == "lstm":
         cst = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
         with _timed("rnn", "lstm_fwd[N=%d,H=%d]" % (N, H), rflops, T):
-            check(lib().aas_lstm_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(cst),
-                                     ptr(sync), ptr(xchg)), "aas_lstm_fwd")
+            check(lib().aas_lstm_fwd_ex(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(cst),
+                                        ptr(sync), ptr(xchg), _ct.byref(la)), "aas_lstm_fwd_ex")
     else:
         cst = None
         with _timed("rnn", "gru_fwd[N=%d,H=%d]" % (N, H), rflops, T):
-            check(lib().aas_gru_fwd(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync),
-                                    ptr(xchg)), "aas_gru_fwd")
+            check(lib().aas_gru_fwd_ex(stream(), T, N, H, ptr(pre), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(sync),
+                                       ptr(xchg), _ct.byref(la)), "aas_gru_fwd_ex")
     if keep is not None and _precision[0] == 1:
-        pitch = int(lib().aas_rnn_last_fwd_h_pitch())
+        pitch = int(la.fwd_h_pitch)
         if pitch > 0:
             keep["hx"], keep["hpitch"] = xchg, pitch
     return hout, gact, cst
+
+
+def _set_tag(tag):
+    """Launch tag of the recurrent launches that do not take an aasLaunch argument (the plane-emitting BPTT variants, nn.RNN)."""
+    st = state()
+    if st is _PROCESS:
+        lib().aas_set_rnn_launch_tag(int(tag))
+    else:
+        st.c.rnn_tag = int(tag)
 
 
 def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residual, need_dx=True, need_dw=True, rs=None,
@@ -1175,7 +1354,11 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     use_planes6 = (_precision[0] == 2 and kind != "rnn" and PLANES_BWD[0] and R >= 1024 and H >= 64 and I >= 64 and GH % 8 == 0
                    and w_ih_r.data_ptr() != w_ih.data_ptr() and (w_ih_r.data_ptr() - w_ih.data_ptr()) % 4 == 0)
     rflops = 2.0 * 2 * T * N * H * GH
-    lib().aas_set_rnn_launch_tag(2 * lid + 1 if lid else 1)
+    tag = 2 * lid + 1 if lid else 1
+    _set_tag(tag)
+    rs = RowWeights.of(rs)
+    rsw = rs.w if rs is not None else None            # the per-utterance weight vector (device) or None
+    classes_of = lambda: [(0, N, None)] if rs is None else rs.classes
     # d(gates) straight in the operand form of the layer's GEMMs (row-major bf16 hi|lo planes) when the plane path is taken:
     # no fp32 copy and no split pass between the BPTT launch and the input-gradient GEMM
     dgx = dgh = dgp = dghp = None
@@ -1216,14 +1399,14 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
             dgh = dgx
         elif kind == "lstm":
             with _timed("rnn", "lstm_bwd[N=%d,H=%d]" % (N, H), rflops, T):
-                check(lib().aas_lstm_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), ptr(dgx),
-                                         ptr(sync), ptr(xchg)), "aas_lstm_bwd")
+                check(lib().aas_lstm_bwd_ex(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(gact), ptr(cst), ptr(dgx),
+                                            ptr(sync), ptr(xchg), _ct.byref(_launch_arg(tag))), "aas_lstm_bwd_ex")
             dgh = dgx
         else:
             dgh = torch.empty((T, N, 2, GH), device=dev, dtype=torch.float32)
             with _timed("rnn", "gru_bwd[N=%d,H=%d]" % (N, H), rflops, T):
-                check(lib().aas_gru_bwd(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(dgx),
-                                        ptr(dgh), ptr(sync), ptr(xchg)), "aas_gru_bwd")
+                check(lib().aas_gru_bwd_ex(stream(), T, N, H, ptr(dy), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact), ptr(dgx),
+                                           ptr(dgh), ptr(sync), ptr(xchg), _ct.byref(_launch_arg(tag))), "aas_gru_bwd_ex")
     # the weight-gradient products (side stream) only need the BPTT launch's output: their event is recorded here, BEFORE the
     # input-gradient GEMM is queued, so they may start beside it
     ev_bptt = torch.cuda.Event()
@@ -1262,9 +1445,9 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         def transposed(src_f32, src_planes):
             out_ = torch.empty((2 * GH, 2 * Kp), device=dev, dtype=bf)
             if src_planes is not None:
-                check(lib().aas_planes_transpose(stream(), ptr(src_planes), Kpg, T, N, nbp, 2 * GH, Kp, ptr(out_), ptr(rs)), "aas_planes_transpose")
+                check(lib().aas_planes_transpose(stream(), ptr(src_planes), Kpg, T, N, nbp, 2 * GH, Kp, ptr(out_), ptr(rsw)), "aas_planes_transpose")
             else:
-                split_planes_t_into(out_, src_f32, T, N, nbp, 2 * GH, Kp, ld=2 * GH, row_scale=rs)
+                split_planes_t_into(out_, src_f32, T, N, nbp, 2 * GH, Kp, ld=2 * GH, row_scale=rsw)
             return out_
         dgT = transposed(dgx, dgp)
         dghT = dgT if (dgh is dgx and dghp is dgp) else transposed(dgh, dghp)
@@ -1298,7 +1481,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         layer does not have every operand in that form (the transposed-plane path runs instead)."""
         if not (TN_WGRAD[0] and keep and dgp is not None and "xp" in keep and "hx" in keep):
             return False
-        classes = [(0, N, None)] if rs is None else getattr(rs, "_aas_classes", None)
+        classes = classes_of()
         if not classes:
             return False
         xp, hx, hpitch = keep["xp"], keep["hx"], keep["hpitch"]
@@ -1327,7 +1510,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         above for the input-gradient product, or here), the input's sets from the forward projection, h_t split here from `hout`."""
         if not (TN_WGRAD[0] and keep and "xp3" in keep):
             return False
-        classes = [(0, N, None)] if rs is None else getattr(rs, "_aas_classes", None)
+        classes = classes_of()
         if not classes:
             return False
         xp3 = keep["xp3"]
@@ -1367,27 +1550,27 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         tn = lambda *a_, **k_: gemm(TN, *a_, **k_)
         xw, hw = x2, hout
         multi_ok = MULTI_WGRAD[0] and _precision[0] != 1 and not (rs is not None and _precision[0] == 0 and _TN_FOLD) and all(o.is_contiguous() for o in out)
-        by_class = multi_ok and rs is not None and CLASS_WGRAD[0] and bool(getattr(rs, "_aas_classes", None))
+        by_class = multi_ok and rs is not None and CLASS_WGRAD[0] and bool(rs.classes)
         if rs is not None and not by_class:  # per-utterance weights on the parameter gradients only (dx used the unscaled d(gates))
             if _precision[0] == 0 and _TN_FOLD and all(o.is_contiguous() for o in out):
                 # fp32 mode, optional: the weight rides on the reduction rows while the GEMM stages them (no pass at all)
                 def tn(M_, N_, K_, A_, lda_, B_, ldb_, C_, ldc_, a_off=0, b_off=0, accumulate=False):
                     with _timed("gemm", "gemm_tn", 2.0 * M_ * N_ * K_):
                         check(lib().aas_gemm_tn_rowscaled_f32(stream(), M_, N_, K_, A_.data_ptr() + 4 * a_off, lda_, B_.data_ptr() + 4 * b_off, ldb_,
-                                                              C_.data_ptr(), ldc_, int(accumulate), ptr(rs), N), "aas_gemm_tn_rowscaled_f32")
+                                                              C_.data_ptr(), ldc_, int(accumulate), ptr(rsw), N), "aas_gemm_tn_rowscaled_f32")
             else:
                 # the weight of reduction row (t, n) may ride on EITHER operand of the product: scale the narrow ones - x [R, I] and
                 # h [2R, H] - into copies instead of d(gates) [R, 2 G H] in place (8-16x fewer bytes; d(gates) stays untouched)
-                xw = scale_rows(x2, rs, N)
+                xw = scale_rows(x2, rsw, N)
                 if T > 1:
-                    hw = scale_rows(hout.view(2 * R, H), rs, N)
+                    hw = scale_rows(hout.view(2 * R, H), rsw, N)
         if multi_ok:
             # the four products of the layer (both directions' dW_ih and dW_hh) share d(gates): ONE launch of 4 x (GH/128 x I/128)
             # tiles fills the chip without split-K (two launches when the input and hidden widths differ).  Per-utterance weights
             # (the batched discriminator pass): one launch per utterance CLASS over that class's reduction rows - two-level row
             # addressing, rows (t, n0 .. n0+ns) of every time step - with the class's weight as the product's alpha: no scaled
             # copies of x / h (10 scale_rows launches, 1 ms of HBM-bound stream time per step before)
-            classes = [(0, N, None)] if rs is None else getattr(rs, "_aas_classes", None)
+            classes = classes_of()
             if classes and (rs is None or by_class):
                 a0, ah, b0, bh = dgx.data_ptr(), dgh.data_ptr(), x2.data_ptr(), hout.data_ptr()
                 first = True
@@ -1452,7 +1635,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
         ev = ev_bptt if (no_mutation and T > 1 and knobs.get("WGRAD_EARLY")) else torch.cuda.Event()
         if ev is not ev_bptt:
             ev.record(main)
-        hook = WGRAD_HOOK[0]
+        hook = state().wgrad_hook
 
         def run():
             with torch.cuda.stream(side), _wgrad_gemm_cap():
@@ -1464,8 +1647,8 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
                 (dga3.buf,) if dga3 is not None else ()):
             if t_ is not None:
                 t_.record_stream(side)
-        if DEFER_WGRAD[0] or lid in DEFER_LIDS:
-            _deferred.append(run)      # (the closure keeps the layer's operands alive until it runs)
+        if state().defer_wgrad or lid in state().defer_lids:
+            state().deferred.append(run)      # (the closure keeps the layer's operands alive until it runs)
         else:
             run()
         return dx, None, None, None, None
@@ -1475,6 +1658,7 @@ def _birnn_bwd(kind, dy, x, w_ih, w_hh, w_ih_r, w_hh_r, hout, gact, cst, residua
     return dx, outs[0], outs[1], outs[2], outs[3]
 
 
+@_scoped
 class _BiRNNLayer(torch.autograd.Function):
     """y = h_fwd + h_rev (+ x if residual)  for a bias-free bidirectional LSTM/GRU layer
     (reference model.py:80-86,101-105 and the residual adds at :223-226)."""
@@ -1482,6 +1666,7 @@ class _BiRNNLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, w_ih_r, w_hh_r, kind, residual, rs=None, lid=0):
         require_cuda(x, w_ih, w_hh)
+        rs = RowWeights.of(rs)
         ctx.rs, ctx.lid = rs, lid
         ctx.params = (w_ih, w_hh, w_ih_r, w_hh_r)  # the nn.Parameters themselves (for the direct-accumulate path)
         x = _c(x)
@@ -1489,7 +1674,7 @@ class _BiRNNLayer(torch.autograd.Function):
         trainable = any(ctx.needs_input_grad[1:5])    # (grad mode is off inside forward(): ask the context)
         ctx.keep = {} if (TN_WGRAD[0] and trainable and PLANES_BWD[0] and PLANES_EMIT[0]
                           and not torch.cuda.is_current_stream_capturing()) else None
-        hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid, keep=ctx.keep, row_len=getattr(rs, "_aas_row_len", None))
+        hout, gact, cst = _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid, keep=ctx.keep, row_len=rs.row_len if rs is not None else None)
         T_, N_, H_ = hout.shape[1], hout.shape[2], hout.shape[3]
         if _precision[0] == 2 and kind != "rnn" and PLANES_PRE[0] and T_ * N_ >= 1024 and H_ >= 64 and H_ % 4 == 0:
             y, yp = add3_planes3(hout[0], hout[1], x if residual else None, H_)
@@ -1523,7 +1708,7 @@ def birnn_layer(x, w_ih, w_hh, w_ih_r, w_hh_r, kind="lstm", residual=False, rs=N
 
 
 # --------------------------------------------------------------------------------------- batch norm
-SYNC_BN = [None]   # a dist.DPContext: train-mode statistics are all-reduced over the ranks (SyncBN)
+# (LaunchState.sync_bn: a dist.DPContext - train-mode statistics are all-reduced over the ranks: SyncBN)
 
 
 def _direct_small(params):
@@ -1534,9 +1719,10 @@ def _direct_small(params):
             and all(p_ is not None and getattr(p_, "_aas_flat_grad", False) and p_.grad is not None and p_.grad.is_contiguous() for p_ in params))
 
 
+@_scoped
 class _BatchNormRows(torch.autograd.Function):
     """Train-mode BatchNorm over the rows of x[..., C] (+ fused LeakyReLU(slope)); updates running stats.
-    With SYNC_BN set (data parallel, --sync_bn) the per-channel sums and the row count are all-reduced between the
+    With the launch state's `sync_bn` set (data parallel, --sync_bn) the per-channel sums and the row count are all-reduced between the
     statistics pass and the apply pass, forward and backward, so the result equals the single-process global batch."""
 
     @staticmethod
@@ -1547,7 +1733,7 @@ class _BatchNormRows(torch.autograd.Function):
         R = x.numel() // C
         y = torch.empty_like(x)
         stats = torch.empty((4, C), device=x.device, dtype=torch.float32)
-        dp = SYNC_BN[0]
+        dp = state().sync_bn
         ctx.dp, ctx.rows = dp, None
         if dp is None:
             wsd = _wsd(x.device, 2 * C)
@@ -1595,6 +1781,7 @@ class _BatchNormRows(torch.autograd.Function):
         return dx, (dgamma if ctx.needs_input_grad[1] else None), (dbeta if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
 
 
+@_scoped
 class _LeakyReLU(torch.autograd.Function):
     """nn.LeakyReLU(negative_slope) on its own (AM_training/model.py:364-367, include_first_BN=False: no BatchNorm to fuse it into)."""
 
@@ -1662,6 +1849,7 @@ def _kf_to_w(W2, F, KW):  # [M,KW*F] -> [M,F,KW]
     return transpose(W2, out, M, KW, F, KW * F, F, F * KW, KW)
 
 
+@_scoped
 class _Conv1dCL(torch.autograd.Function):
     """Temporal conv (no padding) on channels-last x[N,T,F] with PyTorch-layout weight [M,F,KW]:
     implicit-im2col batched GEMM (a row of the im2col matrix is KW consecutive frames of x)."""
@@ -1718,6 +1906,7 @@ def conv1d_cl(x, W, b, stride):
 
 
 # --------------------------------------------------------------------------------------- losses
+@_scoped
 class _L1Sum(torch.autograd.Function):
     """sum |a - b| over all elements (fp64 device accumulation), differentiable wrt both."""
 
@@ -1761,6 +1950,7 @@ def unit_root(like):
     return u
 
 
+@_scoped
 class _L1Pair(torch.autograd.Function):
     """The two masked-L1 sums of the batched discriminator pass (model.py:23-31 twice: trainer_AAS.py:146-147 on the enhanced rows
     with `enhanced` itself as the target, :176-177 on the clean rows), each with its weight / nElement scale folded into the
@@ -1780,7 +1970,7 @@ class _L1Pair(torch.autograd.Function):
         check(lib().aas_l1_fwd(stream(), ptr(ae), ptr(leaf), n0, ptr(acc)), "aas_l1_fwd")
         check(lib().aas_l1_fwd(stream(), ae.data_ptr() + 4 * n0, ptr(clean), n1, acc.data_ptr() + 8), "aas_l1_fwd")
         ctx.save_for_backward(ae, leaf, clean)
-        ctx.scales = (float(s_ny), float(s_cl))
+        ctx.scales = tuple((s_ if torch.is_tensor(s_) else float(s_)) for s_ in (s_ny, s_cl))    # python floats or device scalars (data parallel)
         ctx.mark_dirty(acc)
         return acc
 
@@ -1789,11 +1979,19 @@ class _L1Pair(torch.autograd.Function):
         ae, leaf, clean = ctx.saved_tensors
         n0, n1 = leaf.numel(), clean.numel()
         gs = None if getattr(g, "_aas_unit", False) else _c(g.to(torch.float32))
+
+        def factors(i):   # -> (host factor, device factor or None) of loss i: its scale times the upstream gradient
+            sc, gi = ctx.scales[i], (gs[i:i + 1] if gs is not None else None)
+            if not torch.is_tensor(sc):
+                return sc, gi
+            sc = _c(sc.reshape(1).to(torch.float32))
+            return 1.0, (sc if gi is None else sc * gi)
         dae = torch.empty_like(ae)
         dleaf = torch.empty_like(leaf) if ctx.needs_input_grad[1] else None
-        check(lib().aas_l1_bwd(stream(), ptr(ae), ptr(leaf), n0, ctx.scales[0], ptr(gs), ptr(dae), ptr(dleaf), 0), "aas_l1_bwd")
-        check(lib().aas_l1_bwd(stream(), ae.data_ptr() + 4 * n0, ptr(clean), n1, ctx.scales[1], (gs.data_ptr() + 4) if gs is not None else None,
-                               dae.data_ptr() + 4 * n0, None, 0), "aas_l1_bwd")
+        f0, d0 = factors(0)
+        f1, d1 = factors(1)
+        check(lib().aas_l1_bwd(stream(), ptr(ae), ptr(leaf), n0, f0, ptr(d0), ptr(dae), ptr(dleaf), 0), "aas_l1_bwd")
+        check(lib().aas_l1_bwd(stream(), ae.data_ptr() + 4 * n0, ptr(clean), n1, f1, ptr(d1), dae.data_ptr() + 4 * n0, None, 0), "aas_l1_bwd")
         if ctx.target_grad is not None and dleaf is not None:
             ctx.target_grad.append(dleaf)
             dleaf = None
@@ -1804,6 +2002,7 @@ def l1_pair(ae, leaf, clean, s_ny, s_cl, acc, target_grad=None):
     return _L1Pair.apply(ae, leaf, clean, s_ny, s_cl, acc, target_grad)
 
 
+@_scoped
 class _L1Scaled(torch.autograd.Function):
     """ONE masked-L1 sum (model.py:23-31) with its 1 / nElement (or weight / nElement) folded into the backward launch:
     acc[0] += sum|a - b| (acc: fp64, zeroed by the step prologue; a plain output buffer, not an autograd tensor); the returned
@@ -1878,6 +2077,7 @@ def ctc_prepare(labels, act_lens, label_lens, device):  # device may be "cpu": t
     return dict(meta=meta, nl=nl, N=N, max_l=max_l)
 
 
+@_scoped
 class _CTC(torch.autograd.Function):
     """sum_n -log p(l_n | softmax(acts[:len_n, n])); gradient wrt pre-softmax acts (warp-ctc semantics)."""
 
@@ -1919,6 +2119,7 @@ def ctc_sum(acts, labels, act_lens, label_lens, blank=0, prepared=None):
     return _CTC.apply(acts, labels, act_lens, label_lens, blank, prepared)
 
 
+@_scoped
 class _CTCScaled(torch.autograd.Function):
     """CTC with the loss weight (w_acoustic / N, trainer_AAS.py:168) folded into the kernel's gradient scale: the root is the vector
     of per-utterance costs [N] (summed and scaled where it is consumed - aas_began_step_raw), backward hands the scaled gradient over
@@ -1940,15 +2141,20 @@ class _CTCScaled(torch.autograd.Function):
         costs = torch.empty((N,), device=dev, dtype=torch.float32)
         grads = torch.empty_like(acts)
         lp = ptr(d_lab) if nl > 0 else ptr(meta)
+        dscale = scale if torch.is_tensor(scale) else None      # a device scalar (data parallel: w_acoustic / global N)
         with _timed("ctc", "ctc[N=%d,T=%d,L<=%d]" % (N, T, max_l), 0.0, 2 * T):
             check(lib().aas_ctc_loss_async(stream(), ptr(acts), ptr(grads), lp, ptr(d_off), ptr(d_ll), ptr(d_al), C, N, T,
-                                           max_l, ptr(costs), ptr(ws), int(blank), float(scale)), "aas_ctc_loss_async")
+                                           max_l, ptr(costs), ptr(ws), int(blank), 1.0 if dscale is not None else float(scale)), "aas_ctc_loss_async")
         ctx.save_for_backward(grads)
+        ctx.dscale = dscale
         return costs
 
     @staticmethod
     def backward(ctx, g):
         (grads,) = ctx.saved_tensors
+        if ctx.dscale is not None:      # the kernel left the gradient unscaled: one launch applies the device scalar
+            d = _c(ctx.dscale.reshape(1).to(torch.float32))
+            check(lib().aas_scale_dev_f32(stream(), ptr(grads), ptr(grads), ptr(d), 1.0, grads.numel()), "aas_scale_dev_f32")
         if not getattr(g, "_aas_unit", False):     # a general root gradient: per-utterance factors on the [T, N, C] gradient
             grads = grads * g.to(torch.float32).view(1, -1, 1)
         return grads, None, None, None

@@ -22,20 +22,23 @@ from .validation import ValidationMixin
 
 
 class _LazyScales(object):
-    """(w_adversarial / nElement_noisy, w_adversarial / nElement_clean, w_acoustic / N) from counts that are all-reduced on an
-    auxiliary stream: whichever stream reads a scale first waits for that stream's event (device side, not host side), so the
-    collective's latency hides behind the forward passes queued in the meantime."""
+    """The loss normalisers (w_adversarial / nElement_noisy, w_adversarial / nElement_clean, w_acoustic / N) from counts that are
+    all-reduced on an auxiliary stream and never leave the device: the collective, then ONE library launch that forms the three
+    scales (aas_scales_from_counts).  Whichever stream reads a scale first waits for that stream's event (device side, not host
+    side), so the collective's latency hides behind the forward passes queued in the meantime."""
 
     def __init__(self, dp, cnt, config, aux):
         main = torch.cuda.current_stream()
         aux.wait_stream(main)                      # the upload of `cnt`
         with torch.cuda.stream(aux):
             dp.reduce_scalars(cnt)
-            self.vals = ((config.w_adversarial / cnt[1]).float(), (config.w_adversarial / cnt[2]).float(), (config.w_acoustic / cnt[0]).float())
+            self.all = torch.empty(3, device=cnt.device, dtype=torch.float32)
+            ops.scales_from_counts(cnt, [config.w_adversarial, config.w_adversarial, config.w_acoustic], [1, 2, 0], self.all)
+            self.vals = (self.all[0], self.all[1], self.all[2])
             self.cnt = cnt
             self.ev = torch.cuda.Event()
             self.ev.record(aux)
-        for t_ in self.vals + (cnt,):
+        for t_ in (self.all, cnt):
             t_.record_stream(main)
 
     def __getitem__(self, i):
@@ -121,7 +124,7 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         # (recurrent-layer weight gradients of FlatBuffers-owned parameters accumulate into the flat buffers on a side stream)
         self._reducer = BucketReducer(self.dp, self._flat.values()) if self.dp.active else None
         # data parallel: A's BatchNorm statistics over the GLOBAL batch (--sync_bn) instead of "8 replicas with local-batch BN"
-        ops.SYNC_BN[0] = self.dp if (self.dp.active and getattr(c, "sync_bn", False)) else None
+        self.launch.sync_bn = self.dp if (self.dp.active and getattr(c, "sync_bn", False)) else None
         return self._opts
 
     def zero_grad_all(self):
@@ -225,10 +228,10 @@ class Trainer(ops.TrainerContext, ValidationMixin):
                 if not interleave:
                     acoustic = self._acoustic_branch(enhanced, targets, sizes, target_sizes, N_glob, ctc_meta)
             if interleave:
-                rs = torch.empty(Nn + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
-                rs[:Nn] = -float(self.kt)
-                rs[Nn:] = 1.0
-                rs._aas_classes = [(0, Nn, rs[0:1]), (Nn, cl_inputs.size(0), None)]
+                w = torch.empty(Nn + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
+                w[:Nn] = -float(self.kt)
+                w[Nn:] = 1.0
+                rs = ops.RowWeights(w, classes=[(0, Nn, w[0:1]), (Nn, cl_inputs.size(0), None)])
                 l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, N_glob, ctc_meta, targets, sizes,
                                                                                 target_sizes, mask=mask, cl_mask=cl_mask)
                 acoustic = (prob, l_CTC, leaf_a)
@@ -237,10 +240,10 @@ class Trainer(ops.TrainerContext, ValidationMixin):
                 # statistics).  The D-step gradients of the enhanced half are (-kt) x its G-step parameter
                 # gradients (:152-160), applied as per-utterance weights on the weight-gradient products only,
                 # so the gradient flowing back to `enhanced` stays the G-step one.
-                rs = torch.empty(Nn + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
-                rs[:Nn] = -float(self.kt)
-                rs[Nn:] = 1.0
-                rs._aas_classes = [(0, Nn, rs[0:1]), (Nn, cl_inputs.size(0), None)]
+                w = torch.empty(Nn + cl_inputs.size(0), device=leaf.device, dtype=torch.float32)
+                w[:Nn] = -float(self.kt)
+                w[Nn:] = 1.0
+                rs = ops.RowWeights(w, classes=[(0, Nn, w[0:1]), (Nn, cl_inputs.size(0), None)])
                 ae = self.D(torch.cat([leaf, cl_inputs], 0), wgrad_row_scale=rs)
                 l_adv_ny_G, _ = self.diffLoss(ae[:Nn], leaf, mask)
                 l_adv_cl, _ = self.diffLoss(ae[Nn:], cl_inputs, cl_mask)
@@ -313,35 +316,49 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, kt=self.kt,
                     conv_measure=conv_measure, g_adv=g_adv, g_ctc_adv=g_ctc_adv, enhanced=enhanced, prob=prob)
 
-    # ---- hipGraph path ----------------------------------------------------------------------------------
-    # The whole fused iteration (zero-grad .. Adam .. kt update) as ONE device-only launch sequence: kt, the Adam
-    # bias corrections and the loss scalars stay on the device, so the sequence is identical every step and is
-    # captured once per batch signature and replayed (the ~300 launches of a step otherwise cost more host time
-    # than GPU time).  Same kernels, same order, same results as train_step(schedule='fused', log_norms=False).
-    def _device_core(self, inputs, cl_inputs, nv_ny, nv_cl, ctc_meta, capturing=False, it=None):
+    # ---- device-resident step ---------------------------------------------------------------------------
+    # The whole fused iteration (zero-grad .. Adam .. kt update) as ONE device-only launch sequence: kt, the Adam bias corrections
+    # and the loss scalars stay on the device, so the host queues step i+1 while the GPU runs step i.  Same kernels, same results
+    # as train_step(schedule='fused', log_norms=False).  (Rounds 1-5 also replayed this sequence from a captured hipGraph,
+    # `train_step_graph`: the graph executor ran the two interleaved chains one after the other - 26.4 vs 21.7 ms in the fast
+    # mode - and capture forced the exchange buffers and split-K workspaces onto their slow paths; removed in round 6)
+    def _device_core(self, inputs, cl_inputs, nv_ny, nv_cl, ctc_meta, it=None):
         """The fused iteration as a device-only launch sequence.  Data parallel: the loss normalisers are the all-reduced
         GLOBAL counts (kept on the device), the gradient buffers are all-reduced bucket by bucket as the weight-gradient
         products finish (dist.BucketReducer), and kt is advanced from the all-reduced loss scalars - still no host sync."""
         c, dp = self.config, self.dp
         optimizer_g, optimizer_asr, optimizer_d = self._opts
         asr_steps = optimizer_asr is not None and (it is None or it > c.allow_ASR_update_iter)
-        if not capturing:
-            ops.sync_wgrad()
+        ops.sync_wgrad()
         N = inputs.size(0)
         dev = inputs.device
-        # device-resident glue as library launches (knobs.FUSED_GLUE; single process, equal padded lengths): ONE prologue launch zeroes
-        # the flat gradient buffers and the loss accumulators and writes the discriminator's per-utterance weights [-kt]*N + [1]*N;
-        # the losses stay raw device sums until the controller launch consumes them (no scaling / slicing / summing launches)
-        fused = (knobs.get("FUSED_GLUE") and not dp.active and not capturing and tuple(cl_inputs.shape) == tuple(inputs.shape)
+        # device-resident glue as library launches (knobs.FUSED_GLUE; equal padded lengths): ONE prologue launch zeroes the flat
+        # gradient buffers and the loss accumulators and writes the discriminator's per-utterance weights [-kt]*N + [1]*N; the
+        # losses stay raw device sums until the controller launch consumes them (no scaling / slicing / summing launches).  Data
+        # parallel: the same, with the normalisers as device scalars formed from the all-reduced counts and the three raw loss sums
+        # all-reduced before the controller (aas_loss_pack -> all-reduce -> aas_began_step_sums)
+        fused = (knobs.get("FUSED_GLUE") and tuple(cl_inputs.shape) == tuple(inputs.shape)
                  and not self._lanes_ok(True) and self._interleave_ok())
         self._fused = None
+        if dp.active:
+            cnt = self._upload_small(torch.tensor([float(N), float(nv_ny), float(nv_cl)], dtype=torch.float64), dev)
+            # global N, nElement(noisy), nElement(clean): all-reduced asynchronously and kept on the device; a loss only waits for
+            # them where it is formed (after the forward passes), so the collective's latency hides behind E
+            if getattr(self, "_aux_stream", None) is None:
+                self._aux_stream = ops.refresh_stream(dev)
+            scales = _LazyScales(dp, cnt, c, self._aux_stream)
+            n_glob = scales
+        else:
+            scales = (c.w_adversarial / nv_ny, c.w_adversarial / nv_cl, c.w_acoustic / N)
+            n_glob = float(N)
         if fused:
             if getattr(self, "_l1_acc", None) is None or self._rs_pair.numel() != 2 * N:
                 self._l1_acc = torch.zeros(2, device=dev, dtype=torch.float64)
                 self._rs_pair = torch.empty(2 * N, device=dev, dtype=torch.float32)
+            self._wait_kt()      # (data parallel: kt was advanced on the auxiliary stream behind the previous step's scalar all-reduce)
             ops.step_prologue([f.flat_g for f in self._flat.values()] + [self._l1_acc], self._rs_pair, N, N, self._kt_dev)
             self._fused = {}
-        elif knobs.get("FUSED_GLUE") and not dp.active and not capturing:
+        elif knobs.get("FUSED_GLUE") and not dp.active:
             # the other single-process device paths (ragged pair on the two-lane schedule, ...): the zero fills and the weights
             # [-kt] * N of the enhanced pass in one prologue launch; their losses keep the autograd scaling
             if getattr(self, "_rs_lane", None) is None or self._rs_lane.numel() != N:
@@ -349,26 +366,15 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             ops.step_prologue([f.flat_g for f in self._flat.values()], self._rs_lane, N, 0, self._kt_dev)
         else:
             self._rs_lane = None
-            for f in self._flat.values():
-                f.flat_g.zero_()
+            ops.step_prologue([f.flat_g for f in self._flat.values()])
         if dp.active:
-            cnt = self._upload_small(torch.tensor([float(N), float(nv_ny), float(nv_cl)], dtype=torch.float64), dev)
-            # global N, nElement(noisy), nElement(clean): all-reduced asynchronously and kept on the device; the loss scales are
-            # only formed when the first loss needs them (after the forward passes), so the collective's latency hides behind E
-            if getattr(self, "_aux_stream", None) is None:
-                self._aux_stream = ops.refresh_stream(dev)
-            scales = _LazyScales(dp, cnt, c, self._aux_stream)
-            n_glob = scales
             self._reducer.begin()
             if not self._reducer.deferred:     # E's first recurrent layer is back-propagated last
                 first = next((m for m in self.G.modules() if getattr(m, "_aas_layer_id", None) is not None), None)
                 if first is not None:
                     self._reducer.defer_layer([p_.grad for p_ in (first.weight_ih_l0, first.weight_hh_l0, first.weight_ih_l0_reverse,
                                                                   first.weight_hh_l0_reverse) if p_.grad is not None])
-            ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
-        else:
-            scales = (c.w_adversarial / nv_ny, c.w_adversarial / nv_cl, c.w_acoustic / N)
-            n_glob = float(N)
+            self.launch.wgrad_hook = self._reducer.on_wgrad
         try:
             # two chains of half-chip persistent launches run side by side: the weight-gradient GEMMs never take more than the
             # other half of the CUs, so a recurrent launch always finds its CUs (AAS_WGRAD_WGS overrides)
@@ -390,8 +396,9 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             self._early_adam = False
             raise
         finally:
-            ops.WGRAD_HOOK[0] = None
-        optimizer_g.step_dev()
+            self.launch.wgrad_hook = None
+        with ops._timed("mark", "optimizer_g.step_dev", 0.0):      # (ops.Profiler class "mark": where the step's first consumer of the all-reduced gradients is queued)
+            optimizer_g.step_dev()
         if not getattr(self, "_early_adam", False):
             optimizer_d.step_dev()
             if asr_steps:
@@ -399,7 +406,7 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         self._early_adam = False
         # the updated weights' operand planes for the next step, off the critical path (weight-gradient stream)
         for net, on in ((self.G, True), (self.D, True), (self.ASR, asr_steps)):
-            if on and not capturing:
+            if on:
                 ops.refresh_weight_planes(net)
         if not dp.active:   # controller + log scalars in one tiny launch
             if self._fused:     # from the raw sums: L = scale x sum inside the launch
@@ -410,8 +417,25 @@ class Trainer(ops.TrainerContext, ValidationMixin):
                 ops.began_step(l_adv_ny_G, l_adv_cl, l_CTC, self._kt_dev, self._g_out, self.gamma, self.lb, n_glob)
             return enhanced, prob
         # data parallel: the three loss scalars are all-reduced and kt advanced on the auxiliary stream - the main stream goes
-        # straight on to the next step and only waits for this event where kt is read (the weight-gradient scaling of D)
+        # straight on to the next step and only waits for this event where kt is read (the step prologue)
         main, aux = torch.cuda.current_stream(), self._aux_stream
+        if self._fused:
+            # raw sums -> [sum L1 noisy, sum L1 clean, sum CTC costs] (one launch) -> SUM over the ranks -> the controller with the
+            # GLOBAL normalisers and batch size as device scalars (one launch): Proportional Control Theory (:190-194) on the device
+            l1, costs = self._fused["l1"], self._fused["costs"]
+            self._fused = None
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                out3 = torch.empty(3, device=l1.device, dtype=torch.float64)
+                ops.loss_pack(l1, costs, out3)
+                dp.reduce_scalars(out3)
+                ops.began_step_sums(out3, out3[2:], 1.0, 1.0, 1.0, self._kt_dev, self._g_out, self.gamma, self.lb, 0.0,
+                                    d_scales3=scales.all, d_n_batch=scales.cnt)
+                self._kt_ev = torch.cuda.Event()
+                self._kt_ev.record(aux)
+            for t_ in (l1, costs, scales.all, scales.cnt):
+                t_.record_stream(aux)
+            return enhanced, prob
         packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), l_CTC.detach().reshape(())]).double()
         aux.wait_stream(main)
         with torch.cuda.stream(aux):
@@ -430,8 +454,9 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         return enhanced, prob
 
     def _batched_D_core(self, inputs, cl_inputs, scales, ctc_meta, asr_steps):
-        """D(enhanced) and D(clean) as ONE batched pass of 2N rows beside the acoustic chain (the round-1 schedule; needs
-        equal padded lengths).  Kept for hipGraph capture and as the A/B reference of the two-lane schedule."""
+        """D(enhanced) and D(clean) as ONE batched pass of 2N rows beside the acoustic chain - the default schedule: for equal
+        padded lengths, and for a ragged noisy / clean pair with two row classes of different length inside D's recurrent
+        launches (`_ragged_batched_ok`; pinned to the reference by fixtures F1r / F3r)."""
         dp = self.dp
         N, dev = inputs.size(0), inputs.device
         enhanced = self.G(inputs)
@@ -440,30 +465,31 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         acoustic = None
         self._wait_kt()
         if getattr(self, "_fused", None) is not None:
-            rs = self._rs_pair.detach()        # written by the step prologue: [-kt] * N + [1] * N
+            w = self._rs_pair.detach()        # written by the step prologue: [-kt] * N + [1] * N
         else:
-            rs = torch.empty(N + cl_inputs.size(0), device=dev, dtype=torch.float32)
-            rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
-            rs[N:] = 1.0
-        # the two utterance classes of the batched pass and their weights (device scalars), for the row-major weight-gradient GEMM
-        rs._aas_classes = [(0, N, rs[0:1]), (N, cl_inputs.size(0), None)]
+            w = torch.empty(N + cl_inputs.size(0), device=dev, dtype=torch.float32)
+            w[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
+            w[N:] = 1.0
         ragged = cl_inputs.size(2) != inputs.size(2)
         if ragged:
             # noisy / clean batches of different padded length in ONE pass of max(T) frames: the recurrent launches treat the two
-            # row classes as sequences of their own length (aas_set_rnn_row_classes), the losses read each class's own frames
+            # row classes as sequences of their own length (ops.RowWeights.row_len -> aasLaunch.cls_*), the losses read each class's
+            # own frames
             assert self._ragged_batched_ok(inputs, cl_inputs)
-            rs._aas_row_len = (N, inputs.size(2), cl_inputs.size(2))
+        # the two utterance classes of the batched pass and their weights (device scalars), for the row-major weight-gradient GEMM
+        rs = ops.RowWeights(w, classes=[(0, N, w[0:1]), (N, cl_inputs.size(0), None)],
+                            row_len=(N, inputs.size(2), cl_inputs.size(2)) if ragged else None)
         if overlap:  # two chains of persistent launches side by side, half the chip each
             ops.set_rnn_cu_limit(ops.device_cus() // 2)
         if self._interleave_ok():
             # the discriminator's weight-gradient products are held back while the two BPTT chains run (they slow the chains'
             # cross-CU exchange) and released into E's backward phase, where half of the chip has little else to do
-            ops.DEFER_WGRAD[0] = knobs.get("DEFER_WGRAD")   # (measured: no gain, 19.0 vs 19.2 ms - kept as a switch)
+            self.launch.defer_wgrad = knobs.get("DEFER_WGRAD")   # (measured: no gain, 19.0 vs 19.2 ms - kept as a switch)
             # The weight-gradient products of the layers that are back-propagated FIRST (D's - and a trainable A's - top layers)
             # are held back until E's backward: beside the two BPTT chains every CU is taken and the products only slow the chains
             # down, beside E's backward half of the chip is free.  Not all of them: E's backward phase has room for about two D
             # layers on top of E's own (16.7 -> 16.1 ms with two, 16.2 with three, 16.5 with one).
-            ops.DEFER_LIDS.clear()
+            self.launch.defer_lids.clear()
             # (fp32 mode, same-box runs: 0 / 1 / 2 / 3 / 4 held-back layers = 30.6-31.0 / 30.1 / 29.9-30.4 / 30.2-30.3 / 30.1-30.2 ms
             #  with the eight-wave fp32 GEMM; with the four-wave one the weight-gradient stream was saturated and 0 was best)
             # (fp32-equivalent mode, with the six-product BPTT: 0 / 1 / 2 = 23.9-24.2 / 24.1-24.2 / 24.5-24.6 ms - its weight-gradient
@@ -473,13 +499,13 @@ class Trainer(ops.TrainerContext, ValidationMixin):
                 ndef = dflt if ndef is None else int(ndef)
                 if ndef > 0:
                     lids = [m._aas_layer_id for m in net.modules() if getattr(m, "_aas_layer_id", None) is not None]
-                    ops.DEFER_LIDS.update(lids[-ndef:])
+                    self.launch.defer_lids.update(lids[-ndef:])
             try:
                 l_adv_ny_G, l_adv_cl, prob, l_CTC, leaf_a = self._interleaved_DA(enhanced, leaf, cl_inputs, rs, None, ctc_meta, None, None, None,
                                                                                 scales=scales)
             finally:
-                ops.DEFER_WGRAD[0] = False
-                ops.DEFER_LIDS.clear()
+                self.launch.defer_wgrad = False
+                self.launch.defer_lids.clear()
         else:
             if overlap:
                 acoustic = self._acoustic_branch(enhanced, None, None, None, None, ctc_meta, scale=scales[2])
@@ -505,8 +531,7 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             self._reducer.flush(self._flat["D"])
             if asr_steps:
                 self._reducer.flush(self._flat["A"])
-        elif (knobs.get("EARLY_ADAM") and not torch.cuda.is_current_stream_capturing()
-              and ops.DIRECT_WGRAD[0] and ops.LINEAR_DIRECT[0]):
+        elif knobs.get("EARLY_ADAM") and ops.DIRECT_WGRAD[0] and ops.LINEAR_DIRECT[0]:
             # D's (and a trainable A's) gradients are complete once the products queued on the weight-gradient stream have run:
             # their Adam steps and weight-plane refreshes go onto that stream now and overlap E's backward instead of
             # following it (every parameter gradient of D is produced on that stream; A's BatchNorm / conv / fc ones on `side`)
@@ -569,10 +594,10 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             self._reducer.expect(self._flat["D"], 2)      # every D layer is back-propagated twice: reduce after the second
         self._wait_kt()
         if getattr(self, "_rs_lane", None) is not None and self._rs_lane.numel() == N and not dp.active:
-            rs = self._rs_lane.detach()          # written by the step prologue
+            w = self._rs_lane.detach()          # written by the step prologue
         else:
-            rs = (-self._kt_dev).to(torch.float32).expand(N).contiguous()
-        rs._aas_classes = [(0, N, rs[0:1])]
+            w = (-self._kt_dev).to(torch.float32).expand(N).contiguous()
+        rs = ops.RowWeights(w, classes=[(0, N, w[0:1])])
 
         def alternate(gen_main, gen_side):
             a = b = None
@@ -624,20 +649,21 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         if getattr(self, "_kt_dev", None) is None:
             self._kt_dev = torch.zeros(1, device=dev, dtype=torch.float64)
             self._g_out = torch.zeros(6, device=dev, dtype=torch.float64)
-            self._graphs = {}
             self._kt_dev.fill_(float(self.kt))
             self._kt_dev_live = False   # the host copy is the current one until a device-resident step has run
 
     @ops.with_trainer_precision
     def train_step_async(self, data_list, data_list_cl, iter):
         """The fused iteration queued WITHOUT any host synchronisation: kt, the Adam bias corrections and the loss scalars
-        stay on the device (`_device_core`, the same launch sequence the graph path captures), the CTC metadata goes up
+        stay on the device (`_device_core`), the CTC metadata goes up
         from pinned memory, and nothing is read back - so the host queues step i+1 while the GPU is still running step i
         and the ~10 ms of Python launch overhead per step never leaves a stream dry at a step boundary.  Returns device
         tensors; `read_scalars()` (one D2H copy) updates `self.kt` and returns the last step's losses - call it when a log
         line needs them (the reference logs every `log_iter` iterations, trainer_AAS.py:196-215).  Works data parallel
-        (global normalisers, bucketed gradient all-reduce, all-reduced kt inputs: all on the device) and with a trainable
-        A.  Falls back to train_step for the as-executed schedule and for a noisy / clean pair of different padded length."""
+        (global normalisers, bucketed gradient all-reduce, all-reduced kt inputs: all on the device), with a trainable A, and
+        on noisy / clean pairs of different padded length (batched pass with two row classes, or the two-lane schedule below a
+        length ratio of knobs.RAGGED_MIN_RATIO).  Falls back to train_step for the as-executed schedule and for masks without
+        a host-side frame count."""
         if self._opts is None:
             self.make_optimizers()
         if self.schedule != "fused":
@@ -680,104 +706,6 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         bal = self.gamma * l_adv_cl - l_adv_ny_G
         return dict(l_adv_ny_G=l_adv_ny_G, l_adv_cl=l_adv_cl, l_ctc=l_ctc, kt=kt, conv_measure=l_adv_cl + abs(bal))
 
-    @ops.with_trainer_precision
-    def train_step_graph(self, data_list, data_list_cl, iter):
-        """Graph-replayed fused iteration (single GPU, no gradient-norm logging).  Falls back to train_step when the
-        configuration needs host decisions inside the step."""
-        if self._opts is None:
-            self.make_optimizers()
-        c = self.config
-        asr_steps = self._opts[1] is not None
-        # (a trainable A is not captured yet: capture_end faults in the HIP runtime with A's weight-gradient
-        #  side-stream work in the graph - the frozen-A configuration of the benchmark is what is graphed)
-        if self.dp.active or self.schedule != "fused" or asr_steps:
-            return self.train_step(data_list, data_list_cl, iter, log_norms=False)
-        inputs, targets, input_percentages, target_sizes, mask = self._prep(data_list)
-        cl_inputs, cl_mask = data_list_cl[0], data_list_cl[4]
-        if not cl_mask.is_cuda:
-            attach_n_valid(cl_mask)
-        nv = lambda m: getattr(m, "n_valid", None) or (int(m.numel()) - int(m.sum().item()))
-        nv_ny, nv_cl = nv(mask), nv(cl_mask)
-        if tuple(cl_inputs.shape) != tuple(inputs.shape):
-            return self.train_step(data_list, data_list_cl, iter, log_norms=False)
-        t_out = self.ASR.output_length(inputs.size(2))
-        sizes = input_percentages.clone().mul_(int(t_out)).int()
-        meta = ops.ctc_prepare(targets, sizes, target_sizes, "cpu")
-        sig = (tuple(inputs.shape), nv_ny, nv_cl, meta["nl"], meta["max_l"])
-        dev = next(self.G.parameters()).device
-        self._ensure_dev_state(dev)
-        if getattr(self, "_kt_dev_live", False):
-            self.read_scalars()
-        self._kt_dev.fill_(float(self.kt))
-        self._kt_dev_live = False
-        g = self._graphs.get(sig)
-        if g is None:
-            st = dict(inputs=torch.empty(inputs.shape, device=dev), cl=torch.empty(cl_inputs.shape, device=dev),
-                      meta=dict(meta=torch.empty(meta["meta"].shape, dtype=torch.int32, device=dev), nl=meta["nl"],
-                                N=meta["N"], max_l=meta["max_l"]))
-            st["inputs"].copy_(inputs); st["cl"].copy_(cl_inputs); st["meta"]["meta"].copy_(meta["meta"])
-            # warm-up on a side stream (allocator pools, lazily created scratch), restoring the state it advances
-            pairs = [(self._flat["G"], self._opts[0]), (self._flat["D"], self._opts[2])]
-            if asr_steps:
-                pairs.append((self._flat["A"], self._opts[1]))
-            snap = [(f.flat_p.clone(), o.m.clone(), o.v.clone(), o.vmax.clone() if o.vmax is not None else None, o.step_count)
-                    for f, o in pairs]
-            bn_snap = {k: v.clone() for k, v in self.ASR.state_dict().items() if "running_" in k or "num_batches" in k}
-            # (on the stream the capture will run on: per-stream scratch - the recurrent kernels' sync / exchange buffers, the
-            #  GEMM's split-K slabs - is then sized before the capture starts, where nothing may be allocated)
-            if getattr(self, "_cap_stream", None) is None:
-                self._cap_stream = torch.cuda.Stream()
-            ws = self._cap_stream
-            ws.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(ws):
-                self._device_core(st["inputs"], st["cl"], nv_ny, nv_cl, st["meta"])
-            torch.cuda.current_stream().wait_stream(ws)
-            torch.cuda.synchronize()
-
-            def restore():
-                for (f, o), (p_, m_, v_, vm_, sc) in zip(pairs, snap):
-                    f.flat_p.copy_(p_); o.m.copy_(m_); o.v.copy_(v_)
-                    if vm_ is not None:
-                        o.vmax.copy_(vm_)
-                    o.step_count = sc
-                    o._t_dev.fill_(float(sc))
-                sd = self.ASR.state_dict()
-                for k, v in bn_snap.items():
-                    sd[k].copy_(v)
-                self._kt_dev.fill_(float(self.kt))
-
-            restore()
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            # capture on a stream of our own whose scratch exists already: a sync buffer first created DURING capture would
-            # be zero-filled by a captured memset, i.e. every replay would clear the sticky timeout word
-            if getattr(self, "_cap_stream", None) is None:
-                self._cap_stream = torch.cuda.Stream()
-            with torch.cuda.stream(self._cap_stream):
-                ops._sync_buf(dev)
-            torch.cuda.synchronize()
-            with torch.cuda.graph(graph, stream=self._cap_stream):
-                enh, prob = self._device_core(st["inputs"], st["cl"], nv_ny, nv_cl, st["meta"], capturing=True)
-            for (f, o), sn in zip(pairs, snap):
-                o.step_count = sn[4]  # capture only recorded the launches; nothing ran
-            g = dict(graph=graph, st=st, enh=enh, prob=prob)
-            self._graphs[sig] = g
-        else:
-            g["st"]["inputs"].copy_(inputs, non_blocking=True)
-            g["st"]["cl"].copy_(cl_inputs, non_blocking=True)
-            g["st"]["meta"]["meta"].copy_(meta["meta"], non_blocking=True)
-        g["graph"].replay()
-        for o in (self._opts[0], self._opts[2]) + ((self._opts[1],) if asr_steps else ()):
-            o.step_count += 1
-        l_adv_ny_G_data, l_adv_cl_data, l_ctc_data, kt = self._g_out[:4].tolist()
-        self._g_out[4:6].zero_()
-        ops.check_rnn_health((l_adv_ny_G_data, l_adv_cl_data, l_ctc_data))
-        self.ctc_tr_local.update(l_ctc_data, inputs.size(0))
-        g_d_balance = self.gamma * l_adv_cl_data - l_adv_ny_G_data
-        self.kt = kt
-        return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, l_ctc=l_ctc_data, kt=self.kt,
-                    conv_measure=l_adv_cl_data + abs(g_d_balance), g_adv=None, g_ctc_adv=None, enhanced=g["enh"], prob=g["prob"])
-
     def _interleaved_DA(self, enhanced, leaf, cl_inputs, rs, N_glob, ctc_meta, targets, sizes, target_sizes, scales=None,
                         mask=None, cl_mask=None):
         """Discriminator pass and acoustic pass QUEUED layer by layer in alternation on two streams, one combined backward.
@@ -803,12 +731,12 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         enhanced.record_stream(side)
         with torch.cuda.stream(main):
             if main is not caller:
-                for t_ in (enhanced, leaf, cl_inputs, rs):
+                for t_ in (enhanced, leaf, cl_inputs, rs.w):
                     t_.record_stream(main)
             fused = getattr(self, "_fused", None) is not None and scales is not None and mask is None
             Tn, Tc = leaf.size(2), cl_inputs.size(2)
-            # (different padded lengths: only with the row classes the caller attached to rs - _batched_D_core)
-            assert Tn == Tc or getattr(rs, "_aas_row_len", None) == (leaf.size(0), Tn, Tc)
+            # (different padded lengths: only with the row classes the caller put into rs - _batched_D_core)
+            assert Tn == Tc or rs.row_len == (leaf.size(0), Tn, Tc)
             if fused or Tn != Tc:
                 gD = self.D.forward_stages(None, wgrad_row_scale=rs, pair=(leaf, cl_inputs))
             else:
@@ -900,10 +828,7 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         exact_a = getattr(c, "asr_exact_fp32", None)
         if exact_a is None:
             exact_a = knobs.get("ASR_EXACT")
-        # (not under hipGraph capture: replayed with the nodes of the two chains created alternately, the graph executor
-        #  ran the chains strictly one after the other - 26.4 ms vs 21.7 with one chain captured after the other)
-        return (self._overlap_asr() and not exact_a and knobs.get("INTERLEAVE")
-                and not torch.cuda.is_current_stream_capturing())
+        return self._overlap_asr() and not exact_a and knobs.get("INTERLEAVE")
 
     @staticmethod
     def _overlap_asr():

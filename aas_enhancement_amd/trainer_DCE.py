@@ -87,7 +87,7 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         if dp.active:
             (nElement,) = dp.global_counts([nElement])
             self._reducer.begin()
-            ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
+            self.launch.wgrad_hook = self._reducer.on_wgrad
         try:
             ops.sync_wgrad()
             # the loss root is a RAW device sum in a ring of eight accumulators (a caller may read a step's loss up to seven
@@ -105,7 +105,7 @@ class Trainer(ops.TrainerContext, ValidationMixin):
                 self._reducer.flush(self._flat)
                 self._reducer.wait()
         finally:
-            ops.WGRAD_HOOK[0] = None
+            self.launch.wgrad_hook = None
         self._opt.step_dev()
         ops.refresh_weight_planes(self.G)
         raw = acc

@@ -142,8 +142,8 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             self._rs_pair = torch.empty(2 * N, device=dev, dtype=torch.float32)
         ops.sync_wgrad()
         ops.step_prologue([f.flat_g for f in self._flat.values()] + [self._sums, self._sum3], self._rs_pair, N, N, self._kt_dev)
-        rs = self._rs_pair.detach()
-        rs._aas_classes = [(0, N, rs[0:1]), (N, N, None)]   # the two utterance classes and their weights (device scalars)
+        w = self._rs_pair.detach()
+        rs = ops.RowWeights(w, classes=[(0, N, w[0:1]), (N, N, None)])   # the two utterance classes and their weights (device scalars)
         s_adv, s_dce = c.w_adversarial / nElement, 1.0 / nElement
         enhanced = self.G(mixture)
         leaf = enhanced.detach().requires_grad_(True)
@@ -207,19 +207,19 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         mixture, cleans, mask = self._batch(data_list)
         N = mixture.size(0)
         (nElement,) = dp.global_counts([mask.n_valid])
-        rs = torch.empty(2 * N, device=mixture.device, dtype=torch.float32)
-        rs[:N] = -float(self.kt)
-        rs[N:] = 1.0
-        rs._aas_classes = [(0, N, rs[0:1]), (N, N, None)]   # the two utterance classes and their weights (ops.gemm_planes_tn)
+        w = torch.empty(2 * N, device=mixture.device, dtype=torch.float32)
+        w[:N] = -float(self.kt)
+        w[N:] = 1.0
+        rs = ops.RowWeights(w, classes=[(0, N, w[0:1]), (N, N, None)])   # the two utterance classes and their weights (ops.gemm_planes_tn)
         self._reducer.begin()
-        ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
+        self.launch.wgrad_hook = self._reducer.on_wgrad
         try:
             enhanced, l_adv_ny_G, l_adv_cl, dce = self._forward_backward(mixture, cleans, rs, c.w_adversarial / nElement, 1.0 / nElement)
             ops.sync_wgrad()
             self._reducer.flush(self._flat["G"])
             self._reducer.wait()
         finally:
-            ops.WGRAD_HOOK[0] = None
+            self.launch.wgrad_hook = None
         g_norm = self.get_gradient_norm(self.G)
         optimizer_g.step(); optimizer_d.step()
         ops.refresh_weight_planes(self.G); ops.refresh_weight_planes(self.D)
@@ -269,20 +269,20 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         n_glob = cnt.get(0)
         s_adv, s_dce = (c.w_adversarial / n_glob).float(), (1.0 / n_glob).float()
         self._reducer.begin()
-        ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
+        self.launch.wgrad_hook = self._reducer.on_wgrad
         if self._kt_ev is not None:
             torch.cuda.current_stream().wait_event(self._kt_ev)
-        rs = torch.empty(2 * N, device=dev, dtype=torch.float32)
-        rs[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
-        rs[N:] = 1.0
-        rs._aas_classes = [(0, N, rs[0:1]), (N, N, None)]
+        w = torch.empty(2 * N, device=dev, dtype=torch.float32)
+        w[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
+        w[N:] = 1.0
+        rs = ops.RowWeights(w, classes=[(0, N, w[0:1]), (N, N, None)])
         try:
             enhanced, l_adv_ny_G, l_adv_cl, dce = self._forward_backward(mixture, cleans, rs, s_adv, s_dce)
             ops.sync_wgrad()
             self._reducer.flush(self._flat["G"])
             self._reducer.wait()
         finally:
-            ops.WGRAD_HOOK[0] = None
+            self.launch.wgrad_hook = None
         optimizer_g.step_dev(); optimizer_d.step_dev()
         ops.refresh_weight_planes(self.G); ops.refresh_weight_planes(self.D)
         main = torch.cuda.current_stream()

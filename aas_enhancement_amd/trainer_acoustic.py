@@ -47,7 +47,7 @@ class Trainer(_AASTrainer):
         mk = lambda f: FlatAdam(f, lr=c.lr, betas=(self.beta1, self.beta2), amsgrad=True)
         self._opts = (mk(self._flat["G"]), mk(self._flat["A"]) if "A" in self._flat else None, None)
         self._reducer = BucketReducer(self.dp, self._flat.values()) if self.dp.active else None
-        ops.SYNC_BN[0] = self.dp if (self.dp.active and getattr(c, "sync_bn", False)) else None
+        self.launch.sync_bn = self.dp if (self.dp.active and getattr(c, "sync_bn", False)) else None
         return self._opts
 
     # ---- one iteration of :120-142 -------------------------------------------------------------
@@ -62,7 +62,7 @@ class Trainer(_AASTrainer):
             f.flat_g.zero_()
         if self._reducer is not None:
             self._reducer.begin()
-            ops.WGRAD_HOOK[0] = self._reducer.on_wgrad
+            self.launch.wgrad_hook = self._reducer.on_wgrad
         try:
             ops.set_rnn_cu_limit(0)
             enhanced = self.G(inputs)
@@ -81,7 +81,7 @@ class Trainer(_AASTrainer):
                     self._reducer.flush(f)
                 self._reducer.wait()
         finally:
-            ops.WGRAD_HOOK[0] = None
+            self.launch.wgrad_hook = None
         return enhanced, prob, l_CTC, asr_steps
 
     @ops.with_trainer_precision

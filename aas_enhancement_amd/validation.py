@@ -139,11 +139,11 @@ class ValidationMixin(object):
         from . import ops
         dp = getattr(self, "dp", None)
         if dp is None or dp.rank == 0:
-            armed, ops.SYNC_BN[0] = ops.SYNC_BN[0], None
+            armed, self.launch.sync_bn = self.launch.sync_bn, None
             try:
                 self.validate_and_checkpoint(iter)
             finally:
-                ops.SYNC_BN[0] = armed
+                self.launch.sync_bn = armed
         if dp is not None and dp.active:
             dp.barrier()
             if getattr(self, "ASR", None) is not None:

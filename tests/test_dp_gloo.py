@@ -338,9 +338,10 @@ def _bench8_worker(rank, world, port, q):
         # global normalisers as the trainer forms them (N, nElement noisy / clean summed over the ranks)
         counts = dp.global_counts([ny[0].shape[0], ny[4].n_valid, cl[4].n_valid])
         # the timed region: rank r "measured" (1 + r/10) s for 4 steps - the contract takes the MAX over ranks
+        per_rank = bench.per_rank_times(1.0 + rank / 10.0, world, dev)
         dt = bench.max_over_ranks(1.0 + rank / 10.0, world, dev)
         value, ms = bench.whole_job(world, bench.N_PER * bench.T, dt, 4)
-        q.put((rank, [g.tolist() for g in gathered], list(counts), dt, value, ms, bench.rank_seeds(rank)))
+        q.put((rank, [g.tolist() for g in gathered], list(counts), dt, value, ms, bench.rank_seeds(rank), per_rank))
     finally:
         dist.destroy_process_group()
 
@@ -372,3 +373,4 @@ def test_bench_worker_bookkeeping_world8():
         assert r[2] == [3 * world, 3 * bench.T * world, 3 * bench.T * world]   # global N, nElement(noisy), nElement(clean)
         assert r[3] == pytest.approx(1.7)                                  # MAX over ranks (rank 7's 1.7 s), on every rank
         assert r[4] == pytest.approx(world * bench.N_PER * bench.T / (1.7 / 4)) and r[5] == pytest.approx(425.0)
+        assert r[7] == pytest.approx([1.0 + k / 10.0 for k in range(world)])     # every rank's own time, on every rank (config.per_rank_ms_per_step)

@@ -644,8 +644,8 @@ def test_layer_weight_gradients_row_major_path_equals_transposed_path(ops, kind,
     dy = R(T, N, H, seed=30).to(dev)
     rs = None
     if classes == 2:
-        rs = torch.cat([torch.full((N // 2,), -0.37), torch.ones(N - N // 2)]).to(dev)
-        rs._aas_classes = [(0, N // 2, rs[0:1]), (N // 2, N - N // 2, None)]
+        w_ = torch.cat([torch.full((N // 2,), -0.37), torch.ones(N - N // 2)]).to(dev)
+        rs = ops.RowWeights(w_, classes=[(0, N // 2, w_[0:1]), (N // 2, N - N // 2, None)])
     res = {}
     for tn in (True, False):
         ops.TN_WGRAD[0] = tn

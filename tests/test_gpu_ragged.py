@@ -62,8 +62,7 @@ def test_row_classes_match_one_launch_per_class(gpu, kind, H, I, Na, Nb, Ta, Tb,
         x[:Ta, :Na] = xa
         x[:Tb, Na:] = xb
         x = x.requires_grad_(True)
-        rs = torch.ones(N, device=dev)
-        rs._aas_row_len = (Na, Ta, Tb)
+        rs = ops.RowWeights(torch.ones(N, device=dev), row_len=(Na, Ta, Tb))
         y = _layer(kind, x, ws2, rs=rs)
         dy = torch.randn(T, N, H, generator=g).to(dev)
         dy[:Ta, :Na] = ga
@@ -100,8 +99,7 @@ def test_row_classes_on_row_chunked_launches_and_the_counter_kernels(gpu, kind, 
     x = torch.randn(T, N, I, generator=g).to(dev)
     x[:Ta, :Na], x[:Tb, Na:] = xa, xb
     dy = torch.randn(T, N, H, generator=g).to(dev)
-    rs = torch.ones(N, device=dev)
-    rs._aas_row_len = (Na, Ta, Tb)
+    rs = ops.RowWeights(torch.ones(N, device=dev), row_len=(Na, Ta, Tb))
     lib = _lib.lib()
     try:
         if how == "chunks":
@@ -143,8 +141,7 @@ def test_row_classes_are_one_shot_and_validated(gpu):
     g = torch.Generator().manual_seed(7)
     w = [((torch.rand(s, generator=g) - 0.5) * 0.3).to(dev) for s in ((4 * H, I), (4 * H, H), (4 * H, I), (4 * H, H))]
     x = torch.randn(T, N, I, generator=g).to(dev)
-    rs = torch.ones(N, device=dev)
-    rs._aas_row_len = (2, T, 5)
+    rs = ops.RowWeights(torch.ones(N, device=dev), row_len=(2, T, 5))
     y1 = _layer("lstm", x, w, rs=rs)
     y2 = _layer("lstm", x, w)              # the setting was consumed by the launch above
     y3 = _layer("lstm", x, w)
@@ -152,17 +149,17 @@ def test_row_classes_are_one_shot_and_validated(gpu):
     assert float(y1[5:, 2:].abs().max()) == 0.0 and float(y2[5:, 2:].abs().max()) > 0.0
     assert torch.equal(y2, y3)
     assert torch.equal(y1[:, :2], y2[:, :2])
-    rs._aas_row_len = (2, T + 1, 5)        # longer than the launch
+    rs.row_len = (2, T + 1, 5)        # longer than the launch
     with pytest.raises(RuntimeError, match="row classes"):
         _layer("lstm", x, w, rs=rs)
-    rs._aas_row_len = (2, 5, 6)            # neither class spans the launch
+    rs.row_len = (2, 5, 6)            # neither class spans the launch
     with pytest.raises(RuntimeError, match="row classes"):
         _layer("lstm", x, w, rs=rs)
     y4 = _layer("lstm", x, w)              # a refused setting does not linger
     torch.cuda.synchronize()
     assert torch.equal(y2, y4)
     with pytest.raises(NotImplementedError):
-        rs._aas_row_len = (2, T, 5)
+        rs.row_len = (2, T, 5)
         ops.birnn_layer(x, w[0][:H], w[1][:H], w[2][:H], w[3][:H], kind="rnn", rs=rs)
 
 
@@ -188,8 +185,7 @@ def test_row_classes_random_shapes_and_degenerate_classes(gpu):
         T, N = max(Ta if Na else 0, Tb if Nb else 0), Na + Nb
         x = torch.randn(T, N, I, generator=g).to(dev)
         dy = torch.randn(T, N, H, generator=g).to(dev)
-        rs = torch.ones(N, device=dev)
-        rs._aas_row_len = (Na, Ta if Na else T, Tb if Nb else T)
+        rs = ops.RowWeights(torch.ones(N, device=dev), row_len=(Na, Ta if Na else T, Tb if Nb else T))
         ws = [t.clone().requires_grad_(True) for t in w]
         xj = x.clone().requires_grad_(True)
         y = _layer(kind, xj, ws, rs=rs)

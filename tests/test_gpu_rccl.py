@@ -183,6 +183,88 @@ def test_am_async_steps_on_one_rank_rccl_config5_buckets_and_goldens():
         assert big >= 4, (it, big)
 
 
+def _readiness_worker(port, q):
+    """One-rank RCCL, config 2, frozen A (the headline's configuration), steady state: (1) the data-parallel step issues NO host
+    synchronisation (torch's sync debug mode raises on one); (2) HIP events on the issuing streams say when each gradient bucket's
+    all-reduce becomes eligible relative to the launch that first consumes the reduced gradients (optimizer_g.step_dev)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", AAS_DP_FORCE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", AAS_PRECISION="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from aas_enhancement_amd import ops
+        from aas_enhancement_amd.trainer_AAS import Trainer
+        from tests.test_gpu_round2 import _config2_batches, _config2_models
+        from tests.test_gpu_step import cfg
+        tr = Trainer(cfg(lr=1e-5, nFeat=80, rnn_size=500, allow_ASR_update_iter=10 ** 9), None, models=_config2_models())
+        ny, cl = _config2_batches(0)
+        dev = torch.device("cuda", 0)
+        ny = tuple(t_.to(dev) if (torch.is_tensor(t_) and t_.dim() == 3) else t_ for t_ in ny)
+        cl = tuple(t_.to(dev) if (torch.is_tensor(t_) and t_.dim() == 3) else t_ for t_ in cl)
+        ny[4].n_valid = cl[4].n_valid = 30 * 200
+        for it in range(10):                       # allocator pools, scratch, streams, the pinned staging ring: all settled
+            tr.train_step_async(ny, cl, it)
+        torch.cuda.synchronize()
+        assert tr.dp.active and tr._last_schedule == "batched"
+        sync_error = None
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            for it in range(10, 14):
+                tr.train_step_async(ny, cl, it)
+        except Exception as e:  # noqa: BLE001
+            sync_error = repr(e)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+        marks = []
+        ops.Profiler.start(("coll", "mark"))
+        for it in range(14, 18):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            marks.append((e, len(ops.Profiler.records)))
+            tr.train_step_async(ny, cl, it)
+        marks.append((None, len(ops.Profiler.records)))
+        torch.cuda.synchronize()
+        recs = list(ops.Profiler.records)
+        ops.Profiler.enabled = False
+        steps = []
+        for i in range(4):
+            rows = []
+            for name, _, e0, e1, _t in recs[marks[i][1]:marks[i + 1][1]]:
+                rows.append((name, marks[i][0].elapsed_time(e0)))
+            steps.append(rows)
+        tr.read_scalars()
+        q.put(dict(ok=True, sync_error=sync_error, steps=steps, timeout=ops.rnn_timeout_flag()))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(dict(ok=False, err=traceback.format_exc() + repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_step_issues_no_host_sync_and_buckets_run_ahead_of_the_optimiser():
+    """Multi-GPU readiness on the one GPU there is (no 8-GPU node has been available in any round): the device-resident
+    data-parallel step queues without a host synchronisation, and every gradient bucket except the one of the layer that is
+    back-propagated last (E's first, left to the final flush by design) becomes eligible >= 0.5 ms before optimizer_g.step_dev is
+    queued - an 8-rank ring all-reduce of a 15.3 MB bucket takes 0.18 ms on one xGMI link direction, so only that last
+    bucket's duration is exposed."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = _run_child(_readiness_worker)
+    assert not out["timeout"]
+    assert out["sync_error"] is None, out["sync_error"]
+    for rows in out["steps"][1:]:
+        opt = [t for n, t in rows if n.startswith("optimizer_g")]
+        colls = sorted((t, n) for n, t in rows if n.startswith("allreduce"))
+        assert len(opt) == 1 and len(colls) >= 8, rows
+        big = [(t, n) for t, n in colls if float(n.split("[")[1].split(" MB")[0]) >= 4.0]
+        assert len(big) >= 7, colls                          # 4 layer buckets of D, 3 of E (+ the final flush holding E's first layer)
+        early = [t for t, n in big[:-1]]
+        assert all(t <= opt[0] - 0.5 for t in early), (opt, big)
+        assert all(t <= opt[0] + 0.05 for t, n in colls), (opt, colls)       # nothing is issued behind the optimiser
+
+
 def test_bench_gpus_2_on_a_one_gpu_box_fails_fast_with_a_clear_message():
     """`python bench.py --gpus N` starts its own N ranks (no launcher needed); with fewer devices than ranks it must say so
     and exit non-zero before anything touches the GPU - not hang, not exit 0."""

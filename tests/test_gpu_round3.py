@@ -322,7 +322,7 @@ def test_train_loop_dp_with_sharding_loader_and_syncbn_across_save_iter(gpu, tmp
     assert any(f.startswith("G_3") for f in res[0][4]) and any(f.startswith("ASR_3") for f in res[0][4])
     from aas_enhancement_amd import ops
     single = _run_train(tmp, 71, None)
-    assert ops.SYNC_BN[0] is None
+    assert single.launch.sync_bn is None and ops.state().sync_bn is None
     for got, want in ((res[0][1], single._flat["G"].flat_p), (res[0][2], single._flat["A"].flat_p)):
         d_ = np.abs(got - want.detach().cpu().numpy())
         assert float((d_ > 2e-4).mean()) < 5e-3 and float(d_.max()) < 8.1e-3
@@ -543,10 +543,10 @@ def test_birnn_layer_fp32_equivalent_mode_vs_cpu(gpu, kind, T, N, H, classes):
     rs = None
     scale = torch.ones(N)
     if classes == 2:
-        rs = torch.empty(N, device="cuda")
-        rs[:N // 2] = -0.37
-        rs[N // 2:] = 1.0
-        rs._aas_classes = [(0, N // 2, rs[0:1]), (N // 2, N - N // 2, None)]
+        w_ = torch.empty(N, device="cuda")
+        w_[:N // 2] = -0.37
+        w_[N // 2:] = 1.0
+        rs = ops.RowWeights(w_, classes=[(0, N // 2, w_[0:1]), (N // 2, N - N // 2, None)])
         scale[:N // 2] = -0.37
     try:
         ops.set_precision(2)

@@ -215,3 +215,126 @@ def test_dce_and_fsegan_validation_need_the_acoustic_model(gpu):
     for tr in (DCE(cfg(), None, models=(G,)), FSEGAN(cfg(), None, models=(G, D))):
         with pytest.raises(RuntimeError, match="acoustic model"):
             tr.validate_and_checkpoint(0)
+
+
+# ---- launch parameters are arguments / per-thread scopes: two host threads, two trainers ------------------------------------------
+def test_two_host_threads_two_trainers_bit_equal_to_each_alone(gpu):
+    """Two host threads drive two trainers at the same time - one on ragged noisy / clean pairs (row classes inside D's recurrent
+    launches, F1r), one on equal-length pairs in another arithmetic mode and with other kernel-selection bits (F1) - each on a
+    stream of its own, through the device-resident step.  Every scalar and every parameter equals, bit for bit, what the same
+    trainer produces alone: no launch of one thread runs under the other's row classes, CU budget, tag, mode or flags (they travel
+    as the aasLaunch argument / the thread's launch scope), and nothing is left behind in the process settings."""
+    import threading
+    from aas_enhancement_amd import ops
+    from aas_enhancement_amd._lib import lib
+    from aas_enhancement_amd.trainer_AAS import Trainer
+    from tests.helpers import batch_from
+    from tests.test_gpu_step import build_tiny
+    zr, ze = load("f1r_aas_tiny_ragged_pair.npz"), load("f1_aas_tiny.npz")
+    spec = [dict(z=zr, precision=0, flags=0), dict(z=ze, precision=1, flags=512)]
+    STEPS = 6
+
+    def make(i):
+        z = spec[i]["z"]
+        tr = Trainer(cfg(lr=float(z["cfg_lr"])), None, models=build_tiny(z))
+        tr.kt = float(z["kt0"])
+        tr.set_precision(spec[i]["precision"])
+        tr.launch = ops.LaunchState(debug_flags=spec[i]["flags"])
+        return tr
+
+    def drive(i, tr, out, start=None, errs=None):
+        try:
+            z = spec[i]["z"]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                if start is not None:
+                    start.wait()
+                rows = []
+                for it in range(STEPS):
+                    ny, cl = batch_from(z, "it%d.ny." % (it % 3)), batch_from(z, "it%d.cl." % (it % 3))
+                    r = tr.train_step_async(ny, cl, it)
+                    if i == 0:
+                        assert tr._last_schedule == "batched-ragged"
+                    sc = tr.read_scalars()
+                    rows.append([sc[k] for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt")] + [float(r["enhanced"].double().sum()), float(r["prob"].double().sum())])
+                st.synchronize()
+            out[i] = (np.asarray(rows), {k: v.detach().clone() for m in (tr.G, tr.D, tr.ASR) for k, v in m.state_dict().items()})
+        except BaseException as e:  # noqa: BLE001
+            if errs is not None:
+                errs.append((i, repr(e)))
+            raise
+    before = (ops.get_precision(), int(lib().aas_get_gemm_max_steps()), int(lib().aas_get_debug_flags()))
+    alone = {}
+    for i in (0, 1):
+        drive(i, make(i), alone)
+    both, errs = {}, []
+    trs = [make(0), make(1)]
+    start = threading.Barrier(2)
+    ths = [threading.Thread(target=drive, args=(i, trs[i], both, start, errs)) for i in (0, 1)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert not ops.rnn_timeout_flag()
+    assert (ops.get_precision(), int(lib().aas_get_gemm_max_steps()), int(lib().aas_get_debug_flags())) == before
+    for i in (0, 1):
+        assert np.array_equal(alone[i][0], both[i][0]), (i, alone[i][0] - both[i][0])
+        for k, v in alone[i][1].items():
+            assert torch.equal(v, both[i][1][k]), (i, k)
+
+
+def test_launch_argument_entry_points_through_ctypes(gpu):
+    """aas_lstm_fwd_ex with an aasLaunch built by hand (what a C caller writes): row classes are taken from the struct and consumed,
+    the plain entry point right after sees none; a struct of the wrong size is refused; a scope installed with aas_launch_scope
+    applies to the plain entry point and is gone after it is removed."""
+    import ctypes
+    from aas_enhancement_amd import _lib, ops
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    H, T, N = 32, 12, 4
+    g = torch.Generator().manual_seed(3)
+    w_hh, w_hr = [((torch.rand(4 * H, H, generator=g) - 0.5) * 0.3).to(dev) for _ in range(2)]
+    pre = torch.randn(T, N, 2, 4 * H, generator=g).to(dev)
+    sync = torch.zeros(int(L.aas_rnn_sync_bytes()), dtype=torch.uint8, device=dev)
+    xchg = torch.empty(int(L.aas_rnn_xchg_bytes(T, N, H, 4)), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(fn, *extra):
+        hout, gact, cst = (torch.empty(2, T, N, H, device=dev), torch.empty(2, T, N, 4 * H, device=dev), torch.empty(2, T, N, H, device=dev))
+        rc = fn(st, T, N, H, pre.data_ptr(), w_hh.data_ptr(), w_hr.data_ptr(), hout.data_ptr(), gact.data_ptr(), cst.data_ptr(), sync.data_ptr(),
+                xchg.data_ptr(), *extra)
+        torch.cuda.synchronize()
+        return rc, hout
+    la = ops._new_claunch()
+    la.cls_n_first, la.cls_T_first, la.cls_T_rest, la.rnn_tag = 2, T, 5, 7
+    rc, y1 = run(L.aas_lstm_fwd_ex, ctypes.byref(la))
+    assert rc == 0 and la.cls_n_first == -1                       # consumed
+    rc, y2 = run(L.aas_lstm_fwd)
+    assert rc == 0
+    assert float(y1[:, 5:, 2:].abs().max()) == 0.0 and float(y2[:, 5:, 2:].abs().max()) > 0.0 and torch.equal(y1[:, :, :2], y2[:, :, :2])
+    rc, y3 = run(L.aas_lstm_fwd_ex, None)                          # NULL = the plain entry point
+    assert rc == 0 and torch.equal(y3, y2)
+    bad = ops._new_claunch()
+    bad.size = 8
+    rc, _ = run(L.aas_lstm_fwd_ex, ctypes.byref(bad))
+    assert rc != 0 and b"aasLaunch.size" in L.aas_last_error()
+    # a thread scope applies to the plain entry points
+    la.cls_n_first, la.cls_T_first, la.cls_T_rest = 2, T, 5
+    assert L.aas_launch_scope(ctypes.byref(la), None) == 0
+    try:
+        rc, y4 = run(L.aas_lstm_fwd)
+    finally:
+        assert L.aas_launch_scope(None, None) == 0
+    assert rc == 0 and torch.equal(y4, y1)
+    rc, y5 = run(L.aas_lstm_fwd)
+    assert rc == 0 and torch.equal(y5, y2)
+    # nn.RNN launches refuse pending row classes instead of leaking them into the next lstm / gru launch
+    assert L.aas_set_rnn_row_classes(2, T, 5) == 0
+    hout, gact = torch.empty(2, T, N, H, device=dev), torch.empty(2, T, N, 4 * H, device=dev)
+    pre1 = torch.randn(T, N, 2, H, generator=g).to(dev)
+    rc = L.aas_rnn_fwd(st, T, N, H, pre1.data_ptr(), w_hh.data_ptr(), w_hr.data_ptr(), hout.data_ptr(), gact.data_ptr(), sync.data_ptr())
+    assert rc != 0 and b"row classes" in L.aas_last_error()
+    rc, y6 = run(L.aas_lstm_fwd)
+    assert rc == 0 and torch.equal(y6, y2)

@@ -53,5 +53,17 @@ int main() {
     run("odd bits", odd);
     run("bits 0..63", first64);
     run("alternating groups of 8", x8);
+    // Round 6: can a mask select WHOLE XCDs?  bit i -> XCD i mod 8 by the rows above, so "i mod 8 < 4" asks for
+    // XCDs 0-3 with all their CUs and none on XCDs 4-7, the complement for the other four; the third mask keeps one CU-pair row alive
+    // on the excluded XCDs (bits 4..7 of the first group of eight).
+    std::vector<uint32_t> x03(8, 0), x47(8, 0), x03p(8, 0);
+    for (int i = 0; i < 256; ++i) {
+        if (i % 8 < 4) { x03[i / 32] |= 1u << (i % 32); x03p[i / 32] |= 1u << (i % 32); }
+        else x47[i / 32] |= 1u << (i % 32);
+        if (i < 8 && i % 8 >= 4) x03p[i / 32] |= 1u << (i % 32);
+    }
+    run("bits i mod 8 < 4 (XCD 0-3)", x03);
+    run("bits i mod 8 >= 4 (XCD 4-7)", x47);
+    run("XCD 0-3 + bit 4..7", x03p);
     return 0;
 }
