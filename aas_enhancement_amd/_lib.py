@@ -69,6 +69,7 @@ SIGNATURES = {
     "aas_began_step_raw": [c_vp, c_vp, ctypes.c_double, ctypes.c_double, c_vp, c_int, ctypes.c_double, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double],
     "aas_began_step_sums": [c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_vp],
     "aas_loss_pack": [c_vp, c_vp, c_vp, c_int, c_vp],
+    "aas_sums_pack": [c_vp, c_vp, c_vp, c_vp],
     "aas_scales_from_counts": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp],
     "aas_scale_dev_f32": [c_vp, c_vp, c_vp, c_vp, c_f32, c_i64],
     "aas_colsum_f32": [c_vp, c_vp, c_i64, c_int, c_i64, c_vp, c_int],
@@ -95,6 +96,8 @@ SIGNATURES = {
     "aas_col2im_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int],
     "aas_l1_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "aas_l1_bwd": [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_int],
+    "aas_l1_fwd2d": [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp],
+    "aas_l1_bwd2d": [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_i64, c_int, c_vp, c_i64],
     "aas_ctc_get_workspace_size": [c_vp, c_vp, c_int, c_int, c_int, ctypes.POINTER(c_sz)],
     "aas_compute_ctc_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int],
     "aas_ctc_loss_async": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_f32],

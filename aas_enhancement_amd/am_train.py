@@ -23,7 +23,7 @@ import torch
 from . import knobs, ops
 from .ctc import CTCLoss
 from .decoder import GreedyDecoder
-from .dist import BucketReducer, DeviceCounts, DPContext, FlatBuffers
+from .dist import BucketReducer, DeviceCounts, DeviceScales, DPContext, FlatBuffers
 from .model import DeepSpeech, supported_rnns
 from .optim import FlatAdam, FlatSGD
 from .utils import AverageMeter, _get_variable_nograd
@@ -117,54 +117,61 @@ class AMTrainer(ops.TrainerContext):
         N = inputs.size(0)
         t_out = self.model.output_length(inputs.size(2))
         sizes = input_percentages.clone().mul_(int(t_out)).int()
-        if not self.dp.active:
-            return self._device_step(inputs, targets, sizes, target_sizes, N)
-        meta = self.criterion.prepare(targets, sizes, target_sizes, inputs.device)
-        if getattr(self, "_aux", None) is None:
-            self._aux = ops.refresh_stream(inputs.device)
-        counts = DeviceCounts(self.dp, [N], inputs.device, self._aux)
-        ops.sync_wgrad()
-        self.flat.zero_grad()
-        self._reducer.begin()
-        self.launch.wgrad_hook = self._reducer.on_wgrad
-        try:
-            ops.set_rnn_cu_limit(_fwd_cus())
-            out = self.model(inputs).transpose(0, 1)
-            loss = self.criterion(out, targets, sizes, target_sizes, prepared=meta)
-            loss = loss * (1.0 / counts.get(0)).float()
-            ops.set_rnn_cu_limit(_bwd_cus())
-            loss.backward()
-            ops.sync_wgrad()
-            self._reducer.flush(self.flat)
-            self._reducer.wait()
-        finally:
-            self.launch.wgrad_hook = None
-            ops.set_rnn_cu_limit(0)
-        v = self.dp.reduce_scalars(loss.detach().reshape(1).clone())
-        self.opt.step_dev()
-        return dict(loss_dev=v, handle=self._loss_to_host(v, 1.0), logits=out)
+        return self._device_step(inputs, targets, sizes, target_sizes, N)
 
     def _device_step(self, inputs, targets, sizes, target_sizes, N):
-        """The single-process step as library launches only: the CTC metadata goes up from a pinned staging ring, ONE prologue
-        launch zeroes the flat gradient buffer, the loss weight 1 / N (:319-320) rides in the CTC kernel's gradient scale (the
-        root is the vector of per-utterance costs), and the logged value is their raw sum, scaled where it is read."""
-        dev = inputs.device
+        """The step as library launches only: the CTC metadata goes up from a pinned staging ring, ONE prologue launch zeroes the
+        flat gradient buffer, the loss weight 1 / N (:319-320) rides in the CTC kernel's gradient scale (the root is the vector of
+        per-utterance costs), and the logged value is their raw sum, scaled where it is read.  Data parallel: 1 / N_global is a
+        device scalar formed from the all-reduced batch sizes (dist.DeviceScales; one launch applies it to the CTC gradient), the
+        flat gradient buffer is all-reduced bucket by bucket behind the weight-gradient products, and the logged loss is the
+        all-reduced cost sum times that scalar (one controller launch on the utility stream) - no host synchronisation."""
+        dev, dp = inputs.device, self.dp
         meta = ops.ctc_prepare(targets, sizes, target_sizes, "cpu")
         meta = dict(meta, meta=self._upload_small(meta["meta"], dev))
         ops.sync_wgrad()
+        if dp.active:
+            if getattr(self, "_aux", None) is None:
+                self._aux = ops.refresh_stream(dev)   # the one utility stream (few hardware queues)
+            cnt = self._upload_small(torch.tensor([float(N)], dtype=torch.float64), dev)
+            scales = DeviceScales(dp, cnt, [1.0, 1.0, 1.0], [0, 0, 0], self._aux)
+            scale = scales[0]
+        else:
+            scale = 1.0 / N
         ops.step_prologue([self.flat.flat_g])
+        if dp.active:
+            self._reducer.begin()
+            self.launch.wgrad_hook = self._reducer.on_wgrad
         try:
             ops.set_rnn_cu_limit(_fwd_cus())
             out = self.model(inputs).transpose(0, 1)
-            costs = ops.ctc_scaled(out, self.criterion.blank, meta, 1.0 / N)
+            costs = ops.ctc_scaled(out, self.criterion.blank, meta, scale)
             ops.set_rnn_cu_limit(_bwd_cus())
             torch.autograd.backward([costs], [ops.unit_root(costs)])
             ops.sync_wgrad()
+            if dp.active:
+                self._reducer.flush(self.flat)
+                self._reducer.wait()
         finally:
+            self.launch.wgrad_hook = None
             ops.set_rnn_cu_limit(0)
         self.opt.step_dev()
-        # the N per-utterance costs go to the host as they are (summed and scaled where the loss is read: no reduction launch)
-        return dict(costs_dev=costs.detach(), loss_scale=1.0 / N, handle=self._loss_to_host(costs.detach(), 1.0 / N), logits=out)
+        if not dp.active:
+            # the N per-utterance costs go to the host as they are (summed and scaled where the loss is read: no reduction launch)
+            return dict(costs_dev=costs.detach(), loss_scale=1.0 / N, handle=self._loss_to_host(costs.detach(), 1.0 / N), logits=out)
+        if getattr(self, "_dp_acc", None) is None:
+            self._dp_acc = (torch.zeros(1, device=dev, dtype=torch.float64), torch.zeros(6, device=dev, dtype=torch.float64))
+        main = torch.cuda.current_stream()
+        self._aux.wait_stream(main)
+        with torch.cuda.stream(self._aux):
+            out3 = torch.empty(3, device=dev, dtype=torch.float64)
+            ops.loss_pack(None, costs.detach(), out3)            # [0, 0, sum of this rank's costs]
+            dp.reduce_scalars(out3)
+            ops.began_step_sums(out3, out3[2:], 0.0, 0.0, 1.0, self._dp_acc[0], self._dp_acc[1], 0.0, 0.0, 0.0, d_scales3=scales.all, d_n_batch=scales.cnt)
+            handle = self._loss_to_host(self._dp_acc[1][2:3], 1.0)     # slot 2 = the global loss: sum over all ranks' costs / N_global
+        for t_ in (costs, scales.all, scales.cnt):
+            t_.record_stream(self._aux)
+        return dict(handle=handle, logits=out)
 
     def _loss_to_host(self, v, scale):
         """Asynchronous copy of a device loss scalar into a ring of four pinned slots -> the handle `read_loss` waits for."""
@@ -175,9 +182,9 @@ class AMTrainer(ops.TrainerContext):
         ring["i"] += 1
         if slot[1] is not None:
             slot[1].synchronize()          # (the copy of four steps ago)
-        if slot[0].numel() != v.numel():
-            slot[0] = torch.zeros(v.numel(), dtype=torch.float32).pin_memory()
-        slot[0].copy_(v.to(torch.float32), non_blocking=True)
+        if slot[0].numel() != v.numel() or slot[0].dtype != v.dtype:
+            slot[0] = torch.zeros(v.numel(), dtype=v.dtype).pin_memory()
+        slot[0].copy_(v, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         slot[1], slot[2] = ev, float(scale)
@@ -186,7 +193,7 @@ class AMTrainer(ops.TrainerContext):
     def read_loss(self, handle):
         """-> (logged loss, is_inf) of a train_step_async; waits for that step's loss copy only."""
         handle[1].synchronize()
-        loss_value = float(handle[0].sum(dtype=torch.float32)) * (handle[2] if len(handle) > 2 else 1.0)
+        loss_value = float(handle[0].sum(dtype=handle[0].dtype)) * (handle[2] if len(handle) > 2 else 1.0)
         is_inf = loss_value in (float("inf"), float("-inf"))
         if not is_inf:
             ops.check_rnn_health((loss_value,))

@@ -117,6 +117,49 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a
     }
 }
 
+// Row-strided forms of the two L1 kernels: `rows` rows of `cols` valid elements, a / b / ga / gb with their own row pitches - the
+// loss of one utterance class of a batched pass over a ragged pair (each class's own frames of a tensor padded to the longer class's
+// length).  The backward kernel also ZEROES columns [cols, ga_cols) of ga: no gradient reaches the padding.
+__global__ __launch_bounds__(256) void l1_fwd2d_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                       int64_t rows, int cols, double* __restrict__ acc) {
+    __shared__ double part[4];
+    const int64_t n = rows * cols;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float s = 0.f;
+    for (; i < n; i += stride) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        s += fabsf(a[r * lda + c] - b[r * ldb + c]);
+    }
+    double d = wave_sum_d((double)s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void l1_bwd2d_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                       int64_t rows, int cols, float scale, const float* __restrict__ d_scale,
+                                                       float* __restrict__ ga, int64_t ldga, int ga_cols, float* __restrict__ gb, int64_t ldgb) {
+    const int width = ga ? (ga_cols > cols ? ga_cols : cols) : cols;
+    const int64_t n = rows * width;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if (d_scale) scale *= d_scale[0];
+    for (; i < n; i += stride) {
+        const int64_t r = i / width;
+        const int c = (int)(i - r * width);
+        if (c < cols) {
+            const float d = a[r * lda + c] - b[r * ldb + c];
+            const float g = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+            if (ga) ga[r * ldga + c] = g;
+            if (gb) gb[r * ldgb + c] = -g;
+        } else {
+            ga[r * ldga + c] = 0.f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ vmax, int64_t n, float b1, float b2, float eps,
@@ -341,6 +384,30 @@ extern "C" int aas_l1_bwd(aasStream_t stream, const float* a, const float* b, in
     return 0;
 }
 
+extern "C" int aas_l1_fwd2d(aasStream_t stream, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int cols,
+                            double* loss_sum) {
+    AAS_CHECK(a && b && loss_sum && rows >= 0 && cols >= 0 && lda >= cols && ldb >= cols, "aas_l1_fwd2d: bad args");
+    if (rows == 0 || cols == 0) return 0;
+    const int g = grid_for(rows * cols);
+    hipLaunchKernelGGL(l1_fwd2d_kernel, dim3(g > 512 ? 512 : g), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, rows, cols, loss_sum);
+    AAS_LAUNCH_CHECK("aas_l1_fwd2d");
+    return 0;
+}
+
+extern "C" int aas_l1_bwd2d(aasStream_t stream, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int cols, float scale,
+                            const float* d_scale, float* ga, int64_t ldga, int ga_cols, float* gb, int64_t ldgb) {
+    AAS_CHECK(a && b && rows >= 0 && cols >= 0 && lda >= cols && ldb >= cols, "aas_l1_bwd2d: bad args");
+    AAS_CHECK(!ga || (ldga >= cols && ldga >= ga_cols), "aas_l1_bwd2d: ga pitch");
+    AAS_CHECK(!gb || ldgb >= cols, "aas_l1_bwd2d: gb pitch");
+    if (rows == 0 || (!ga && !gb)) return 0;
+    const int width = ga ? (ga_cols > cols ? ga_cols : cols) : cols;
+    if (width == 0) return 0;
+    hipLaunchKernelGGL(l1_bwd2d_kernel, dim3(grid_for(rows * width)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, rows, cols, scale, d_scale,
+                       ga, ldga, ga_cols, gb, ldgb);
+    AAS_LAUNCH_CHECK("aas_l1_bwd2d");
+    return 0;
+}
+
 extern "C" int aas_adam_f32(aasStream_t stream, float* p, const float* g, float* m, float* v, float* vmax, int64_t n,
                             float lr, float beta1, float beta2, float eps, int step, int amsgrad, float grad_scale) {
     AAS_CHECK(p && g && m && v && (vmax || !amsgrad) && n >= 0 && step >= 1, "aas_adam_f32: bad args");
@@ -449,9 +516,14 @@ __global__ void began_step_sums_kernel(const double* __restrict__ sums, const do
 __global__ void loss_pack_kernel(const double* __restrict__ l1_sums, const float* __restrict__ costs, int n_costs, double* __restrict__ out3) {
     float cs = 0.f;                                   // (fp32 running sum in utterance order, as began_step_raw_kernel)
     for (int i = 0; i < n_costs; ++i) cs += costs[i];
-    out3[0] = l1_sums[0];
-    out3[1] = l1_sums[1];
+    out3[0] = l1_sums ? l1_sums[0] : 0.0;
+    out3[1] = l1_sums ? l1_sums[1] : 0.0;
     out3[2] = (double)cs;
+}
+__global__ void sums_pack_kernel(const double* __restrict__ a2, const double* __restrict__ b1, double* __restrict__ out3) {
+    out3[0] = a2 ? a2[0] : 0.0;
+    out3[1] = a2 ? a2[1] : 0.0;
+    out3[2] = b1 ? b1[0] : 0.0;
 }
 __global__ void scales_from_counts_kernel(const double* __restrict__ counts, int n, double w0, double w1, double w2, double w3, int i0, int i1,
                                           int i2, int i3, float* __restrict__ out) {
@@ -504,9 +576,16 @@ extern "C" int aas_began_step_sums(aasStream_t stream, const double* d_l1_sums, 
 }
 
 extern "C" int aas_loss_pack(aasStream_t stream, const double* d_l1_sums, const float* d_ctc_costs, int n_costs, double* d_out3) {
-    AAS_CHECK(d_l1_sums && d_out3 && n_costs >= 0 && (n_costs == 0 || d_ctc_costs), "aas_loss_pack: null pointer");
+    AAS_CHECK(d_out3 && n_costs >= 0 && (n_costs == 0 || d_ctc_costs), "aas_loss_pack: null pointer");
     hipLaunchKernelGGL(loss_pack_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_l1_sums, d_ctc_costs, n_costs, d_out3);
     AAS_LAUNCH_CHECK("aas_loss_pack");
+    return 0;
+}
+
+extern "C" int aas_sums_pack(aasStream_t stream, const double* d_a2, const double* d_b1, double* d_out3) {
+    AAS_CHECK(d_out3 && (d_a2 || d_b1), "aas_sums_pack: null pointer");
+    hipLaunchKernelGGL(sums_pack_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_a2, d_b1, d_out3);
+    AAS_LAUNCH_CHECK("aas_sums_pack");
     return 0;
 }
 

@@ -228,6 +228,37 @@ class DeviceCounts(object):
         return self.t[i]
 
 
+class DeviceScales(object):
+    """Loss normalisers of a data-parallel step that never leave the device: `cnt` (a device fp64 vector of this rank's counts - N,
+    nElement ... - uploaded by the caller) is SUM-all-reduced on the auxiliary stream, then ONE library launch forms
+    scales[i] = weights[i] / cnt[index[i]] as device floats (include/aas_hip.h: aas_scales_from_counts).  `sc[i]` / `sc.count(i)`
+    make the CURRENT stream wait for that stream's event (device side, not host side) and return a 0-dim device view: the
+    collective's latency hides behind whatever the caller queued in between."""
+
+    def __init__(self, dp, cnt, weights, index, aux):
+        from . import ops
+        main = torch.cuda.current_stream()
+        aux.wait_stream(main)                      # the upload of `cnt`
+        with torch.cuda.stream(aux):
+            dp.reduce_scalars(cnt)
+            self.all = torch.empty(max(3, len(weights)), device=cnt.device, dtype=torch.float32)
+            ops.scales_from_counts(cnt, list(weights), list(index), self.all)
+            self.vals = tuple(self.all[i] for i in range(len(weights)))
+            self.cnt = cnt
+            self.ev = torch.cuda.Event()
+            self.ev.record(aux)
+        for t_ in (self.all, cnt):
+            t_.record_stream(main)
+
+    def __getitem__(self, i):
+        torch.cuda.current_stream().wait_event(self.ev)
+        return self.vals[i]
+
+    def count(self, i):
+        torch.cuda.current_stream().wait_event(self.ev)
+        return self.cnt[i]
+
+
 class _Done(object):
     def wait(self):
         return True

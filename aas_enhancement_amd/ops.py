@@ -80,6 +80,7 @@ def clear_rnn_timeout():
             b.view(torch.int32)[1024:1025].zero_()
         elif k[0] in ("xchg_fwd", "xchg_bwd"):
             lib().aas_rnn_xchg_forget(ptr(b))
+            _xchg_meta.pop(k, None)        # (not a fallback of the library's: prepare afresh at the next use)
 
 
 def check_rnn_health(scalars=()):
@@ -124,9 +125,22 @@ def _xchg_buf(dev, T, N, H, G, kind="any"):
             lib().aas_rnn_xchg_forget(ptr(b))
         b = torch.empty(need, dtype=torch.uint8, device=dev)
         _scratch[key] = b
-    if (grown or not lib().aas_rnn_xchg_is_managed(ptr(b))) and not torch.cuda.is_current_stream_capturing():
+        _xchg_meta[key] = dict(last=None, fell=set())
+    meta = _xchg_meta.setdefault(key, dict(last=None, fell=set()))
+    managed = bool(lib().aas_rnn_xchg_is_managed(ptr(b)))
+    shape = (T, N, H, G, state().rnn_cu_limit)
+    if not grown and not managed and meta["last"] is not None:
+        # the previous launch on this buffer ended its management: the library fell back to its own poison fill for that shape (a
+        # launch of fewer than 4 steps, a batch split over several launches, ...).  Preparing the buffer again for the same shape
+        # would only add a whole-buffer memset in front of the library's own: hand it out as it is until the shape changes.
+        meta["fell"].add(meta["last"])
+    if (grown or not managed) and shape not in meta["fell"] and not torch.cuda.is_current_stream_capturing():
         check(lib().aas_rnn_xchg_prepare(stream(), ptr(b), b.numel()), "aas_rnn_xchg_prepare")
+    meta["last"] = shape
     return b
+
+
+_xchg_meta = {}
 
 
 @_locked
@@ -1965,19 +1979,33 @@ class _L1Pair(torch.autograd.Function):
         require_cuda(ae, leaf, clean)
         ctx.target_grad = target_grad
         ae, leaf, clean = _c(ae), _c(leaf), _c(clean)
-        n0, n1 = leaf.numel(), clean.numel()
-        assert ae.numel() == n0 + n1 and acc.dtype == torch.float64 and acc.numel() == 2
-        check(lib().aas_l1_fwd(stream(), ptr(ae), ptr(leaf), n0, ptr(acc)), "aas_l1_fwd")
-        check(lib().aas_l1_fwd(stream(), ae.data_ptr() + 4 * n0, ptr(clean), n1, acc.data_ptr() + 8), "aas_l1_fwd")
+        assert acc.dtype == torch.float64 and acc.numel() == 2
+        # ae [Nn + Nc, F, T]: rows [0, Nn) against leaf [Nn, F, Tn], rows [Nn, ..) against clean [Nc, F, Tc], T = max(Tn, Tc): a class
+        # shorter than T takes the row-strided kernels over its own frames (ragged noisy / clean pair, one batched D pass)
+        Nn, Fd, Tn = leaf.shape
+        Nc, Tc = clean.shape[0], clean.shape[2]
+        T = ae.shape[2]
+        assert tuple(ae.shape) == (Nn + Nc, Fd, T) and clean.shape[1] == Fd and T == max(Tn, Tc)
+        ctx.dims = (Nn, Nc, Fd, Tn, Tc, T)
+        _L1Pair._fwd_class(ae, 0, leaf, Nn * Fd, Tn, T, acc, 0)
+        _L1Pair._fwd_class(ae, Nn * Fd * T, clean, Nc * Fd, Tc, T, acc, 1)
         ctx.save_for_backward(ae, leaf, clean)
         ctx.scales = tuple((s_ if torch.is_tensor(s_) else float(s_)) for s_ in (s_ny, s_cl))    # python floats or device scalars (data parallel)
         ctx.mark_dirty(acc)
         return acc
 
     @staticmethod
+    def _fwd_class(ae, off, tgt, rows, cols, T, acc, slot):
+        a_ptr, acc_ptr = ae.data_ptr() + 4 * off, acc.data_ptr() + 8 * slot
+        if cols == T:
+            check(lib().aas_l1_fwd(stream(), a_ptr, ptr(tgt), rows * cols, acc_ptr), "aas_l1_fwd")
+        else:
+            check(lib().aas_l1_fwd2d(stream(), a_ptr, T, ptr(tgt), cols, rows, cols, acc_ptr), "aas_l1_fwd2d")
+
+    @staticmethod
     def backward(ctx, g):
         ae, leaf, clean = ctx.saved_tensors
-        n0, n1 = leaf.numel(), clean.numel()
+        Nn, Nc, Fd, Tn, Tc, T = ctx.dims
         gs = None if getattr(g, "_aas_unit", False) else _c(g.to(torch.float32))
 
         def factors(i):   # -> (host factor, device factor or None) of loss i: its scale times the upstream gradient
@@ -1988,10 +2016,13 @@ class _L1Pair(torch.autograd.Function):
             return 1.0, (sc if gi is None else sc * gi)
         dae = torch.empty_like(ae)
         dleaf = torch.empty_like(leaf) if ctx.needs_input_grad[1] else None
-        f0, d0 = factors(0)
-        f1, d1 = factors(1)
-        check(lib().aas_l1_bwd(stream(), ptr(ae), ptr(leaf), n0, f0, ptr(d0), ptr(dae), ptr(dleaf), 0), "aas_l1_bwd")
-        check(lib().aas_l1_bwd(stream(), ae.data_ptr() + 4 * n0, ptr(clean), n1, f1, ptr(d1), dae.data_ptr() + 4 * n0, None, 0), "aas_l1_bwd")
+        for i, (off, tgt, rows, cols, gt) in enumerate(((0, leaf, Nn * Fd, Tn, dleaf), (Nn * Fd * T, clean, Nc * Fd, Tc, None))):
+            f_, d_ = factors(i)
+            a_ptr, ga_ptr = ae.data_ptr() + 4 * off, dae.data_ptr() + 4 * off
+            if cols == T:
+                check(lib().aas_l1_bwd(stream(), a_ptr, ptr(tgt), rows * cols, f_, ptr(d_), ga_ptr, ptr(gt), 0), "aas_l1_bwd")
+            else:       # the class's own frames; the padding columns of d(ae) are written as zeros
+                check(lib().aas_l1_bwd2d(stream(), a_ptr, T, ptr(tgt), cols, rows, cols, f_, ptr(d_), ga_ptr, T, T, ptr(gt), cols), "aas_l1_bwd2d")
         if ctx.target_grad is not None and dleaf is not None:
             ctx.target_grad.append(dleaf)
             dleaf = None
@@ -2188,6 +2219,10 @@ def began_step_sums(l1_sums, third, s0, s1, s2, d_kt, d_out6, gamma, lambda_k, n
 
 def loss_pack(l1_acc, costs, out3):
     check(lib().aas_loss_pack(stream(), ptr(l1_acc), ptr(costs), int(costs.numel()) if costs is not None else 0, ptr(out3)), "aas_loss_pack")
+
+
+def sums_pack(a2, b1, out3):
+    check(lib().aas_sums_pack(stream(), ptr(a2), ptr(b1), ptr(out3)), "aas_sums_pack")
 
 
 def scales_from_counts(counts, weights, index, out):

@@ -21,35 +21,6 @@ from .utils import _get_variable_nograd, _get_variable_volatile, attach_n_valid
 from .validation import ValidationMixin
 
 
-class _LazyScales(object):
-    """The loss normalisers (w_adversarial / nElement_noisy, w_adversarial / nElement_clean, w_acoustic / N) from counts that are
-    all-reduced on an auxiliary stream and never leave the device: the collective, then ONE library launch that forms the three
-    scales (aas_scales_from_counts).  Whichever stream reads a scale first waits for that stream's event (device side, not host
-    side), so the collective's latency hides behind the forward passes queued in the meantime."""
-
-    def __init__(self, dp, cnt, config, aux):
-        main = torch.cuda.current_stream()
-        aux.wait_stream(main)                      # the upload of `cnt`
-        with torch.cuda.stream(aux):
-            dp.reduce_scalars(cnt)
-            self.all = torch.empty(3, device=cnt.device, dtype=torch.float32)
-            ops.scales_from_counts(cnt, [config.w_adversarial, config.w_adversarial, config.w_acoustic], [1, 2, 0], self.all)
-            self.vals = (self.all[0], self.all[1], self.all[2])
-            self.cnt = cnt
-            self.ev = torch.cuda.Event()
-            self.ev.record(aux)
-        for t_ in (self.all, cnt):
-            t_.record_stream(main)
-
-    def __getitem__(self, i):
-        torch.cuda.current_stream().wait_event(self.ev)
-        return self.vals[i]
-
-    def count(self, i):
-        torch.cuda.current_stream().wait_event(self.ev)
-        return self.cnt[i]
-
-
 class Trainer(ops.TrainerContext, ValidationMixin):
     def __init__(self, config, data_loader=None, models=None):
         self.config = config
@@ -337,8 +308,10 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         # losses stay raw device sums until the controller launch consumes them (no scaling / slicing / summing launches).  Data
         # parallel: the same, with the normalisers as device scalars formed from the all-reduced counts and the three raw loss sums
         # all-reduced before the controller (aas_loss_pack -> all-reduce -> aas_began_step_sums)
-        fused = (knobs.get("FUSED_GLUE") and tuple(cl_inputs.shape) == tuple(inputs.shape)
-                 and not self._lanes_ok(True) and self._interleave_ok())
+        # (a ragged noisy / clean pair on the batched schedule - two row classes inside D's recurrent launches - takes the same path:
+        #  its L1 sums run on the row-strided kernels over each class's own frames)
+        batched = tuple(cl_inputs.shape) == tuple(inputs.shape) or self._ragged_batched_ok(inputs, cl_inputs)
+        fused = knobs.get("FUSED_GLUE") and batched and not self._lanes_ok(True) and self._interleave_ok()
         self._fused = None
         if dp.active:
             cnt = self._upload_small(torch.tensor([float(N), float(nv_ny), float(nv_cl)], dtype=torch.float64), dev)
@@ -346,17 +319,19 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             # them where it is formed (after the forward passes), so the collective's latency hides behind E
             if getattr(self, "_aux_stream", None) is None:
                 self._aux_stream = ops.refresh_stream(dev)
-            scales = _LazyScales(dp, cnt, c, self._aux_stream)
+            from .dist import DeviceScales
+            scales = DeviceScales(dp, cnt, [c.w_adversarial, c.w_adversarial, c.w_acoustic], [1, 2, 0], self._aux_stream)
             n_glob = scales
         else:
             scales = (c.w_adversarial / nv_ny, c.w_adversarial / nv_cl, c.w_acoustic / N)
             n_glob = float(N)
         if fused:
-            if getattr(self, "_l1_acc", None) is None or self._rs_pair.numel() != 2 * N:
+            Nc = cl_inputs.size(0)
+            if getattr(self, "_l1_acc", None) is None or self._rs_pair.numel() != N + Nc:
                 self._l1_acc = torch.zeros(2, device=dev, dtype=torch.float64)
-                self._rs_pair = torch.empty(2 * N, device=dev, dtype=torch.float32)
+                self._rs_pair = torch.empty(N + Nc, device=dev, dtype=torch.float32)
             self._wait_kt()      # (data parallel: kt was advanced on the auxiliary stream behind the previous step's scalar all-reduce)
-            ops.step_prologue([f.flat_g for f in self._flat.values()] + [self._l1_acc], self._rs_pair, N, N, self._kt_dev)
+            ops.step_prologue([f.flat_g for f in self._flat.values()] + [self._l1_acc], self._rs_pair, N, Nc, self._kt_dev)
             self._fused = {}
         elif knobs.get("FUSED_GLUE") and not dp.active:
             # the other single-process device paths (ragged pair on the two-lane schedule, ...): the zero fills and the weights
@@ -763,7 +738,7 @@ class Trainer(ops.TrainerContext, ValidationMixin):
                 self._backward_pair(l_pair, l_CTC, main, side)
             if main is not caller:
                 caller.wait_stream(main)
-                for t_ in (leaf.grad, ae):
+                for t_ in [leaf.grad, ae] + list(self._fused["tgrad"]):     # (the target gradient is read by add3 on the caller's stream too)
                     if t_ is not None:
                         t_.record_stream(caller)
             return None, None, prob, None, leaf_a

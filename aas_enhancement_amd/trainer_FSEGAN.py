@@ -107,58 +107,75 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             mask.n_valid = int(mask.numel()) - int(mask.sum().item())
         return _get_variable_nograd(data_list[0]), _get_variable_nograd(data_list[1]), _get_variable_nograd(mask)
 
-    def _forward_backward(self, mixture, cleans, rs, s_adv, s_dce):
-        """The fused pass shared by both step forms (data parallel: the autograd-scaled form).  D(enhanced | mixture) and
-        D(clean | mixture) share ONE batched pass of 2N rows, the D-step parameter gradients of the enhanced half are (-kt) x its
-        G-step ones (per-utterance weights `rs` on the weight-gradient products only), and E is back-propagated once with
-        d(adv)/d(enhanced) + d(dce)/d(enhanced).
-        s_adv = w_adversarial / nElement, s_dce = 1 / nElement (python floats, or device scalars when data parallel)."""
-        N = mixture.size(0)
-        enhanced = self.G(mixture)
-        leaf = enhanced.detach().requires_grad_(True)
-        ae = self.D(None, wgrad_row_scale=rs, tnc=ops.layout_paired_cat(leaf, mixture, cleans))   # forward_paired x 2 (model.py:233-238)
-        l_adv_ny_G = ops.l1_sum(ae[:N], leaf) * s_adv
-        l_adv_cl = ops.l1_sum(ae[N:], cleans) * s_adv
-        dce = ops.l1_sum(leaf, cleans) * s_dce
-        total = l_adv_ny_G + l_adv_cl
-        if not self.as_written:   # the reference only logs the DCE term (:161-163); the intended G loss back-propagates it
-            total = total + dce
-        total.backward()
-        if self._reducer is not None:   # D's small parameters; its layer buckets are in flight: overlaps E's backward
-            self._reducer.flush(self._flat["D"])
-        enhanced.backward(leaf.grad)
-        return enhanced, l_adv_ny_G, l_adv_cl, dce
-
     def _device_step(self, mixture, cleans, nElement):
-        """The single-process step as library launches only (no torch glue): ONE prologue launch zeroes the flat gradient buffers
-        and the three loss sums and writes the discriminator's per-utterance weights [-kt] * N + [1] * N; the batched D input is
-        laid down time-major directly; the three L1 losses are raw device sums whose weights ride in their backward launches;
-        the controller consumes the raw sums (aas_began_step_sums).  -> enhanced."""
-        c = self.config
+        """The step as library launches only (no torch glue): ONE prologue launch zeroes the flat gradient buffers and the three
+        loss sums and writes the discriminator's per-utterance weights [-kt] * N + [1] * N; the batched D input is laid down
+        time-major directly; the three L1 losses are raw device sums whose weights ride in their backward launches; the
+        controller consumes the raw sums (aas_began_step_sums).  Data parallel: the normalisers are device scalars formed from
+        the all-reduced nElement (dist.DeviceScales), the gradient buffers are all-reduced bucket by bucket behind the
+        weight-gradient products.  -> (enhanced, scales): scales = python floats, or the DeviceScales when data parallel."""
+        c, dp = self.config, self.dp
         N, dev = mixture.size(0), mixture.device
         if getattr(self, "_sums", None) is None or self._rs_pair.numel() != 2 * N:
             self._sums = torch.zeros(2, device=dev, dtype=torch.float64)       # raw L1 sums [adv_ny, adv_cl]
             self._sum3 = torch.zeros(2, device=dev, dtype=torch.float64)       # [dce, -] (a 16-byte block of its own)
             self._rs_pair = torch.empty(2 * N, device=dev, dtype=torch.float32)
         ops.sync_wgrad()
+        if dp.active:
+            from .dist import DeviceScales
+            cnt = self._upload_small(torch.tensor([float(nElement)], dtype=torch.float64), dev)
+            scales = DeviceScales(dp, cnt, [c.w_adversarial, c.w_adversarial, 1.0], [0, 0, 0], ops.refresh_stream(dev))
+            if self._kt_ev is not None:     # kt was advanced on the auxiliary stream behind the previous step's scalar all-reduce
+                torch.cuda.current_stream().wait_event(self._kt_ev)
+        else:
+            scales = (c.w_adversarial / nElement, c.w_adversarial / nElement, 1.0 / nElement)
         ops.step_prologue([f.flat_g for f in self._flat.values()] + [self._sums, self._sum3], self._rs_pair, N, N, self._kt_dev)
         w = self._rs_pair.detach()
         rs = ops.RowWeights(w, classes=[(0, N, w[0:1]), (N, N, None)])   # the two utterance classes and their weights (device scalars)
-        s_adv, s_dce = c.w_adversarial / nElement, 1.0 / nElement
-        enhanced = self.G(mixture)
-        leaf = enhanced.detach().requires_grad_(True)
-        ae = self.D(None, wgrad_row_scale=rs, tnc=ops.layout_paired_cat(leaf, mixture, cleans))
-        tgrad = []
-        l_pair = ops.l1_pair(ae, leaf, cleans, s_adv, s_adv, self._sums.detach(), tgrad)
-        l_dce = ops.l1_scaled(leaf, cleans, s_dce, self._sum3, tgrad)
-        roots = [l_pair] if self.as_written else [l_pair, l_dce]     # (:161-163: the reference only logs the DCE term)
-        torch.autograd.backward(roots, [ops.unit_root(r_) for r_ in roots])
-        # the gradients arriving at `enhanced`: through D's input, as the target of the adversarial L1, from the DCE term
-        parts = [leaf.grad] + tgrad
-        gsum = ops.add3(parts[0], parts[1], parts[2] if len(parts) > 2 else None)
-        enhanced.backward(gsum)
-        ops.sync_wgrad()
-        return enhanced
+        if dp.active:
+            self._reducer.begin()
+            self.launch.wgrad_hook = self._reducer.on_wgrad
+        try:
+            enhanced = self.G(mixture)
+            leaf = enhanced.detach().requires_grad_(True)
+            ae = self.D(None, wgrad_row_scale=rs, tnc=ops.layout_paired_cat(leaf, mixture, cleans))
+            tgrad = []
+            l_pair = ops.l1_pair(ae, leaf, cleans, scales[0], scales[1], self._sums.detach(), tgrad)
+            l_dce = ops.l1_scaled(leaf, cleans, scales[2], self._sum3, tgrad)
+            roots = [l_pair] if self.as_written else [l_pair, l_dce]     # (:161-163: the reference only logs the DCE term)
+            torch.autograd.backward(roots, [ops.unit_root(r_) for r_ in roots])
+            if dp.active:   # D's small parameters; its layer buckets are in flight: overlaps E's backward
+                self._reducer.flush(self._flat["D"])
+            # the gradients arriving at `enhanced`: through D's input, as the target of the adversarial L1, from the DCE term
+            parts = [leaf.grad] + tgrad
+            gsum = ops.add3(parts[0], parts[1], parts[2] if len(parts) > 2 else None)
+            enhanced.backward(gsum)
+            ops.sync_wgrad()
+            if dp.active:
+                self._reducer.flush(self._flat["G"])
+                self._reducer.wait()
+        finally:
+            self.launch.wgrad_hook = None
+        return enhanced, scales
+
+    def _controller(self, scales, nElement):
+        """The BEGAN controller (:175-179) and the log scalars from the raw sums in one launch; slot 2 carries the DCE term.  Data
+        parallel: on the auxiliary stream, behind the all-reduce of the three sums; the main stream only waits for its event where
+        kt is next read (the step prologue)."""
+        if not self.dp.active:
+            ops.began_step_sums(self._sums, self._sum3, scales[0], scales[1], scales[2], self._kt_dev, self._g_out, self.gamma, self.lb, float(nElement))
+            return
+        main, aux = torch.cuda.current_stream(), ops.refresh_stream(self._sums.device)
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            out3 = torch.empty(3, device=self._sums.device, dtype=torch.float64)
+            ops.sums_pack(self._sums, self._sum3, out3)
+            self.dp.reduce_scalars(out3)
+            ops.began_step_sums(out3, out3[2:], 1.0, 1.0, 1.0, self._kt_dev, self._g_out, self.gamma, self.lb, 0.0, d_scales3=scales.all, d_n_batch=scales.cnt)
+            self._kt_ev = torch.cuda.Event()
+            self._kt_ev.record(aux)
+        for t_ in (scales.all, scales.cnt):
+            t_.record_stream(aux)
 
     def _ensure_dev_state(self, dev):
         if getattr(self, "_kt_dev", None) is None:
@@ -178,61 +195,18 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         the single-process gradients."""
         if self._opts is None:
             self.make_optimizers()
-        if self.dp.active:
-            return self._train_step_dp_sync(data_list, iter)
         optimizer_g, optimizer_d = self._opts
         mixture, cleans, mask = self._batch(data_list)
         nElement = mask.n_valid
         self._ensure_dev_state(mixture.device)
-        enhanced = self._device_step(mixture, cleans, nElement)
+        enhanced, scales = self._device_step(mixture, cleans, nElement)
         g_norm = self.get_gradient_norm(self.G)
         optimizer_g.step_dev(); optimizer_d.step_dev()
         ops.refresh_weight_planes(self.G); ops.refresh_weight_planes(self.D)
-        c = self.config
-        ops.began_step_sums(self._sums, self._sum3, c.w_adversarial / nElement, c.w_adversarial / nElement, 1.0 / nElement, self._kt_dev, self._g_out,
-                            self.gamma, self.lb, float(nElement))
+        self._controller(scales, nElement)
         r = self.read_scalars()
         r.update(g_norm=float(g_norm), enhanced=enhanced)
         return r
-
-    def _train_step_dp_sync(self, data_list, iter):
-        """The host-synchronous step under data parallelism (global nElement from the host-side count exchange)."""
-        c, dp = self.config, self.dp
-        optimizer_g, optimizer_d = self._opts
-        if getattr(self, "_kt_dev_live", False):
-            self.read_scalars()
-        ops.sync_wgrad()
-        for f in self._flat.values():
-            f.zero_grad()
-        mixture, cleans, mask = self._batch(data_list)
-        N = mixture.size(0)
-        (nElement,) = dp.global_counts([mask.n_valid])
-        w = torch.empty(2 * N, device=mixture.device, dtype=torch.float32)
-        w[:N] = -float(self.kt)
-        w[N:] = 1.0
-        rs = ops.RowWeights(w, classes=[(0, N, w[0:1]), (N, N, None)])   # the two utterance classes and their weights (ops.gemm_planes_tn)
-        self._reducer.begin()
-        self.launch.wgrad_hook = self._reducer.on_wgrad
-        try:
-            enhanced, l_adv_ny_G, l_adv_cl, dce = self._forward_backward(mixture, cleans, rs, c.w_adversarial / nElement, 1.0 / nElement)
-            ops.sync_wgrad()
-            self._reducer.flush(self._flat["G"])
-            self._reducer.wait()
-        finally:
-            self.launch.wgrad_hook = None
-        g_norm = self.get_gradient_norm(self.G)
-        optimizer_g.step(); optimizer_d.step()
-        ops.refresh_weight_planes(self.G); ops.refresh_weight_planes(self.D)
-        packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), dce.detach().reshape(())])
-        l_adv_ny_G_data, l_adv_cl_data, dce_loss = dp.reduce_scalars(packed).tolist()
-        g_norm = float(g_norm)
-        ops.check_rnn_health((l_adv_ny_G_data, l_adv_cl_data, dce_loss))
-        self.dce_tr_local.update(dce_loss, nElement)
-        g_d_balance = self.gamma * l_adv_cl_data - l_adv_ny_G_data
-        self.kt += self.lb * g_d_balance
-        self.kt = max(min(1, self.kt), 0)
-        return dict(l_adv_ny_G=l_adv_ny_G_data, l_adv_cl=l_adv_cl_data, dce=dce_loss, kt=self.kt,
-                    conv_measure=l_adv_cl_data + abs(g_d_balance), g_norm=g_norm, enhanced=enhanced)
 
     # ---- the same step without a host synchronisation (what train() queues on iterations that print nothing) -----------
     @ops.with_trainer_precision
@@ -240,65 +214,19 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         """train_step queued WITHOUT reading anything back: kt, the Adam bias corrections, the loss sums and the running DCE
         average of the log line stay on the device (`aas_began_step_sums`, `FlatAdam.step_dev`), so the host queues step i+1
         while the GPU runs step i.  `read_scalars()` (one D2H copy) returns the last step's losses and updates the host-side kt.
-        Single process: library launches only (`_device_step`).  Data parallel: the global nElement is all-reduced on the utility
-        stream and kept on the device, the gradient buffers are all-reduced bucket by bucket behind the weight-gradient products
-        (dist.BucketReducer), and kt is advanced from the all-reduced loss scalars - still no host synchronisation."""
-        c = self.config
+        Library launches only (`_device_step`).  Data parallel: the global nElement is all-reduced on the utility stream and kept
+        on the device, the gradient buffers are all-reduced bucket by bucket behind the weight-gradient products
+        (dist.BucketReducer), and kt is advanced from the all-reduced loss sums - still no host synchronisation."""
         if self._opts is None:
             self.make_optimizers()
         optimizer_g, optimizer_d = self._opts
-        dp = self.dp
         mixture, cleans, mask = self._batch(data_list)
         nElement = mask.n_valid
-        N, dev = mixture.size(0), mixture.device
-        self._ensure_dev_state(dev)
-        if not dp.active:
-            enhanced = self._device_step(mixture, cleans, nElement)
-            optimizer_g.step_dev(); optimizer_d.step_dev()
-            ops.refresh_weight_planes(self.G); ops.refresh_weight_planes(self.D)
-            # controller (:175-179) + the log scalars in one tiny launch from the raw sums; slot 2 carries the DCE term
-            ops.began_step_sums(self._sums, self._sum3, c.w_adversarial / nElement, c.w_adversarial / nElement, 1.0 / nElement, self._kt_dev, self._g_out,
-                                self.gamma, self.lb, float(nElement))
-            return dict(enhanced=enhanced, scalars=self._g_out)
-        ops.sync_wgrad()
-        for f in self._flat.values():
-            f.flat_g.zero_()
-        aux = ops.refresh_stream(dev)
-        from .dist import DeviceCounts
-        cnt = DeviceCounts(dp, [nElement], dev, aux)
-        n_glob = cnt.get(0)
-        s_adv, s_dce = (c.w_adversarial / n_glob).float(), (1.0 / n_glob).float()
-        self._reducer.begin()
-        self.launch.wgrad_hook = self._reducer.on_wgrad
-        if self._kt_ev is not None:
-            torch.cuda.current_stream().wait_event(self._kt_ev)
-        w = torch.empty(2 * N, device=dev, dtype=torch.float32)
-        w[:N].copy_((-self._kt_dev).to(torch.float32).expand(N))
-        w[N:] = 1.0
-        rs = ops.RowWeights(w, classes=[(0, N, w[0:1]), (N, N, None)])
-        try:
-            enhanced, l_adv_ny_G, l_adv_cl, dce = self._forward_backward(mixture, cleans, rs, s_adv, s_dce)
-            ops.sync_wgrad()
-            self._reducer.flush(self._flat["G"])
-            self._reducer.wait()
-        finally:
-            self.launch.wgrad_hook = None
+        self._ensure_dev_state(mixture.device)
+        enhanced, scales = self._device_step(mixture, cleans, nElement)
         optimizer_g.step_dev(); optimizer_d.step_dev()
         ops.refresh_weight_planes(self.G); ops.refresh_weight_planes(self.D)
-        main = torch.cuda.current_stream()
-        packed = torch.stack([l_adv_ny_G.detach().reshape(()), l_adv_cl.detach().reshape(()), dce.detach().reshape(())]).double()
-        aux.wait_stream(main)
-        with torch.cuda.stream(aux):
-            dp.reduce_scalars(packed)
-            bal = self.gamma * packed[1] - packed[0]
-            self._kt_dev.copy_(torch.clamp(self._kt_dev + self.lb * bal, 0.0, 1.0))
-            self._g_out[:3].copy_(packed)
-            self._g_out[3:4].copy_(self._kt_dev)
-            self._g_out[4:5].add_(packed[2] * n_glob)
-            self._g_out[5:6].add_(n_glob)
-            self._kt_ev = torch.cuda.Event()
-            self._kt_ev.record(aux)
-        packed.record_stream(aux)
+        self._controller(scales, nElement)
         return dict(enhanced=enhanced, scalars=self._g_out)
 
     def read_scalars(self):

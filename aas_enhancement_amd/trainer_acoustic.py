@@ -125,47 +125,61 @@ class Trainer(_AASTrainer):
             self._acc = torch.zeros(6, device=dev, dtype=torch.float64)      # aas_began_step* layout: [-, -, last loss, -, sum(loss * N), sum(N)]
             self._no_l1 = torch.zeros(2, device=dev, dtype=torch.float64)
             self._no_kt = torch.zeros(1, device=dev, dtype=torch.float64)
-        if not self.dp.active:
-            # library launches only: one prologue launch zeroes the flat gradient buffers, the loss weight 1 / N rides in the CTC
-            # kernel's gradient scale, and the log accumulators are advanced from the raw per-utterance costs by the controller
-            # launch (its adversarial inputs are zero here: this trainer has no discriminator)
-            c = self.config
-            optimizer_g, optimizer_asr, _ = self._opts
-            asr_steps = optimizer_asr is not None and iter > c.allow_ASR_update_iter
+        # library launches only: one prologue launch zeroes the flat gradient buffers, the loss weight 1 / N rides in the CTC kernel's
+        # gradient scale, and the log accumulators are advanced from the raw per-utterance costs by the controller launch (its
+        # adversarial inputs are zero here: this trainer has no discriminator).  Data parallel: 1 / N_global as a device scalar from
+        # the all-reduced batch sizes, bucketed gradient all-reduce, the cost sum all-reduced before the controller.
+        c, dp = self.config, self.dp
+        optimizer_g, optimizer_asr, _ = self._opts
+        asr_steps = optimizer_asr is not None and iter > c.allow_ASR_update_iter
+        ops.sync_wgrad()
+        if dp.active:
+            from .dist import DeviceScales
+            aux = ops.refresh_stream(dev)
+            cnt = self._upload_small(torch.tensor([float(N)], dtype=torch.float64), dev)
+            scales = DeviceScales(dp, cnt, [1.0, 1.0, 1.0], [0, 0, 0], aux)
+            scale = scales[0]
+        else:
+            scale = 1.0 / N
+        ops.step_prologue([f.flat_g for f in self._flat.values()])
+        if dp.active:
+            self._reducer.begin()
+            self.launch.wgrad_hook = self._reducer.on_wgrad
+        try:
+            ops.set_rnn_cu_limit(0)
+            enhanced = self.G(inputs)
+            prob = self.ASR(enhanced).transpose(0, 1)
+            costs = ops.ctc_scaled(prob, self.CTCLoss.blank, meta, scale)
+            ops.set_rnn_cu_limit(knobs.get("AC_BWD_CUS"))
+            torch.autograd.backward([costs], [ops.unit_root(costs)])
+            ops.set_rnn_cu_limit(0)
             ops.sync_wgrad()
-            ops.step_prologue([f.flat_g for f in self._flat.values()])
-            try:
-                ops.set_rnn_cu_limit(0)
-                enhanced = self.G(inputs)
-                prob = self.ASR(enhanced).transpose(0, 1)
-                costs = ops.ctc_scaled(prob, self.CTCLoss.blank, meta, 1.0 / N)
-                ops.set_rnn_cu_limit(knobs.get("AC_BWD_CUS"))
-                torch.autograd.backward([costs], [ops.unit_root(costs)])
-            finally:
-                ops.set_rnn_cu_limit(0)
-            ops.sync_wgrad()
-            optimizer_g.step_dev()
-            if asr_steps:
-                optimizer_asr.step_dev()
-                ops.refresh_weight_planes(self.ASR)
-            ops.refresh_weight_planes(self.G)
-            ops.began_step_raw(self._no_l1, 0.0, 0.0, costs.detach(), 1.0 / N, self._no_kt, self._acc, 0.0, 0.0, float(N))
-            self._acc_live = True
-            return dict(enhanced=enhanced, prob=prob, scalars=self._acc)
-        from .dist import DeviceCounts
-        cnt = DeviceCounts(self.dp, [N], dev, ops.refresh_stream(dev))
-        n_dev = cnt.get(0)
-        scale = (1.0 / n_dev).float()
-        enhanced, prob, l_CTC, asr_steps = self._core(inputs, meta, scale, iter)
-        self._opts[0].step_dev()
+            if dp.active:
+                for f in self._flat.values():
+                    self._reducer.flush(f)
+                self._reducer.wait()
+        finally:
+            self.launch.wgrad_hook = None
+            ops.set_rnn_cu_limit(0)
+        optimizer_g.step_dev()
         if asr_steps:
-            self._opts[1].step_dev()
+            optimizer_asr.step_dev()
             ops.refresh_weight_planes(self.ASR)
         ops.refresh_weight_planes(self.G)
-        l = self.dp.reduce_scalars(l_CTC.detach().reshape(1).double())     # every rank's loss is already divided by the global N
-        self._acc[2:3].copy_(l)
-        self._acc[4:5].add_(l * n_dev)
-        self._acc[5:6].add_(n_dev)
+        if not dp.active:
+            ops.began_step_raw(self._no_l1, 0.0, 0.0, costs.detach(), 1.0 / N, self._no_kt, self._acc, 0.0, 0.0, float(N))
+        else:
+            main = torch.cuda.current_stream()
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                out3 = torch.empty(3, device=dev, dtype=torch.float64)
+                ops.loss_pack(None, costs.detach(), out3)
+                dp.reduce_scalars(out3)
+                ops.began_step_sums(out3, out3[2:], 0.0, 0.0, 1.0, self._no_kt, self._acc, 0.0, 0.0, 0.0, d_scales3=scales.all, d_n_batch=scales.cnt)
+                self._acc_ev = torch.cuda.Event()
+                self._acc_ev.record(aux)
+            for t_ in (costs, scales.all, scales.cnt):
+                t_.record_stream(aux)
         self._acc_live = True
         return dict(enhanced=enhanced, prob=prob, scalars=self._acc)
 
@@ -174,6 +188,8 @@ class Trainer(_AASTrainer):
         point - raises if a persistent kernel timed out or the run diverged."""
         if getattr(self, "_acc", None) is None:      # only synchronous train_step calls so far: nothing queued to read back
             return dict(l_ctc=getattr(self, "_last_sync_l_ctc", None))
+        if getattr(self, "_acc_ev", None) is not None:     # (data parallel: the controller ran on the auxiliary stream)
+            torch.cuda.current_stream().wait_event(self._acc_ev)
         _, _, l_ctc, _, s, n = self._acc.tolist()
         self._acc[4:6].zero_()
         self._acc_live = False

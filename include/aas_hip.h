@@ -394,6 +394,13 @@ int aas_l1_fwd(aasStream_t stream, const float* a, const float* b, int64_t n, do
  * gradient can stay on the device (no host sync in backward); `accumulate` adds into ga/gb. */
 int aas_l1_bwd(aasStream_t stream, const float* a, const float* b, int64_t n, float scale, const float* d_scale,
                float* ga, float* gb, int accumulate);
+/* The same two on `rows` rows of `cols` valid elements with row pitches (lda, ldb, ldga, ldgb >= cols): the L1 sum of ONE utterance
+ * class of a batched pass over a noisy / clean pair of different padded length (trainer_AAS.py:146-147,176-177 on batches from two
+ * loaders) - its own frames inside a tensor padded to the longer class's length.  aas_l1_bwd2d also writes zeros to columns
+ * [cols, ga_cols) of ga: no gradient reaches the padding. */
+int aas_l1_fwd2d(aasStream_t stream, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int cols, double* loss_sum);
+int aas_l1_bwd2d(aasStream_t stream, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int cols, float scale,
+                 const float* d_scale, float* ga, int64_t ldga, int ga_cols, float* gb, int64_t ldgb);
 
 /* CTC (warpctc_pytorch.CTCLoss; call site trainer_AAS.py:168).  Mirrors warp-ctc's C ABI
  * (get_workspace_size / compute_ctc_loss): activations [T,N,C] pre-softmax, gradients [T,N,C]
@@ -481,8 +488,12 @@ int aas_began_step_sums(aasStream_t stream, const double* d_l1_sums, const doubl
                         const float* d_scales3, double* d_kt, double* d_out6, double gamma, double lambda_k, double n_batch,
                         const double* d_n_batch);
 /* d_out3 = [d_l1_sums[0], d_l1_sums[1], sum(d_ctc_costs[0 .. n_costs))]: the three raw loss sums of an AAS step (trainer_AAS.py:146-177) in
- * one buffer - what a data-parallel step all-reduces before the controller (aas_began_step_sums). */
+ * one buffer - what a data-parallel step all-reduces before the controller (aas_began_step_sums).  d_l1_sums = NULL reads as zeros
+ * (a step without a discriminator: AM_training/train.py:297-349, trainer_acoustic.py:120-142). */
 int aas_loss_pack(aasStream_t stream, const double* d_l1_sums, const float* d_ctc_costs, int n_costs, double* d_out3);
+/* d_out3 = [d_a2[0], d_a2[1], d_b1[0]] (a NULL source reads as zeros): raw fp64 loss sums that live in separate accumulators, in one
+ * buffer for ONE all-reduce (FSEGAN: the two adversarial L1 sums and the DCE sum, trainer_FSEGAN.py:139-171; DCE: the one sum). */
+int aas_sums_pack(aasStream_t stream, const double* d_a2, const double* d_b1, double* d_out3);
 /* d_out[i] = (float)(weights[i] / d_counts[index[i]]), i < n <= 4: the loss normalisers (w_adversarial / nElement, w_acoustic / N:
  * model.py:30, trainer_AAS.py:147,168,177) from device-resident (all-reduced) counts, in one launch; weights / index are host arrays. */
 int aas_scales_from_counts(aasStream_t stream, const double* d_counts, int n, const double* weights, const int* index, float* d_out);

@@ -176,3 +176,11 @@ def test_bench_launcher_builds_the_torchrun_command_and_relays(monkeypatch, caps
     assert c[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and c[c.index("--nproc-per-node") + 1] == "4"
     assert c[c.index("--master-addr") + 1] == "127.0.0.1" and c[-4:] == ["--gpus", "4", "--steps", "3"] and c[-5].endswith("bench.py")
     assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+
+
+def test_knobs_document_is_generated_from_the_table():
+    """docs/KNOBS.md is `python -m aas_enhancement_amd.knobs` verbatim: the README's switch list cannot drift from knobs.py."""
+    from aas_enhancement_amd import knobs
+    path = os.path.join(ROOT, "docs", "KNOBS.md")
+    assert open(path).read() == knobs.markdown_table()
+    assert all(len(v) == 3 and isinstance(v[2], str) and v[2] for v in knobs._TABLE.values())
