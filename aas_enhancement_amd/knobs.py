@@ -41,9 +41,11 @@ _TABLE = {
     "EARLY_ADAM": (True, _b, "D's (and a trainable A's) Adam step on the weight-gradient stream, beside E's backward"),
     "DEFER_WGRAD": (False, _b, "hold ALL weight-gradient products back until E's backward (measured: no gain)"),
     "DEFER_D_LAYERS": (None, _opt_i, "D's top layers whose products are held back until E's backward (None = 2; 0 in the fp32-equivalent mode)"),
-    "DEFER_A_LAYERS": (0, _i, "the same for a trainable A"),
+    "DEFER_A_LAYERS": (None, _opt_i, "the same for a trainable A (None = all of its recurrent layers: 30.7 -> 30.3 ms, profiles/r06_trainableA_sweep.txt)"),
     "EBWD_CUS": (128, _i, "CU budget of E's BPTT launches (the rest runs E's weight-gradient products)"),
     "LANE_CUS": (0, _i, "CU budget per lane of the two-lane schedule (0 = half the device)"),
+    "FSEGAN_BWD_CUS": (0, _i, "trainer_FSEGAN: CU budget of the BPTT launches (0 = whole device); the rest runs the weight-gradient products"),
+    "FSEGAN_DEFER_D": (0, _i, "trainer_FSEGAN: D's top layers whose weight-gradient products are held back until E's backward"),
     "AC_BWD_CUS": (0, _i, "trainer_acoustic: CU budget of the BPTT launches (0 = whole device)"),
     "AM_FWD_CUS": (0, _i, "am_train: CU budget of the forward recurrent launches (0 = whole device)"),
     "AM_BWD_CUS": (None, _opt_i, "am_train: CU budget of the BPTT launches (None = half the device in the fp32-class modes)"),

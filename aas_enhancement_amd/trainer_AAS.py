@@ -469,7 +469,10 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             #  with the eight-wave fp32 GEMM; with the four-wave one the weight-gradient stream was saturated and 0 was best)
             # (fp32-equivalent mode, with the six-product BPTT: 0 / 1 / 2 = 23.9-24.2 / 24.1-24.2 / 24.5-24.6 ms - its weight-gradient
             #  products are cheap enough to run beside the chains)
-            for net, knob, dflt in ((self.D, "DEFER_D_LAYERS", 0 if ops._precision[0] == 2 else 2), (self.ASR, "DEFER_A_LAYERS", 0)):
+            # (a trainable A - the reference's default - round 6, same box, 30 steps each: 0 / 1 / 2 / 3 / 4 / all 5 of A's layers held back =
+            #  30.7-30.9 / 30.7 / 30.8 / 30.8 / 30.7 / 30.3-30.5 ms: beside the two chains A's 306 GFLOP of weight-gradient products slow
+            #  the chain they belong to; profiles/r06_trainableA_sweep.txt.  A frozen A has no such products: the setting is moot there.)
+            for net, knob, dflt in ((self.D, "DEFER_D_LAYERS", 0 if ops._precision[0] == 2 else 2), (self.ASR, "DEFER_A_LAYERS", 99)):
                 ndef = knobs.get(knob)
                 ndef = dflt if ndef is None else int(ndef)
                 if ndef > 0:

@@ -11,7 +11,7 @@ keeps the reference's behaviour of only logging the DCE term (:161-163).
 """
 import torch
 
-from . import ops
+from . import knobs, ops
 from .decoder import GreedyDecoder
 from .model import L1Loss_mask, stackedBRNN, supported_rnns
 from .utils import _get_variable_nograd, _get_variable_volatile, attach_n_valid
@@ -143,19 +143,32 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             l_pair = ops.l1_pair(ae, leaf, cleans, scales[0], scales[1], self._sums.detach(), tgrad)
             l_dce = ops.l1_scaled(leaf, cleans, scales[2], self._sum3, tgrad)
             roots = [l_pair] if self.as_written else [l_pair, l_dce]     # (:161-163: the reference only logs the DCE term)
-            torch.autograd.backward(roots, [ops.unit_root(r_) for r_ in roots])
+            # (knobs.FSEGAN_BWD_CUS / FSEGAN_DEFER_D: CU budget of the BPTT launches and held-back discriminator layers, as in the AAS
+            #  step; measured flat for this single-chain step - profiles/r06_fsegan_sweep.txt - so both default to "off")
+            ops.set_rnn_cu_limit(knobs.get("FSEGAN_BWD_CUS"))
+            ndef = int(knobs.get("FSEGAN_DEFER_D"))
+            if ndef > 0:
+                lids = [m._aas_layer_id for m in self.D.modules() if getattr(m, "_aas_layer_id", None) is not None]
+                self.launch.defer_lids.update(lids[-ndef:])
+            try:
+                torch.autograd.backward(roots, [ops.unit_root(r_) for r_ in roots])
+            finally:
+                self.launch.defer_lids.clear()
+            ops.flush_deferred_wgrad()
             if dp.active:   # D's small parameters; its layer buckets are in flight: overlaps E's backward
                 self._reducer.flush(self._flat["D"])
             # the gradients arriving at `enhanced`: through D's input, as the target of the adversarial L1, from the DCE term
             parts = [leaf.grad] + tgrad
             gsum = ops.add3(parts[0], parts[1], parts[2] if len(parts) > 2 else None)
             enhanced.backward(gsum)
+            ops.set_rnn_cu_limit(0)
             ops.sync_wgrad()
             if dp.active:
                 self._reducer.flush(self._flat["G"])
                 self._reducer.wait()
         finally:
             self.launch.wgrad_hook = None
+            ops.set_rnn_cu_limit(0)
         return enhanced, scales
 
     def _controller(self, scales, nElement):

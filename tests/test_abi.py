@@ -184,3 +184,46 @@ def test_knobs_document_is_generated_from_the_table():
     path = os.path.join(ROOT, "docs", "KNOBS.md")
     assert open(path).read() == knobs.markdown_table()
     assert all(len(v) == 3 and isinstance(v[2], str) and v[2] for v in knobs._TABLE.values())
+
+
+def test_aaslaunch_struct_matches_the_header_and_scopes_nest():
+    """`ops._CLaunch` (what the host side hands to the `*_ex` entry points) has exactly the fields of `struct aasLaunch` in
+    include/aas_hip.h, in order; `aas_launch_scope` installs / returns the previous scope per thread and refuses a struct of another
+    size - no GPU needed (the call only records a pointer)."""
+    import ctypes
+    import re
+    import threading
+    from aas_enhancement_amd import _lib, ops
+    src = open(os.path.join(ROOT, "include", "aas_hip.h")).read()
+    body = re.search(r"typedef struct aasLaunch \{(.*?)\} aasLaunch;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\bint\s+(\w+)\s*;", body)
+    assert fields == [n for n, _ in ops._CLaunch._fields_] and all(t is ctypes.c_int for _, t in ops._CLaunch._fields_)
+    L = _lib.lib()
+    a, b = ops._new_claunch(), ops._new_claunch()
+    assert a.size == ctypes.sizeof(ops._CLaunch) == 4 * len(fields)
+    prev = ctypes.c_void_p()
+    assert L.aas_launch_scope(ctypes.byref(a), ctypes.byref(prev)) == 0 and prev.value is None
+    assert L.aas_launch_scope(ctypes.byref(b), ctypes.byref(prev)) == 0 and prev.value == ctypes.addressof(a)
+    a.debug_flags = 512                                  # scope b is installed: a's fields are not read
+    b.debug_flags = 64
+    assert L.aas_get_debug_flags() == 64
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(L.aas_get_debug_flags()))    # another thread: no scope there
+    t.start(); t.join()
+    assert seen == [0]
+    assert L.aas_launch_scope(None, ctypes.byref(prev)) == 0 and prev.value == ctypes.addressof(b)
+    assert L.aas_get_debug_flags() == 0
+    bad = ops._new_claunch()
+    bad.size = 12
+    assert L.aas_launch_scope(ctypes.byref(bad), None) != 0 and b"aasLaunch.size" in L.aas_last_error()
+    assert L.aas_launch_scope(None, None) == 0
+    # the Python wrapper: nested launch_state blocks restore what was installed before them
+    s1, s2 = ops.LaunchState(debug_flags=512), ops.LaunchState(precision=1)
+    assert ops.state() is ops._PROCESS
+    with ops.launch_state(s1):
+        assert ops.state() is s1 and L.aas_get_debug_flags() == 512
+        with ops.launch_state(s2):
+            assert ops.state() is s2 and ops.get_precision() == 1 and L.aas_get_debug_flags() == 0
+        assert ops.state() is s1 and L.aas_get_debug_flags() == 512
+    assert ops.state() is ops._PROCESS and L.aas_get_debug_flags() == 0
