@@ -211,36 +211,40 @@ __global__ __launch_bounds__(256, 2) void lmfb320_kernel(LP p) {
         // ---- MFMA: C[frame][column] for this wave's column groups, real and imaginary part in the same lane
         if (!(p.flags & 4)) {
             const int fr = lane & 15, kc = (lane >> 4) * 16;  // A fragment: frame row, 16-byte k chunk
-            bf16x8 are[3][2], aim[3][2];
+            // k-step outermost: the four A fragments of ONE k-step are live at a time (16 VGPRs instead of 48 for all three - the
+            // kernel spilled 8 VGPRs before); every accumulator sees its products in the same order as before (ks ascending; hi x lo,
+            // lo x hi, hi x hi), so the results are bit-identical
+            f32x4 re0 = {0.f, 0.f, 0.f, 0.f}, re1 = re0, re2 = re0, im0 = re0, im1 = re0, im2 = re0;
+#define AAS_LMFB_STEP(G, RE, IM)                                                             \
+    RE = __builtin_amdgcn_mfma_f32_16x16x32_bf16(are0, bre[G][ks][1], RE, 0, 0, 0);          \
+    RE = __builtin_amdgcn_mfma_f32_16x16x32_bf16(are1, bre[G][ks][0], RE, 0, 0, 0);          \
+    RE = __builtin_amdgcn_mfma_f32_16x16x32_bf16(are0, bre[G][ks][0], RE, 0, 0, 0);          \
+    IM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aim0, bim[G][ks][1], IM, 0, 0, 0);          \
+    IM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aim1, bim[G][ks][0], IM, 0, 0, 0);          \
+    IM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aim0, bim[G][ks][0], IM, 0, 0, 0);
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
-                are[ks][0] = *reinterpret_cast<const bf16x8*>(a_hi + fr * A_STRIDE + (seg_re * SEGK + ks * 32) * 2 + kc);
-                are[ks][1] = *reinterpret_cast<const bf16x8*>(a_lo + fr * A_STRIDE + (seg_re * SEGK + ks * 32) * 2 + kc);
-                aim[ks][0] = *reinterpret_cast<const bf16x8*>(a_hi + fr * A_STRIDE + (seg_im * SEGK + ks * 32) * 2 + kc);
-                aim[ks][1] = *reinterpret_cast<const bf16x8*>(a_lo + fr * A_STRIDE + (seg_im * SEGK + ks * 32) * 2 + kc);
+                const bf16x8 are0 = *reinterpret_cast<const bf16x8*>(a_hi + fr * A_STRIDE + (seg_re * SEGK + ks * 32) * 2 + kc);
+                const bf16x8 are1 = *reinterpret_cast<const bf16x8*>(a_lo + fr * A_STRIDE + (seg_re * SEGK + ks * 32) * 2 + kc);
+                const bf16x8 aim0 = *reinterpret_cast<const bf16x8*>(a_hi + fr * A_STRIDE + (seg_im * SEGK + ks * 32) * 2 + kc);
+                const bf16x8 aim1 = *reinterpret_cast<const bf16x8*>(a_lo + fr * A_STRIDE + (seg_im * SEGK + ks * 32) * 2 + kc);
+                AAS_LMFB_STEP(0, re0, im0)
+                AAS_LMFB_STEP(1, re1, im1)
+                if (ng > 2) { AAS_LMFB_STEP(2, re2, im2) }
             }
+#undef AAS_LMFB_STEP
+            // lane holds column c = (g0+g)*16 + lane%16 of frames 4*(lane/16) .. +3
+            auto emit = [&](int g, const f32x4& re, const f32x4& im) {
+                const int c = (g0 + g) * 16 + (lane & 15);
+                if (c < ncols) {
+                    const int k = odd ? 2 * c + 1 : 2 * c;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                if (g < ng) {
-                    f32x4 re = {0.f, 0.f, 0.f, 0.f}, im = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < 3; ++ks) {
-                        re = __builtin_amdgcn_mfma_f32_16x16x32_bf16(are[ks][0], bre[g][ks][1], re, 0, 0, 0);
-                        re = __builtin_amdgcn_mfma_f32_16x16x32_bf16(are[ks][1], bre[g][ks][0], re, 0, 0, 0);
-                        re = __builtin_amdgcn_mfma_f32_16x16x32_bf16(are[ks][0], bre[g][ks][0], re, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aim[ks][0], bim[g][ks][1], im, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aim[ks][1], bim[g][ks][0], im, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aim[ks][0], bim[g][ks][0], im, 0, 0, 0);
-                    }
-                    // lane holds column c = (g0+g)*16 + lane%16 of frames 4*(lane/16) .. +3
-                    const int c = (g0 + g) * 16 + (lane & 15);
-                    if (c < ncols) {
-                        const int k = odd ? 2 * c + 1 : 2 * c;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) P[((lane >> 4) * 4 + r) * P_STRIDE + k] = re[r] * re[r] + im[r] * im[r];
-                    }
+                    for (int r = 0; r < 4; ++r) P[((lane >> 4) * 4 + r) * P_STRIDE + k] = re[r] * re[r] + im[r] * im[r];
                 }
-            }
+            };
+            emit(0, re0, im0);
+            emit(1, re1, im1);
+            if (ng > 2) emit(2, re2, im2);
         }
         __syncthreads();
         // ---- mel (sparse triangular filters) + log1p + store: thread -> (frame = tid % 16, mel = tid / 16 + 16 i)
