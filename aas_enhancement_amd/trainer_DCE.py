@@ -84,21 +84,29 @@ class Trainer(ops.TrainerContext, ValidationMixin):
         nElement = getattr(mask, "n_valid", None)
         if nElement is None:
             nElement = int(mask.numel()) - int(mask.sum().item())
+        dev = inputs.device
+        ops.sync_wgrad()
         if dp.active:
-            (nElement,) = dp.global_counts([nElement])
+            # the global nElement never leaves the device: all-reduced on the utility stream, turned into 1 / nElement by one launch
+            from .dist import DeviceScales
+            cnt = self._upload_small(torch.tensor([float(nElement)], dtype=torch.float64), dev)
+            scales = DeviceScales(dp, cnt, [1.0, 1.0, 1.0], [0, 0, 0], ops.refresh_stream(dev))
+            scale = scales[0]
+        else:
+            scale = 1.0 / nElement
+        # the loss root is a RAW device sum in a ring of eight accumulators (a caller may read a step's loss up to seven steps later);
+        # ONE prologue launch zeroes the flat gradient buffer and this step's accumulator
+        if getattr(self, "_l1_ring", None) is None:
+            self._l1_ring, self._l1_i = torch.zeros(16, device=dev, dtype=torch.float64), 0   # (16-byte slots)
+        self._l1_i = (self._l1_i + 1) % 8
+        acc = self._l1_ring[2 * self._l1_i:2 * self._l1_i + 1]
+        ops.step_prologue([self._flat.flat_g, acc])
+        if dp.active:
             self._reducer.begin()
             self.launch.wgrad_hook = self._reducer.on_wgrad
         try:
-            ops.sync_wgrad()
-            # the loss root is a RAW device sum in a ring of eight accumulators (a caller may read a step's loss up to seven
-            # steps later); ONE prologue launch zeroes the flat gradient buffer and this step's accumulator
-            if getattr(self, "_l1_ring", None) is None:
-                self._l1_ring, self._l1_i = torch.zeros(16, device=inputs.device, dtype=torch.float64), 0   # (16-byte slots)
-            self._l1_i = (self._l1_i + 1) % 8
-            acc = self._l1_ring[2 * self._l1_i:2 * self._l1_i + 1]
-            ops.step_prologue([self._flat.flat_g, acc])
             outputs = self.G(inputs)
-            root = ops.l1_scaled(outputs, cleans, 1.0 / nElement, acc)
+            root = ops.l1_scaled(outputs, cleans, scale, acc)
             torch.autograd.backward([root], [ops.unit_root(root)])
             ops.sync_wgrad()   # the recurrent layers' weight gradients accumulate into the flat buffer on a side stream
             if dp.active:
@@ -108,15 +116,27 @@ class Trainer(ops.TrainerContext, ValidationMixin):
             self.launch.wgrad_hook = None
         self._opt.step_dev()
         ops.refresh_weight_planes(self.G)
-        raw = acc
+        if dp.active:
+            # the logged loss: all-reduced raw sum x 1 / global nElement, formed on the utility stream (a collective: every rank, every step)
+            main, aux = torch.cuda.current_stream(), ops.refresh_stream(dev)
+            if getattr(self, "_no_kt", None) is None:
+                self._no_kt = torch.zeros(1, device=dev, dtype=torch.float64)
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                out3 = torch.empty(3, device=dev, dtype=torch.float64)
+                out6 = torch.empty(6, device=dev, dtype=torch.float64)     # (this step's own: slot 2 = the loss; the running sums are not used here)
+                ops.sums_pack(None, acc, out3)
+                dp.reduce_scalars(out3)
+                ops.began_step_sums(out3, out3[2:], 0.0, 0.0, 1.0, self._no_kt, out6, 0.0, 0.0, 0.0, d_scales3=scales.all, d_n_batch=scales.cnt)
+                ev = torch.cuda.Event()
+                ev.record(aux)
+            main.wait_event(ev)
+            for t_ in (scales.all, scales.cnt, out6):
+                t_.record_stream(main)
+            return ops.StepResult(dce=out6[2], nElement=nElement, outputs=outputs)
 
-        def dce():     # formed when a log line (or a test) reads it: L = sum / nElement (the GLOBAL sum when data parallel)
-            v = raw.clone()
-            if dp.active:
-                v = dp.reduce_scalars(v)
-            return (v / nElement).reshape(()).to(torch.float32)
-        if dp.active:   # (a collective: every rank forms it every step)
-            return ops.StepResult(dce=dce(), nElement=nElement, outputs=outputs)
+        def dce():     # formed when a log line (or a test) reads it: L = sum / nElement
+            return (acc.clone() / nElement).reshape(()).to(torch.float32)
         return ops.StepResult(nElement=nElement, outputs=outputs, lazy=dict(dce=dce))
 
     def train(self):

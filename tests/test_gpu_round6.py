@@ -256,7 +256,7 @@ def test_two_host_threads_two_trainers_bit_equal_to_each_alone(gpu):
                     if i == 0:
                         assert tr._last_schedule == "batched-ragged"
                     sc = tr.read_scalars()
-                    rows.append([sc[k] for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt")] + [float(r["enhanced"].double().sum()), float(r["prob"].double().sum())])
+                    rows.append([sc[k] for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt")] + [float(r["enhanced"].detach().double().sum()), float(r["prob"].detach().double().sum())])
                 st.synchronize()
             out[i] = (np.asarray(rows), {k: v.detach().clone() for m in (tr.G, tr.D, tr.ASR) for k, v in m.state_dict().items()})
         except BaseException as e:  # noqa: BLE001
