@@ -10,6 +10,8 @@ for f in bench_under_rocprof.json kernel_stats.csv step_launches.csv kernel_time
 done
 python tools/pmc_summary.py --rebuild profiles/r06_f32_pmc_traffic.json > /dev/null
 cp $S/xcd_stats.txt profiles/r06_xcd_placement_stats.txt
+[ -f $S/f32_soak_6000.txt ] && cp $S/f32_soak_6000.txt profiles/r06_f32_soak_6000.txt
+[ -f $S/lmfb_ablation.txt ] && grep -v amdgpu.ids $S/lmfb_ablation.txt > profiles/r06_lmfb_ablation.txt
 [ -f gpurun_out/${1}_dp_onerank_timeline.txt ] && cp gpurun_out/${1}_dp_onerank_timeline.txt profiles/r06_dp_onerank_timeline.txt
 for c in config1 config4 config5; do cp $S/${c}_kernel_stats.csv profiles/r06_${c}_kernel_stats.csv; done
 cp $S/trainableA_kernel_stats.csv profiles/r06_f32_trainableA_kernel_stats.csv

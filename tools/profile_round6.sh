@@ -33,4 +33,6 @@ python3 $R/tools/xcd_stats.py > $O/xcd_stats.txt 2>&1
 bash $R/tools/r05_dp_timeline.sh $TAG > /dev/null 2>&1
 # 7. soak: 1500 steps, schedules alternating
 python3 $R/tools/soak.py 1500 > $O/f32_soak.txt 2>&1
+python3 $R/tools/soak.py 6000 > $O/f32_soak_6000.txt 2>&1
+python3 $R/tools/lmfb_bench.py 2048 > $O/lmfb_ablation.txt 2>&1
 ls -la $O
