@@ -234,10 +234,14 @@ def test_batchrnn_golden(ops, precision):
 
 
 @pytest.mark.parametrize("kind,T,N,H", [("lstm", 200, 30, 500), ("gru", 85, 30, 1000), ("lstm", 40, 60, 128), ("gru", 30, 70, 64),
-                                        ("lstm", 9, 3, 16), ("gru", 1, 2, 12), ("lstm", 40, 30, 1000), ("lstm", 20, 8, 768)])
+                                        ("lstm", 9, 3, 16), ("gru", 1, 2, 12), ("lstm", 40, 30, 1000), ("lstm", 20, 8, 768),
+                                        ("lstm", 1603, 30, 500), ("gru", 803, 30, 1000), ("lstm", 2050, 5, 96)])
 def test_birnn_layer_vs_cpu_at_size(ops, precision, kind, T, N, H):
-    """config-2 layer shapes (E: T=200,N=30,H=500; A: T'=85,N=30,H=1000), multi-group batches, and LSTM layers wider than 512
-    units (--rnn_type lstm --rnn_size 1000 is legal: AM_training/train.py:46,203-204)."""
+    """config-2 layer shapes (E: T=200,N=30,H=500; A: T'=85,N=30,H=1000), multi-group batches, LSTM layers wider than 512
+    units (--rnn_type lstm --rnn_size 1000 is legal: AM_training/train.py:46,203-204), and utterances of 16-20 s (1600-2050
+    frames: LibriSpeech's longest; the exchange tags and ring slots of the persistent kernels wrap many times)."""
+    if T > 400 and precision != 0 and H >= 500:
+        pytest.skip("the 8-16 s cases at full width run in the headline arithmetic only (20-30 s of CPU reference each)")
     torch.manual_seed(0)
     ref = (nn.LSTM if kind == "lstm" else nn.GRU)(H, H, bidirectional=True, bias=False)
     x = R(T, N, H, seed=1) * 0.5

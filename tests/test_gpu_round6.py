@@ -338,3 +338,78 @@ def test_launch_argument_entry_points_through_ctypes(gpu):
     assert rc != 0 and b"row classes" in L.aas_last_error()
     rc, y6 = run(L.aas_lstm_fwd)
     assert rc == 0 and torch.equal(y6, y2)
+
+
+@pytest.mark.parametrize("Tn,Tc", [(521, 454)])
+def test_long_utterances_step_vs_live_fp64_oracle(gpu, Tn, Tc):
+    """5 s utterances (the fixtures stop at T = 200; 731 / 640 and 667 / 667 pass the same way, 50-60 s of CPU each): one AAS step of
+    small networks - synchronous and device-resident, ragged pair - against the CPU oracle run here IN FP64 on the same inputs (trainer_AAS.py:131-194).  The exchange tags / ring slots
+    of the persistent kernels, the CTC kernel's 64-frame passes (T' = 260) and the row classes of the ragged batched pass all wrap
+    or repeat many times at this length.  Why fp64: at T > 1000 the fp32 CPU oracle itself sits 0.9e-3 ... 2.5e-3 from its fp64 run
+    in the gradients that pass through CTC (torch's fp32 CPU ctc_loss over hundreds of frames), the product 2e-6 ... 7e-6
+    (tools/probe/long_step_err.py) - so the tolerances here are 1e-4, not the fixtures' 1e-3 / 1e-2."""
+    import copy
+    from aas_enhancement_amd import ops, prng
+    from aas_enhancement_amd.model import DeepSpeech, stackedBRNN
+    from aas_enhancement_amd.trainer_AAS import Trainer
+    from oracle import ref_model as RM
+    from oracle import ref_step as RS
+    from tests.helpers import NOISE_PARAMS
+    F, H, HA, M = 8, 16, 12, 8
+    nets_ref = (RM.RefStackedBRNN(F, F, H, 4), RM.RefStackedBRNN(F, F, H, 4), RM.RefDeepSpeech(nn.GRU, LABELS, HA, 3, 11, 2, M, 2, nFreq=F))
+    for i, r in enumerate(nets_ref):
+        w = prng.fill_state_dict(r.state_dict(), 70 + i, conv_std=0.1 if i == 2 else None)
+        sd = r.state_dict()
+        for k, v in w.items():
+            sd[k].copy_(torch.from_numpy(v))
+
+    def gpu_nets():
+        nets = (stackedBRNN(I=F, H=H, L=4), stackedBRNN(I=F, H=H, L=4), DeepSpeech(nn.GRU, LABELS, HA, 3, True, 11, 2, M, 2, nFreq=F))
+        for r, g in zip(nets_ref, nets):
+            g.load_state_dict(r.state_dict())
+        return nets
+    nets64 = tuple(copy.deepcopy(m).double() for m in nets_ref)
+    N, L = 3, 20
+    lens_n, lens_c = [Tn, Tn - 111, Tn - 340], [Tc, Tc - 97, Tc - 255]
+
+    def batch(seed, T, lens, labelled, dt):
+        x = prng.uniform(seed, (N, F, T), 0.0, 6.0)
+        mask = np.zeros((N, 1, T), dtype=np.uint8)
+        for n, l in enumerate(lens):
+            x[n, :, l:] = 0.0
+            mask[n, 0, l:] = 1
+        m = torch.from_numpy(mask)
+        if not labelled:
+            return (torch.from_numpy(x).to(dt), None, None, None, m)
+        return (torch.from_numpy(x).to(dt), torch.from_numpy(prng.randint(seed + 1, (N * L,), 1, 28).astype(np.int32)),
+                torch.tensor([l / float(T) for l in lens]), torch.full((N,), L, dtype=torch.int32), m)
+    ny, cl = batch(11, Tn, lens_n, True, torch.float32), batch(13, Tc, lens_c, False, torch.float32)
+    c = cfg(lr=1e-3, allow_ASR_update_iter=0)
+    kt0 = 0.3
+    t_sync, t_dev = Trainer(c, None, models=gpu_nets()), Trainer(c, None, models=gpu_nets())
+    t_sync.kt = t_dev.kt = kt0
+    r = t_sync.train_step(ny, cl, 1, log_norms=True)
+    t_dev.train_step_async(ny, cl, 1)
+    rd = t_dev.read_scalars()
+    torch.cuda.synchronize()
+    assert not ops.rnn_timeout_flag()
+    rc = RS.StepConfig(lr=1e-3)
+    opts = [RS.make_optim(m, rc) for m in nets64]
+    _, ref = RS.aas_step(nets64[0], nets64[1], nets64[2], opts[0], opts[1], opts[2], batch(11, Tn, lens_n, True, torch.float64),
+                         batch(13, Tc, lens_c, False, torch.float64), rc, kt0, 1)
+    tol = 1e-4
+    for k in ("l_adv_ny_G", "l_adv_cl", "l_ctc", "kt"):
+        assert abs(r[k] - ref[k]) <= tol * abs(ref[k]) + 1e-6, (k, r[k], ref[k])
+        assert abs(rd[k] - ref[k]) <= tol * abs(ref[k]) + 1e-6, ("device-resident", k, rd[k], ref[k])
+    for k in ("g_adv", "g_ctc_adv"):
+        assert abs(r[k] - ref[k]) <= tol * abs(ref[k]), (k, r[k], ref[k])
+    assert rel_err(r["prob"], ref["logits"]) < tol
+    assert rel_err(r["enhanced"], ref["enhanced"]) < tol
+    # every parameter gradient of the three networks, both product paths (the oracle's .grad is what its optimisers stepped on)
+    for tr_ in (t_sync, t_dev):
+        for nm, net, rn in zip("GDA", (tr_.G, tr_.D, tr_.ASR), nets64):
+            ref_g = {k: v.grad for k, v in rn.named_parameters()}
+            for k, v in net.named_parameters():
+                if nm == "A" and k in NOISE_PARAMS:
+                    continue
+                assert rel_err(v.grad, ref_g[k]) < tol, (nm, k)
