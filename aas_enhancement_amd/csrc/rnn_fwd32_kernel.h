@@ -52,8 +52,18 @@ __global__ __launch_bounds__(512, 1) void rnn_fwd32_kernel(RnnP p) {
         for (int cg = 0; cg < CG; ++cg) {
             const int c = cg * 64 + lane;
             const int gate = c % G, unit = u0 + c / G;
+            const float* wrow = W + (int64_t)(gate * H + unit) * H;
+            if ((H & 3) == 0) {    // 16-byte loads of the lane's contiguous k range (rnn_split_kernel.h)
 #pragma unroll
-            for (int kk = 0; kk < 64; ++kk) wr[cg][kk] = (unit < H && kb + kk < H) ? W[(int64_t)(gate * H + unit) * H + kb + kk] : 0.f;
+                for (int kk = 0; kk < 64; kk += 4) {
+                    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (unit < H && kb + kk < H) v = *reinterpret_cast<const f32x4*>(wrow + kb + kk);
+                    wr[cg][kk] = v[0]; wr[cg][kk + 1] = v[1]; wr[cg][kk + 2] = v[2]; wr[cg][kk + 3] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 64; ++kk) wr[cg][kk] = (unit < H && kb + kk < H) ? wrow[kb + kk] : 0.f;
+            }
         }
     } else {
         const int n = lane & 15, q = lane >> 4;

@@ -62,6 +62,11 @@ struct RnnP {
     // (LSTM: all zeros; GRU: z = 0, n = 1)
     int cls_n, cls_t0, cls_t1;
     int ring;            // exact forward kernels: h_t exchanged through 4 time slots ([2][4][N] rows), producers re-poison behind themselves
+    // fused input projection (rnn_split_kernel.h, XF): `pre` is not read; the launch forms x_t W_ih^T itself from the layer input
+    const float* xin;    // [T,N,I]
+    const float* w_ih;   // [G*H,I] forward direction
+    const float* w_ih_r; // [G*H,I] reverse direction
+    int I;
 };
 
 __device__ __forceinline__ unsigned ld_cnt(const unsigned* p) {

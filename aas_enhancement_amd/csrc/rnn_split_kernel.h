@@ -179,7 +179,12 @@ __device__ __forceinline__ bool xcd_set_colocated(unsigned* tab, int set, int ps
 // exchange load holds row i, k = 4b .. 4b+3, so ONE load per 64 k feeds 64 instructions (abid = b picks the k quad) with no LDS and no
 // lane shuffles.  A 16 x 16 x 4 tile spends 32 cycles on 16 rows whether 8 or 16 exist; this form spends 8 cycles per k on each 4 rows
 // that do, at the same peak rate: E's forward (N=30 over the chip: 8 rows per group) issues half the MFMA cycles.
-template <int MODE, int MT, int KS, bool EX = false, int NRB = 0>
+//
+// XF (R4 LSTM forward, one wave per SIMD: the lane's register budget is 512): the layer's INPUT PROJECTION inside the launch.  The wave
+// also holds its k range of W_ih for gate column `lane` (KT more registers); x_{t+1} W_ih^T is formed right after h_t is published -
+// MFMAs that need nothing from the exchange, issued while the published words travel - and kept as the next step's starting sum.
+// The [T N, 2 G H] pre-activation tensor and the projection GEMM in front of the launch are gone (E's forward: 0.215 of 0.785 ms per layer).
+template <int MODE, int MT, int KS, bool EX = false, int NRB = 0, bool XF = false>
 __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     using C = Cfg<MODE>;
     constexpr int G = C::G, U = C::U, NT = C::NT;
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     constexpr int ROWS = MT * 16;
     constexpr bool R4 = NRB > 0;
     static_assert(!R4 || (EX && (MODE == LSTM_FWD || MODE == GRU_FWD) && MT == 1 && KS % 2 == 0 && G * U <= 64 && NRB <= 4), "R4: exact forward, one 64-column group");
+    static_assert(!XF || (R4 && MODE == LSTM_FWD), "XF: the 4 x 4 x 1 LSTM forward form only");
     constexpr int KT = KS * 32, KG = KS / 2;             // R4: k extent per wave, 64-wide k groups
     constexpr int EPT = (ROWS * U + 255) / 256;         // (row, unit) slots per thread; lanes l, l^1 hold a unit pair
     // double-buffered by step parity (one barrier per step) when it fits the 64 KB static LDS limit
@@ -216,13 +222,32 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     const float* W = d == 0 ? p.w_hh : p.w_hh_r;
     u32x4 b0[R4 ? 1 : KS][R4 ? 1 : NT], b1[R4 ? 1 : KS][R4 ? 1 : NT];
     float wr[R4 ? KT : 1];                               // R4: W[gate column `lane`][k of this wave]
+    float wx[XF ? KT : 1];                               // XF: W_ih[gate column `lane`][k of this wave]
     if constexpr (R4) {
+        // a lane's KT weights are contiguous in its row of W: 16-byte loads where the rows allow (a quarter of the load instructions,
+        // each of them 64 different cache lines: the launch reaches its first step ~ 15 us sooner)
         const int gate = lane / U, unit = u0 + lane % U;
+        const bool wrow_ok = lane < G * U && unit < H;
+        auto load_slice = [&](const float* Wm, int K, float (&dst)[KT]) {
+            const float* wrow = Wm + (int64_t)(gate * H + unit) * K;
+            if ((K & 3) == 0) {
 #pragma unroll
-        for (int kk = 0; kk < KT; ++kk) {
-            const int k = kb + kk;
-            wr[kk] = (lane < G * U && unit < H && k < H) ? W[(int64_t)(gate * H + unit) * H + k] : 0.f;
-        }
+                for (int kk = 0; kk < KT; kk += 4) {
+                    const int k = kb + kk;
+                    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (wrow_ok && k < K) v = *reinterpret_cast<const f32x4*>(wrow + k);
+                    dst[kk] = v[0]; dst[kk + 1] = v[1]; dst[kk + 2] = v[2]; dst[kk + 3] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KT; ++kk) {
+                    const int k = kb + kk;
+                    dst[kk] = (wrow_ok && k < K) ? wrow[k] : 0.f;
+                }
+            }
+        };
+        load_slice(W, H, wr);
+        if constexpr (XF) load_slice(d == 0 ? p.w_ih : p.w_ih_r, p.I, wx);
     } else {
         const int n = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -230,6 +255,9 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int c = nt * 16 + n;
+                // (two 16-byte loads instead of these eight - the lane's k are contiguous - reach the first step 10 us sooner and cost the
+                //  32-unit LSTM forward 0.55 us on EVERY step, N = 60 on 128 CUs: 6.11 -> 6.65; the register assignment that follows
+                //  from the loads decides the steady state.  Only the 4 x 4 x 1 forms load their slices with 16-byte loads.)
                 float wv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -266,6 +294,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     for (int i = 0; i < EPT; ++i) carry[i] = 0.f;
 
     unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    unsigned long long retry_n = 0, retry_steps = 0;     // (stamp mode) reloads of the exchanged rows / steps whose first attempt found poison
     const bool stamp = (p.flags & 64) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     __shared__ unsigned long long xcd_flag;
     bool plain = false;   // plain (L2-resident) publish stores once the set is verified to share an XCD (xcd_set_colocated)
@@ -273,10 +302,93 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
         unsigned* tab = p.xchg + xrows * KC * 32;          // behind the exchange rows, poisoned by the same memset
         plain = xcd_set_colocated(tab, xset, pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag, p.sync + XSTAT_WORD + 4 * (LSTM ? 0 : 2)) && !(p.flags & 524288);
     }
+    // XF: lane 4b+i of a 16-byte load holds row q0 + 4 rb + i, k = kb + 64 kg + 4b .. +3 of the layer input at one time index
+    u32x4 xf[XF ? NRB : 1][XF ? KG : 1];
+    f32x4 r4x[XF ? NRB : 1];
+    [[maybe_unused]] auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(XF ? p.xin : nullptr), 0, XF ? (int)((int64_t)T * N * p.I * 4) : 0, 0x00020000);
+    // per-lane offsets of those loads, formed once: the time index adds a wave-uniform term under the lane's validity mask (no
+    // branches in the step: a divergent select around a load costs an s_waitcnt vmcnt(0) - i.e. the publish stores' round trip)
+    unsigned xo[XF ? NRB : 1][XF ? KG : 1], xm[XF ? NRB : 1][XF ? KG : 1], ho[XF ? NRB : 1][XF ? KG : 1], hm[XF ? NRB : 1][XF ? KG : 1];
+    if constexpr (XF) {
+        const int i4 = lane & 3, bq = lane >> 2;
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            const int gr = q0 + rb * 4 + i4;
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                const int k = kb + kg * 64 + bq * 4;
+                const bool vx = gr < NB && k < p.I, vh = gr < NB && k < Kxp;
+                xm[rb][kg] = vx ? 0xFFFFFFFFu : 0u;
+                xo[rb][kg] = vx ? (unsigned)((gr * p.I + k) * 4) : 0x80000000u;
+                hm[rb][kg] = vh ? 0xFFFFFFFFu : 0u;
+                ho[rb][kg] = vh ? (unsigned)(gr * KC * 128 + k * 4) : 0x80000000u;
+            }
+        }
+    }
+    u32x4 xn[XF ? NRB : 1][XF ? KG : 1];                 // the rows of the step after next, in flight (two-deep: see the step loop)
+    [[maybe_unused]] auto x_load = [&](int tx, u32x4 (&dst)[XF ? NRB : 1][XF ? KG : 1]) {
+        if constexpr (XF) {
+            const unsigned trow = (unsigned)tx * (unsigned)(N * p.I * 4);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg)
+                    dst[rb][kg] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(xo[rb][kg] + (trow & xm[rb][kg])), 0, 0));
+        }
+    };
+    // the projection in two halves (abid 0-7 / 8-15 of every 64-k group): the step's h loads are issued between them (below)
+    f32x4 cx[XF ? NRB : 1][XF ? 4 : 1];
+    [[maybe_unused]] auto x_mma = [&](auto PART) {
+        if constexpr (XF) {
+            constexpr int part = decltype(PART)::value;
+            if constexpr (part == 0) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) cx[rb][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+#define AAS_XF_STEP(B_)                                                                                                              \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                  \
+        cx[rb][v] = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(xf[rb][kg][v]), wx[kg * 64 + (B_) * 4 + v], cx[rb][v], 4, (B_), 0);
+                if constexpr (part == 0) {
+                    AAS_XF_STEP(0) AAS_XF_STEP(1) AAS_XF_STEP(2) AAS_XF_STEP(3) AAS_XF_STEP(4) AAS_XF_STEP(5) AAS_XF_STEP(6) AAS_XF_STEP(7)
+                } else {
+                    AAS_XF_STEP(8) AAS_XF_STEP(9) AAS_XF_STEP(10) AAS_XF_STEP(11) AAS_XF_STEP(12) AAS_XF_STEP(13) AAS_XF_STEP(14) AAS_XF_STEP(15)
+                }
+#undef AAS_XF_STEP
+            }
+            if constexpr (part == 1) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) r4x[rb] = (cx[rb][0] + cx[rb][1]) + (cx[rb][2] + cx[rb][3]);
+            }
+        }
+    };
+    // XF: the exchange loads of a step are issued at the END of the step before (between the projection halves, ~0.5 us behind this
+    // workgroup's own publish, when the other producers' words of the same step are about to be visible): no pre-poll round trip
+    u32x4 hfx[XF ? NRB : 1][XF ? KG : 1];
+    [[maybe_unused]] auto h_issue = [&](int tprev) {
+        if constexpr (XF) {
+            const unsigned trow = (unsigned)(xrow_f(d, tprev) * N) * (unsigned)(KC * 128);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg)
+                    hfx[rb][kg] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ho[rb][kg] + (trow & hm[rb][kg])), 0, 16));
+        }
+    };
+    if constexpr (XF) {
+        x_load(d == 0 ? 0 : T - 1, xf);
+        x_mma(std::integral_constant<int, 0>{});
+        x_mma(std::integral_constant<int, 1>{});
+        if (T > 1) x_load(d == 0 ? 1 : T - 2, xf);          // step 1's rows: used at the end of step 0
+    }
     for (int s = 0; s < T; ++s) {
         unsigned long long st0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull, st1 = st0, st2 = st0, st3 = st0;
         const int fwd_order = (d == 0) ? s : T - 1 - s;
         const int t = FWD ? fwd_order : (T - 1 - fwd_order);
+
         const int tp = FWD ? (d == 0 ? t - 1 : t + 1) : (d == 0 ? t + 1 : t - 1);
 
         // ---- prefetch the step's private inputs ------------------------------------------------
@@ -295,9 +407,11 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             if (ok) {
                 const int64_t tn = (int64_t)t * N + gr;
                 if (FWD) {
-                    const float* pp = p.pre + (tn * 2 + d) * GH + unit;
+                    if constexpr (!XF) {
+                        const float* pp = p.pre + (tn * 2 + d) * GH + unit;
 #pragma unroll
-                    for (int g = 0; g < G; ++g) pin[i][g] = pp[g * H];
+                        for (int g = 0; g < G; ++g) pin[i][g] = pp[g * H];
+                    }
                 } else {
                     pin[i][0] = p.dy[tn * H + unit];
                     const f32x4 ga4 = *reinterpret_cast<const f32x4*>(p.gact + (((int64_t)d * T * N + tn) * H + unit) * 4);
@@ -380,7 +494,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             // k-range (first row of the group, hi array) with a single 4-byte sc1 load per lane; the full loads
             // below are still validated word by word, this only keeps 250 workgroups from hammering the fabric
             // with 16-byte re-loads while the step's data is in flight.
-            if (!(p.flags & 4)) {
+            if (!XF && !(p.flags & 4)) {
                 const int nprod = (KS * 32) / U;               // producer slices inside this wave's k-range
                 const int64_t xr0 = FWD ? xrow_f(d, tp) * N + q0 : ((int64_t)tp * N + q0) * 2 + d;
                 const int kprobe = kb + lane * U;
@@ -430,7 +544,14 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                         for (int kg = 0; kg < KG; ++kg) mx = max(mx, max(max(hf[rb][kg].x, hf[rb][kg].y), max(hf[rb][kg].z, hf[rb][kg].w)));
                     return __any(mx == POISON) != 0;
                 };
-                load_all();
+                if constexpr (XF) {
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                        for (int kg = 0; kg < KG; ++kg) hf[rb][kg] = hfx[rb][kg];
+                } else {
+                    load_all();
+                }
                 if (!(p.flags & 4) && any_poison()) {
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                     unsigned spins = 0;
@@ -444,6 +565,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
                             }
                         }
                     } while (any_poison());
+                    if (stamp) { retry_n += spins; retry_steps += 1; }
                 }
                 // NRB x 4 independent accumulation chains (row block, k mod 4)
                 f32x4 cc[NRB][4];
@@ -500,6 +622,15 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             }
         }
         if (stamp) st2 = __builtin_amdgcn_s_memrealtime();
+        if constexpr (XF) {
+            // the rows the projection at the end of this step works on: loaded a step ago (below), every load has returned by now
+            if (s > 0) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int kg = 0; kg < KG; ++kg) xf[rb][kg] = xn[rb][kg];
+            }
+        }
         float (*red)[ROWS][LDR] = red2[DB ? (s & 1) : 0];
         // ---- cross-wave reduction through LDS ---------------------------------------------------
         if constexpr (R4) {
@@ -507,7 +638,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[wave][rb * 4 + r][lane] = (s > 0) ? r4[rb][r] : 0.f;
+                    for (int r = 0; r < 4; ++r) red[wave][rb * 4 + r][lane] = ((s > 0) ? r4[rb][r] : 0.f) + (XF ? r4x[XF ? rb : 0][r] : 0.f);
             }
         } else {
             const int col = lane & 15, rq = (lane >> 4) * 4;
@@ -651,6 +782,26 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             }
         }
         if (!DB) __syncthreads();  // single reduction buffer: readers must finish before the next step's writes
+        if constexpr (XF) {
+            // behind the publish stores, in front of the next step's poll: the projection of the next step's input
+            __builtin_amdgcn_sched_barrier(0);
+            // Input rows of the step AFTER NEXT, two-deep: where a load is issued decides who waits for it.  Loads return in order and the
+            // compiler places s_waitcnt vmcnt(0) in front of the barrier and of the first register it cannot prove free (the gate
+            // math's), so the only stretch of the step that no wait cuts is this one: behind the publish, in front of the exchange
+            // loads - whose wait, a projection later, then covers these too.
+            if (s + 2 < T) x_load(d == 0 ? t + 2 : t - 2, xn);
+            if (s + 1 < T) {
+                __builtin_amdgcn_sched_barrier(0);
+                x_mma(std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                // the row this step published = the next step's h_{t-1}.  (Issued right behind the publish instead: 3 of 200 first
+                // attempts find poison, same step time; behind the whole projection: + 0.3 us per step.)
+                h_issue(t);
+                __builtin_amdgcn_sched_barrier(0);
+                x_mma(std::integral_constant<int, 1>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (stamp) {
             const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
             ph[0] += st1 - st0; ph[1] += st2 - st1; ph[2] += st3 - st2; ph[3] += st4 - st3; ph[4] += st4 - st0;
@@ -659,6 +810,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     if (stamp && tid == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(p.sync + STAMP_WORD);
         for (int i = 0; i < 5; ++i) o[i] = ph[i];
+        o[5] = retry_n; o[6] = retry_steps;
     }
 }
 
@@ -672,11 +824,19 @@ int launch_sk(const RnnP& p, hipStream_t s) {
         // 8-row tiles: 8.26 vs 8.23 us / step, its sixteen exchange loads are not overlapped with the MFMAs - not kept.)
         const int rows = (p.n1 - p.n0) < p.rpg ? (p.n1 - p.n0) : p.rpg;
         if (rows <= 8 && !(p.flags & 268435456)) {
+            if constexpr (MODE == LSTM_FWD) {
+                if (p.xin) {     // input projection inside the launch (split_xf_covers() admitted the shape)
+                    if (rows <= 4) hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX, 1, true>), grid, dim3(256), 0, s, p);
+                    else hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX, 2, true>), grid, dim3(256), 0, s, p);
+                    return 0;
+                }
+            }
             if (rows <= 4) hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX, 1>), grid, dim3(256), 0, s, p);
             else hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX, 2>), grid, dim3(256), 0, s, p);
             return 0;
         }
     }
+    if (p.xin) return -1;   // (no `pre` exists for any other kernel of the family)
     hipLaunchKernelGGL((rnn_split_kernel<MODE, MT, KS, EX>), grid, dim3(256), 0, s, p);
     return 0;
 }
@@ -713,6 +873,28 @@ constexpr bool split_covers(int mt, int ks_need) {
     return mt == 1 && ks_need <= 24;
 }
 
+// Does the LSTM forward launch with the input projection inside (XF) cover this shape, in the present settings?  It is the exact
+// 4 x 4 x 1 form or nothing: <= 8 rows per workgroup on the CU budget, the whole batch in one launch, H and I <= 512 (the two weight
+// slices of a wave are 2 x 128 registers), 16-byte rows of x.  Debug bit 1073741824 switches it off (A/B runs).
+inline bool split_xf_covers(int T, int N, int H, int I, const void* xchg) {
+    if (!xchg || aas_precision_value() != 0 || T < 1 || N < 1 || H < 1) return false;
+    const int flags = aas_debug_flags_value();
+    if (flags & (134217728 | 268435456 | 1073741824)) return false;
+    const int cus = aas_rnn_cus();
+    if (cus <= 0) return false;
+    if (!(H < 256 || (flags & 512) || cdiv(H, 16) * cdiv(N, 8) * 2 <= cus)) return false;    // run_fwd32 takes the launch
+    const int P = cdiv(H, 16);
+    if (P * 2 > cus || P * 16 > 512 || I > 512 || I < 4 || (I & 3)) return false;
+    int mt, rpg;
+    pick_groups(P, N, cus, mt, rpg);
+    if (mt != 1 || rpg > 8) return false;
+    const int qmax = cus / (P * 2) < 1 ? 1 : cus / (P * 2);
+    if (N > qmax * rpg) return false;
+    if ((int64_t)T * N * I * 4 >= 0x7fffffffLL) return false;
+    if ((int64_t)2 * T * N * ((P * 16 + 31) / 32) * 128 >= 0x7fffffffLL) return false;
+    return true;
+}
+
 // Same chunking of the batch as run() in rnn_kernel.h; falls back to the counter-based fp32 kernel (returns -1)
 // when the shape is outside the instantiated kernels.  EX: exact-fp32 products (forward modes only).
 template <int MODE, bool EX = false>
@@ -730,7 +912,11 @@ int run_split(const char* name, RnnP p, hipStream_t s) {
     AAS_CHECK(p.P * 2 <= cus, "%s: H=%d needs %d resident workgroups, device has %d CUs", name, p.H, p.P * 2, cus);
     const int Hp = p.P * C::U;
     const int kxp = FWD ? Hp : C::G * Hp;
-    const int ks_need = cdiv(kxp, 128);
+    int ks_need = cdiv(kxp, 128);
+    if (p.xin) {     // fused input projection: the waves split max(H, I) the same way, on the 4 x 4 x 1 form (k slices of 64 or 128 per wave)
+        const int kin = cdiv(p.I > kxp ? p.I : kxp, 128);
+        ks_need = kin < 2 ? 2 : kin;
+    }
     const int64_t xbytes = (int64_t)2 * p.T * p.N * ((kxp + 31) / 32) * 128;  // rows x chunks x 128 B (64 B hi + 64 B lo, or 32 fp32)
     if (xbytes >= 0x7fffffffLL) return -1;
     int mt, rpg;

@@ -66,6 +66,7 @@ _TABLE = {
     "MULTI_WGRAD": (True, _b, "fp32: a layer's four weight-gradient products as one multi-problem launch (0: four launches)"),
     "TN_WGRAD": (True, _b, "fast modes: weight gradients from row-major planes (0: transposed planes)"),
     "MANAGED_XCHG": (True, _b, "managed exchange buffers: no poison memset launch in front of a persistent launch"),
+    "FUSED_XPROJ": (True, _b, "LSTM forward launches form their input projection themselves where the library covers the shape (aas_lstm_fwd_x_ex)"),
     "FUSED_GLUE": (True, _b, "step prologue / raw-sum loss roots / controller launches instead of torch eager glue"),
     "WGRAD_MAXSTEPS": (None, _opt_i, "lifetime cap (k-steps) of the weight-gradient products alone (None: GEMM32_MAXSTEPS)"),
     "GEMM32_MAXSTEPS": (48, _i, "lifetime cap (k-steps) of a GEMM workgroup inside the training step (0 = none)"),

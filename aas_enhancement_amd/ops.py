@@ -638,6 +638,7 @@ class _timed:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record(torch.cuda.current_stream())
+        return self
 
     def __exit__(self, *a):
         if self.on:
@@ -1274,6 +1275,24 @@ def _birnn_fwd(kind, x, w_ih, w_hh, w_ih_r, w_hh_r, lid=0, keep=None, row_len=No
     G = _GATES[kind]
     H = w_hh.shape[1]
     dev = x.device
+    if kind == "lstm" and _precision[0] == 0 and knobs.get("FUSED_XPROJ") and I % 4 == 0 and max(I, H) <= 512:
+        # the input projection inside the persistent launch (aas_lstm_fwd_x_ex): no `pre` tensor, no GEMM in front - when the library
+        # covers the shape on the present CU budget (the enhancement network over the whole chip); 3 = it does not, nothing happened
+        hout = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
+        gact = torch.empty((2, T, N, 4 * H), device=dev, dtype=torch.float32)
+        cst = torch.empty((2, T, N, H), device=dev, dtype=torch.float32)
+        tag = 2 * lid if lid else 1
+        la = _launch_arg(tag, row_len)
+        xchg = _xchg_buf(dev, T, N, H, G, "fwd" if knobs.get("MANAGED_XCHG") else "any")
+        with _timed("rnn", "lstm_fwdx[N=%d,H=%d]" % (N, H), 2.0 * 2 * T * N * G * H * (H + I), T) as tm:
+            rc = lib().aas_lstm_fwd_x_ex(stream(), T, N, H, I, ptr(x), ptr(w_ih), ptr(w_ih_r), ptr(w_hh), ptr(w_hh_r), ptr(hout), ptr(gact),
+                                         ptr(cst), ptr(_sync_buf(dev)), ptr(xchg), _ct.byref(la))
+            tm.on = tm.on and rc == 0      # (nothing was launched: no record)
+        if rc == 0:
+            return hout, gact, cst
+        if rc != 3:
+            check(rc, "aas_lstm_fwd_x_ex")
+        del hout, gact, cst
     pre = torch.empty((T, N, 2, G * H), device=dev, dtype=torch.float32)
     x2 = x.view(T * N, I)
     dw = (w_ih_r.data_ptr() - w_ih.data_ptr()) // 4  # element distance between the two directions' W_ih

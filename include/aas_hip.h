@@ -343,6 +343,14 @@ int aas_gru_fwd_ex(aasStream_t stream, int T, int N, int H, const float* pre, co
                    float* gact, void* sync, void* xchg, aasLaunch* launch);
 int aas_gru_bwd_ex(aasStream_t stream, int T, int N, int H, const float* dy, const float* w_hh, const float* w_hh_rev,
                    const float* hout, const float* gact, float* dgx, float* dgh, void* sync, void* xchg, aasLaunch* launch);
+/* The LSTM forward launch WITH the layer's input projection inside: x [T,N,I] and w_ih / w_ih_rev [4H,I] instead of `pre` - the whole of
+ * nn.LSTM's forward for one bias-free bidirectional layer (model.py:73-74,83,101-105) in one launch, no [T N, 8H] pre-activation tensor.
+ * -> 0 launched; 3 = not covered in the present settings (needs: fp32 mode, H and I <= 512, I % 4 == 0, <= 8 batch rows per workgroup
+ * on the CU budget with the whole batch in one launch - e.g. the enhancement network's N = 30, H = 500 over the whole chip): NOTHING
+ * was launched or consumed, the caller forms `pre` with aas_gemm_f32 and calls aas_lstm_fwd_ex; 1 = error.  Outputs as aas_lstm_fwd. */
+int aas_lstm_fwd_x_ex(aasStream_t stream, int T, int N, int H, int I, const float* x, const float* w_ih, const float* w_ih_rev,
+                      const float* w_hh, const float* w_hh_rev, float* hout, float* gact, float* cst, void* sync, void* xchg,
+                      aasLaunch* launch);
 
 /* ---------------------------------------------------------------- batch norm (train mode) -----
  * Rows-by-channels BatchNorm with batch statistics (nn.BatchNorm1d in train mode: model.py:72,82

@@ -413,3 +413,124 @@ def test_long_utterances_step_vs_live_fp64_oracle(gpu, Tn, Tc):
                 if nm == "A" and k in NOISE_PARAMS:
                     continue
                 assert rel_err(v.grad, ref_g[k]) < tol, (nm, k)
+
+
+@pytest.mark.parametrize("T,N,H,I", [(200, 30, 500, 500), (33, 30, 500, 500), (61, 7, 96, 96), (40, 30, 128, 64), (17, 5, 100, 200), (5, 2, 12, 8),
+                                     (1, 3, 16, 16), (3, 8, 256, 256), (90, 12, 500, 80)])
+def test_lstm_forward_with_the_input_projection_inside_vs_fp64_and_vs_gemm_plus_launch(gpu, T, N, H, I):
+    """aas_lstm_fwd_x_ex through ctypes - nn.LSTM's forward for one bias-free bidirectional layer in ONE launch (model.py:73-74,83) -
+    against an fp64 recurrence on the CPU and against the two-launch form (aas_gemm_f32 + aas_lstm_fwd_ex): h, the saved gate values
+    and c, at config-2 size, for I != H, ragged k / row tails, T = 1, and with two row classes (a shorter second class)."""
+    import ctypes
+    from aas_enhancement_amd import _lib, ops
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(T * 1000 + N * 10 + H)
+    x = (torch.randn(T, N, I, generator=g) * 0.5)
+    w = [((torch.rand(4 * H, k, generator=g) - 0.5) * (2.0 / k ** 0.5)) for k in (I, H, I, H)]     # w_ih, w_hh, w_ih_rev, w_hh_rev
+    xd, wd = x.to(dev), [t.to(dev) for t in w]
+    sync = torch.zeros(int(L.aas_rnn_sync_bytes()), dtype=torch.uint8, device=dev)
+    xchg = torch.empty(int(L.aas_rnn_xchg_bytes(T, N, H, 4)), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fused(la):
+        out = (torch.empty(2, T, N, H, device=dev), torch.empty(2, T, N, 4 * H, device=dev), torch.empty(2, T, N, H, device=dev))
+        rc = L.aas_lstm_fwd_x_ex(st, T, N, H, I, xd.data_ptr(), wd[0].data_ptr(), wd[2].data_ptr(), wd[1].data_ptr(), wd[3].data_ptr(),
+                                 out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), sync.data_ptr(), xchg.data_ptr(), la)
+        torch.cuda.synchronize()
+        return rc, out
+
+    def two_launches(la):
+        pre = torch.empty(T, N, 2, 4 * H, device=dev)
+        for d_ in range(2):
+            ops.gemm(ops.NT, T * N, 4 * H, I, xd.view(T * N, I), I, wd[2 * d_], I, pre, 8 * H, c_off=4 * H * d_)
+        out = (torch.empty(2, T, N, H, device=dev), torch.empty(2, T, N, 4 * H, device=dev), torch.empty(2, T, N, H, device=dev))
+        rc = L.aas_lstm_fwd_ex(st, T, N, H, pre.data_ptr(), wd[1].data_ptr(), wd[3].data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                               out[2].data_ptr(), sync.data_ptr(), xchg.data_ptr(), la)
+        torch.cuda.synchronize()
+        return rc, out
+
+    def fp64(T_rows):
+        """h, (i, f, g, o), c of both directions; row n is live for t < T_rows[n] (dead (t, n): zeros, the state restarts from zero)"""
+        xx, ww = x.double(), [t.double() for t in w]
+        hout, gact, cst = torch.zeros(2, T, N, H, dtype=torch.float64), torch.zeros(2, T, N, H, 4, dtype=torch.float64), torch.zeros(2, T, N, H, dtype=torch.float64)
+        for d_ in range(2):
+            h, c = torch.zeros(N, H, dtype=torch.float64), torch.zeros(N, H, dtype=torch.float64)
+            for s_ in range(T):
+                t = s_ if d_ == 0 else T - 1 - s_
+                a = (xx[t] @ ww[2 * d_].t() + h @ ww[2 * d_ + 1].t()).view(N, 4, H)
+                i_, f_, g_, o_ = torch.sigmoid(a[:, 0]), torch.sigmoid(a[:, 1]), torch.tanh(a[:, 2]), torch.sigmoid(a[:, 3])
+                c = f_ * c + i_ * g_
+                h = o_ * torch.tanh(c)
+                live = (t < T_rows).double().unsqueeze(1)
+                h, c = h * live, c * live
+                hout[d_, t], cst[d_, t] = h, c
+                gact[d_, t] = torch.stack((i_, f_, g_, o_), -1) * live.unsqueeze(-1)
+        return hout, gact.view(2, T, N, 4 * H), cst
+    rc, got = fused(None)
+    if rc == 3:
+        # not covered on this chip for the shape: nothing was launched - the two-launch form is what the library runs then
+        pytest.skip("shape not covered by the fused launch on this CU count")
+    assert rc == 0, L.aas_last_error()
+    assert not ops.rnn_timeout_flag()
+    ref = fp64(torch.full((N,), T))
+    rc, two = two_launches(None)
+    assert rc == 0
+    for a, b, r, nm in zip(got, two, ref, ("h", "gates", "c")):
+        assert rel_err(a, r) < 2e-6, nm
+        assert rel_err(a, b) < 4e-6, nm
+    # two row classes: the first n1 rows run T steps, the others T2 (aasLaunch.cls_*), consumed by the fused launch like by the plain one
+    if T >= 3 and N >= 2:
+        n1, T2 = max(1, N // 3), max(1, T - 2 - T // 4)
+        la = ops._new_claunch()
+        la.cls_n_first, la.cls_T_first, la.cls_T_rest, la.rnn_tag = n1, T, T2, 9
+        rc, gotc = fused(ctypes.byref(la))
+        assert rc == 0 and la.cls_n_first == -1
+        rows = torch.tensor([T if n < n1 else T2 for n in range(N)])
+        refc = fp64(rows)
+        for a, r, nm in zip(gotc, refc, ("h", "gates", "c")):
+            assert rel_err(a, r) < 2e-6, nm
+        rc, after = fused(None)               # nothing is left over for the next launch
+        assert rc == 0 and all(torch.equal(a, b) for a, b in zip(after, got))
+
+
+def test_fused_lstm_forward_refuses_what_it_does_not_cover_and_consumes_nothing(gpu):
+    """rc = 3 (the caller takes the GEMM + launch form) for: a CU budget on which the batch needs more than 8 rows per workgroup, the
+    split-bf16 mode, I not a multiple of 4, H > 512; the row classes offered with the refused call are still there for the call that
+    follows (nothing consumed), and ops.birnn_layer gives the same layer either way."""
+    import ctypes
+    from aas_enhancement_amd import _lib, ops
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    T, N, H = 10, 30, 500
+    x = torch.randn(T, N, H, device=dev) * 0.5
+    w = [torch.randn(4 * H, H, device=dev) / H ** 0.5 for _ in range(4)]
+    sync = torch.zeros(int(L.aas_rnn_sync_bytes()), dtype=torch.uint8, device=dev)
+    xchg = torch.empty(int(L.aas_rnn_xchg_bytes(T, N, 1000, 4)), dtype=torch.uint8, device=dev)
+    out = (torch.empty(2, T, N, 1000, device=dev), torch.empty(2, T, N, 4000, device=dev), torch.empty(2, T, N, 1000, device=dev))
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call(H_, I_, la=None):
+        return L.aas_lstm_fwd_x_ex(st, T, N, H_, I_, x.data_ptr(), w[0].data_ptr(), w[2].data_ptr(), w[1].data_ptr(), w[3].data_ptr(),
+                                   out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), sync.data_ptr(), xchg.data_ptr(), la)
+    assert call(H, H) == 0
+    la = ops._new_claunch()
+    la.rnn_cu_limit = 128                     # 30 rows on 128 CUs: 32 slices x 2 directions leave two row groups of 15
+    la.cls_n_first, la.cls_T_first, la.cls_T_rest = 10, T, 4
+    assert call(H, H, ctypes.byref(la)) == 3
+    assert la.cls_n_first == 10                # not consumed
+    assert call(H, 498) == 3 and call(H, 6) == 3
+    assert call(1000, 500) == 3
+    with ops.precision(1):
+        assert call(H, H) == 3
+    torch.cuda.synchronize()
+    # the layer op: same result with the fused launch and with the ablation switch that takes the GEMM + launch form
+    ys = []
+    for flag in (0, 1073741824):
+        L.aas_set_debug_flags(flag)
+        try:
+            ys.append(ops.birnn_layer(x, *[t.clone().requires_grad_(True) for t in (w[0], w[1], w[2], w[3])], kind="lstm", residual=True))
+            torch.cuda.synchronize()
+        finally:
+            L.aas_set_debug_flags(0)
+    assert rel_err(ys[0], ys[1]) < 4e-6 and not torch.equal(ys[0], ys[1])

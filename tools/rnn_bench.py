@@ -36,12 +36,18 @@ def rnn_case(kind, T, N, H):
     dgh = torch.empty(T, N, 2, G * H, device=dev)
     s = _lib.stream()
     p = _lib.ptr
+    fx = None
     if kind == "lstm":
         f = lambda: L.aas_lstm_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(cst), p(sync), p(xc))
+        # the same launch with the input projection inside (-> 3 when the shape / CU budget is not covered), and the GEMM it replaces
+        fx = lambda: L.aas_lstm_fwd_x_ex(s, T, N, H, H, p(x), p(w[0]), p(w[2]), p(w[1]), p(w[3]), p(hout), p(gact), p(cst), p(sync), p(xc), None)
+        wcat = torch.cat((w[0], w[2]), 0).contiguous()
+        fx.gemm = lambda: ops.gemm(ops.NT, T * N, 2 * G * H, H, x.view(T * N, H), H, wcat, H, pre.view(T * N, 2 * G * H), 2 * G * H)
         b = lambda: L.aas_lstm_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(gact), p(cst), p(dgx), p(sync), p(xc))
     else:
         f = lambda: L.aas_gru_fwd(s, T, N, H, p(pre), p(w[1]), p(w[3]), p(hout), p(gact), p(sync), p(xc))
         b = lambda: L.aas_gru_bwd(s, T, N, H, p(dy), p(w[1]), p(w[3]), p(hout), p(gact), p(dgx), p(dgh), p(sync), p(xc))
+    f.fx = fx
     return f, b
 
 
@@ -54,6 +60,7 @@ def main():
     ap.add_argument("--skip-rnn", action="store_true")
     ap.add_argument("--cus", type=int, default=0, help="aas_set_rnn_cu_limit for the recurrent launches")
     ap.add_argument("--only", default="", help="comma list of case indices (0 lstm30, 1 gru30, 2 lstm60)")
+    ap.add_argument("--tsweep", action="store_true", help="launch duration against T (4 ... 200): the intercept is what a persistent launch costs before its first step")
     a = ap.parse_args()
     L = _lib.lib()
     L.aas_set_precision(a.precision)
@@ -61,12 +68,37 @@ def main():
     cases = [("lstm", 200, 30, 500), ("gru", 85, 30, 1000), ("lstm", 200, 60, 500)]
     if a.only:
         cases = [cases[int(i)] for i in a.only.split(",")]
+    if a.tsweep:
+        for kind, _, N, H in cases:
+            rows = []
+            for T in (4, 8, 16, 50, 100, 200):
+                f, b = rnn_case(kind, T, N, H)
+                r = [T, timeit(f, 20), timeit(b, 20)]
+                if f.fx is not None and a.precision == 0 and f.fx() == 0:
+                    r.append(timeit(f.fx, 20))
+                rows.append(r)
+            for j, nm in enumerate(("fwd", "bwd", "fwdx")[:len(rows[0]) - 1]):
+                (t0, y0), (t1, y1) = (rows[2][0], rows[2][j + 1]), (rows[-1][0], rows[-1][j + 1])
+                slope = (y1 - y0) / (t1 - t0)
+                print("%s N=%d H=%d %-4s: %s  -> %.2f us/step, intercept %.1f us" % (kind, N, H, nm, "  ".join("T=%d %.3f" % (r[0], r[j + 1]) for r in rows),
+                                                                                     1e3 * slope, 1e3 * (y1 - slope * t1)), flush=True)
+        return
     for kind, T, N, H in ([] if a.skip_rnn else cases):
         f, b = rnn_case(kind, T, N, H)
         for fl in [int(v) for v in a.flags.split(",")]:
             L.aas_set_debug_flags(fl)
             tf, tb = timeit(f), timeit(b)
             print("%s T=%d N=%d H=%d flags=%2d  fwd %.3f ms (%.2f us/step)  bwd %.3f ms (%.2f us/step)" % (kind, T, N, H, fl, tf, 1e3 * tf / T, tb, 1e3 * tb / T), flush=True)
+            if f.fx is not None and a.precision == 0:
+                if f.fx() == 0:
+                    tx, tg = timeit(f.fx), timeit(f.fx.gemm)
+                    print("   input projection inside the launch: %.3f ms (%.2f us/step)  vs  GEMM %.3f + launch %.3f = %.3f ms" % (tx, 1e3 * tx / T, tg, tf, tg + tf), flush=True)
+                    if fl & 64:
+                        f.fx(); torch.cuda.synchronize()
+                        st = ops._sync_buf(torch.device("cuda", 0)).view(torch.int64)[520:527].tolist()
+                        print("   fwdx phases (us/step, WG0 wave0): wait %.2f  load+mfma %.2f  lds+barrier %.2f  gate+publish+xproj %.2f  total %.2f   | %d reloads in %d of %d steps" % (tuple(v * 0.01 / T for v in st[:5]) + (st[5], st[6], T)), flush=True)
+                else:
+                    print("   input projection inside the launch: not covered on this CU budget", flush=True)
             if fl & 64:
                 for nm, fn in (("fwd", f), ("bwd", b)):
                     fn(); torch.cuda.synchronize()
