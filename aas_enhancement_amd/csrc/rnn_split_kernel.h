@@ -222,7 +222,14 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
     const float* W = d == 0 ? p.w_hh : p.w_hh_r;
     u32x4 b0[R4 ? 1 : KS][R4 ? 1 : NT], b1[R4 ? 1 : KS][R4 ? 1 : NT];
     float wr[R4 ? KT : 1];                               // R4: W[gate column `lane`][k of this wave]
-    float wx[XF ? KT : 1];                               // XF: W_ih[gate column `lane`][k of this wave]
+    // XF: W_ih[gate column `lane`][this wave's k of the INPUT].  The waves split x's k unevenly: waves 0 and 1 also do the step's gate
+    // math (8 rows x 16 units = 128 slots, ~0.45 us) while 2 and 3 wait at the next barrier, so they take 104 of every 256 k and
+    // waves 2 and 3 take 152 - between two barriers every wave then has the same work (2.97 -> 2.75 us per step at N = 30, H = 500).
+    constexpr int XK0 = !XF ? 1 : (KS == 4 ? 104 : KT), XK1 = !XF ? 1 : (KS == 4 ? 152 : KT);
+    constexpr int XG = (XK1 + 63) / 64;                  // 64-k groups of the longer share
+    const int xk = wave < 2 ? XK0 : XK1;
+    const int xb = wave < 2 ? wave * XK0 : 2 * XK0 + (wave - 2) * XK1;
+    float wx[XF ? XK1 : 1];
     if constexpr (R4) {
         // a lane's KT weights are contiguous in its row of W: 16-byte loads where the rows allow (a quarter of the load instructions,
         // each of them 64 different cache lines: the launch reaches its first step ~ 15 us sooner)
@@ -247,7 +254,16 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
             }
         };
         load_slice(W, H, wr);
-        if constexpr (XF) load_slice(d == 0 ? p.w_ih : p.w_ih_r, p.I, wx);
+        if constexpr (XF) {
+            const float* wrow = (d == 0 ? p.w_ih : p.w_ih_r) + (int64_t)(gate * H + unit) * p.I;      // (I % 4 == 0: split_xf_covers)
+#pragma unroll
+            for (int kk = 0; kk < XK1; kk += 4) {
+                const int k = xb + kk;
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (wrow_ok && kk < xk && k < p.I) v = *reinterpret_cast<const f32x4*>(wrow + k);
+                wx[kk] = v[0]; wx[kk + 1] = v[1]; wx[kk + 2] = v[2]; wx[kk + 3] = v[3];
+            }
+        }
     } else {
         const int n = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -302,73 +318,86 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
         unsigned* tab = p.xchg + xrows * KC * 32;          // behind the exchange rows, poisoned by the same memset
         plain = xcd_set_colocated(tab, xset, pslice, p.P, p.sync + ERR_WORD, p.tag, &xcd_flag, p.sync + XSTAT_WORD + 4 * (LSTM ? 0 : 2)) && !(p.flags & 524288);
     }
-    // XF: lane 4b+i of a 16-byte load holds row q0 + 4 rb + i, k = kb + 64 kg + 4b .. +3 of the layer input at one time index
-    u32x4 xf[XF ? NRB : 1][XF ? KG : 1];
+    // XF: lane 4b+i of a 16-byte load holds row q0 + 4 rb + i, k = xb + 64 g + 4b .. +3 of the layer input at one time index
+    u32x4 xf[XF ? NRB : 1][XF ? XG : 1];
     f32x4 r4x[XF ? NRB : 1];
     [[maybe_unused]] auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(XF ? p.xin : nullptr), 0, XF ? (int)((int64_t)T * N * p.I * 4) : 0, 0x00020000);
     // per-lane offsets of those loads, formed once: the time index adds a wave-uniform term under the lane's validity mask (no
     // branches in the step: a divergent select around a load costs an s_waitcnt vmcnt(0) - i.e. the publish stores' round trip)
-    unsigned xo[XF ? NRB : 1][XF ? KG : 1], xm[XF ? NRB : 1][XF ? KG : 1], ho[XF ? NRB : 1][XF ? KG : 1], hm[XF ? NRB : 1][XF ? KG : 1];
+    unsigned xo[XF ? NRB : 1][XF ? XG : 1], xm[XF ? NRB : 1][XF ? XG : 1], ho[XF ? NRB : 1][XF ? KG : 1], hm[XF ? NRB : 1][XF ? KG : 1];
     if constexpr (XF) {
         const int i4 = lane & 3, bq = lane >> 2;
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
             const int gr = q0 + rb * 4 + i4;
 #pragma unroll
+            for (int g = 0; g < XG; ++g) {
+                const int kk = g * 64 + bq * 4, k = xb + kk;
+                const bool vx = gr < NB && kk < xk && k < p.I;
+                xm[rb][g] = vx ? 0xFFFFFFFFu : 0u;
+                xo[rb][g] = vx ? (unsigned)((gr * p.I + k) * 4) : 0x80000000u;
+            }
+#pragma unroll
             for (int kg = 0; kg < KG; ++kg) {
                 const int k = kb + kg * 64 + bq * 4;
-                const bool vx = gr < NB && k < p.I, vh = gr < NB && k < Kxp;
-                xm[rb][kg] = vx ? 0xFFFFFFFFu : 0u;
-                xo[rb][kg] = vx ? (unsigned)((gr * p.I + k) * 4) : 0x80000000u;
+                const bool vh = gr < NB && k < Kxp;
                 hm[rb][kg] = vh ? 0xFFFFFFFFu : 0u;
                 ho[rb][kg] = vh ? (unsigned)(gr * KC * 128 + k * 4) : 0x80000000u;
             }
         }
     }
-    u32x4 xn[XF ? NRB : 1][XF ? KG : 1];                 // the rows of the step after next, in flight (two-deep: see the step loop)
-    [[maybe_unused]] auto x_load = [&](int tx, u32x4 (&dst)[XF ? NRB : 1][XF ? KG : 1]) {
+    u32x4 xn[XF ? NRB : 1][XF ? XG : 1];                 // the rows of the step after next, in flight (two-deep: see the step loop)
+    [[maybe_unused]] auto x_load = [&](int tx, u32x4 (&dst)[XF ? NRB : 1][XF ? XG : 1]) __attribute__((always_inline)) {
         if constexpr (XF) {
             const unsigned trow = (unsigned)tx * (unsigned)(N * p.I * 4);
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                for (int kg = 0; kg < KG; ++kg)
-                    dst[rb][kg] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(xo[rb][kg] + (trow & xm[rb][kg])), 0, 0));
+                for (int g = 0; g < XG; ++g)
+                    dst[rb][g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(xo[rb][g] + (trow & xm[rb][g])), 0, 0));
         }
     };
-    // the projection in two halves (abid 0-7 / 8-15 of every 64-k group): the step's h loads are issued between them (below)
+    // the projection in two halves of the wave's k steps (4 k each: one abid value of a 64-k group): the step's h loads are issued
+    // between them (below).  XK = the wave's share (XK0 / XK1), compile-time per role.
     f32x4 cx[XF ? NRB : 1][XF ? 4 : 1];
-    [[maybe_unused]] auto x_mma = [&](auto PART) {
+    [[maybe_unused]] auto x_mma_role = [&](auto XKC, auto PART) __attribute__((always_inline)) {
         if constexpr (XF) {
-            constexpr int part = decltype(PART)::value;
+            constexpr int part = decltype(PART)::value, J = decltype(XKC)::value / 4;
+            constexpr int JB = part == 0 ? 0 : J / 2, JE = part == 0 ? J / 2 : J;
             if constexpr (part == 0) {
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) cx[rb][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-#define AAS_XF_STEP(B_)                                                                                                              \
-    _Pragma("unroll") for (int v = 0; v < 4; ++v) _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                  \
-        cx[rb][v] = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(xf[rb][kg][v]), wx[kg * 64 + (B_) * 4 + v], cx[rb][v], 4, (B_), 0);
-                if constexpr (part == 0) {
-                    AAS_XF_STEP(0) AAS_XF_STEP(1) AAS_XF_STEP(2) AAS_XF_STEP(3) AAS_XF_STEP(4) AAS_XF_STEP(5) AAS_XF_STEP(6) AAS_XF_STEP(7)
-                } else {
-                    AAS_XF_STEP(8) AAS_XF_STEP(9) AAS_XF_STEP(10) AAS_XF_STEP(11) AAS_XF_STEP(12) AAS_XF_STEP(13) AAS_XF_STEP(14) AAS_XF_STEP(15)
-                }
+#define AAS_XF_STEP(G_, B_)                                                                                                          \
+    if constexpr ((G_) < XG && (G_) * 16 + (B_) >= JB && (G_) * 16 + (B_) < JE) {                                                     \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v) _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                              \
+            cx[rb][v] = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(xf[rb][(G_) < XG ? (G_) : 0][v]), wx[(((G_) < XG ? (G_) : 0) * 16 + (B_)) * 4 + v], cx[rb][v], 4, (B_), 0); \
+    }
+#define AAS_XF_GROUP(G_)                                                                                                              \
+    AAS_XF_STEP(G_, 0) AAS_XF_STEP(G_, 1) AAS_XF_STEP(G_, 2) AAS_XF_STEP(G_, 3) AAS_XF_STEP(G_, 4) AAS_XF_STEP(G_, 5) AAS_XF_STEP(G_, 6) AAS_XF_STEP(G_, 7) \
+    AAS_XF_STEP(G_, 8) AAS_XF_STEP(G_, 9) AAS_XF_STEP(G_, 10) AAS_XF_STEP(G_, 11) AAS_XF_STEP(G_, 12) AAS_XF_STEP(G_, 13) AAS_XF_STEP(G_, 14) AAS_XF_STEP(G_, 15)
+            AAS_XF_GROUP(0) AAS_XF_GROUP(1) AAS_XF_GROUP(2)
+#undef AAS_XF_GROUP
 #undef AAS_XF_STEP
-            }
             if constexpr (part == 1) {
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) r4x[rb] = (cx[rb][0] + cx[rb][1]) + (cx[rb][2] + cx[rb][3]);
             }
         }
     };
+    [[maybe_unused]] auto x_mma = [&](auto PART) __attribute__((always_inline)) {   // (not inlined: its state goes through scratch)
+        if constexpr (XF) {
+            if constexpr (XK0 == XK1) x_mma_role(std::integral_constant<int, XK0>{}, PART);
+            else if (wave < 2) x_mma_role(std::integral_constant<int, XK0>{}, PART);
+            else x_mma_role(std::integral_constant<int, XK1>{}, PART);
+        }
+    };
     // XF: the exchange loads of a step are issued at the END of the step before (between the projection halves, ~0.5 us behind this
     // workgroup's own publish, when the other producers' words of the same step are about to be visible): no pre-poll round trip
     u32x4 hfx[XF ? NRB : 1][XF ? KG : 1];
-    [[maybe_unused]] auto h_issue = [&](int tprev) {
+    [[maybe_unused]] auto h_issue = [&](int tprev) __attribute__((always_inline)) {
         if constexpr (XF) {
             const unsigned trow = (unsigned)(xrow_f(d, tprev) * N) * (unsigned)(KC * 128);
 #pragma unroll
@@ -628,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(RnnP p) {
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                    for (int kg = 0; kg < KG; ++kg) xf[rb][kg] = xn[rb][kg];
+                    for (int g = 0; g < XG; ++g) xf[rb][g] = xn[rb][g];
             }
         }
         float (*red)[ROWS][LDR] = red2[DB ? (s & 1) : 0];

@@ -29,6 +29,9 @@ bash $R/tools/r06_stats.sh $TAG > /dev/null 2>&1
 # 6. event timelines (no tracer), isolated recurrent launches, XCD placement, data-parallel bucket timing
 python3 $R/tools/event_timeline.py > $O/f32_event_timeline.txt 2>&1
 python3 $R/tools/rnn_bench.py --precision 0 --flags 0,64 --cus 128 > $O/f32_rnn_bench.txt 2>&1
+# (E's forward over the whole chip: the launch with its input projection inside beside GEMM + launch; duration against T)
+python3 $R/tools/rnn_bench.py --precision 0 --flags 0,64 --only 0 >> $O/f32_rnn_bench.txt 2>&1
+python3 $R/tools/rnn_bench.py --precision 0 --tsweep >> $O/f32_rnn_bench.txt 2>&1
 python3 $R/tools/xcd_stats.py > $O/xcd_stats.txt 2>&1
 bash $R/tools/r05_dp_timeline.sh $TAG > /dev/null 2>&1
 # 7. soak: 1500 steps, schedules alternating
