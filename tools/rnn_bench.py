@@ -91,7 +91,10 @@ def main():
             print("%s T=%d N=%d H=%d flags=%2d  fwd %.3f ms (%.2f us/step)  bwd %.3f ms (%.2f us/step)" % (kind, T, N, H, fl, tf, 1e3 * tf / T, tb, 1e3 * tb / T), flush=True)
             if f.fx is not None and a.precision == 0:
                 if f.fx() == 0:
-                    tx, tg = timeit(f.fx), timeit(f.fx.gemm)
+                    tx = timeit(f.fx)
+                    L.aas_set_debug_flags(0)      # (the bits mean other things to the GEMM: 64 = "no operand loads" - its output would be
+                    tg = timeit(f.fx.gemm)        #  garbage, and a NaN of the poison pattern in `pre` stalls the next plain launch)
+                    L.aas_set_debug_flags(fl)
                     print("   input projection inside the launch: %.3f ms (%.2f us/step)  vs  GEMM %.3f + launch %.3f = %.3f ms" % (tx, 1e3 * tx / T, tg, tf, tg + tf), flush=True)
                     if fl & 64:
                         f.fx(); torch.cuda.synchronize()
