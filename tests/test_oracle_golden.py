@@ -95,6 +95,17 @@ def test_aas_config2_gradients_with_live_D_step():
     from aas_enhancement_amd import prng
     z, zc = load("f3b_aas_config2_kt.npz"), load("f3c_thread_spread.npz")
     N, F, T, H, HA, M, L = [int(z[k]) for k in ("N", "F", "T", "H", "HA", "M", "L")]
+    # (half the cores: with every core taken, one descheduled OpenMP thread makes each parallel region wait - this step has been
+    #  seen to take 9 minutes instead of 25 s on a busy 8-core box; F3c bounds what the thread count may change)
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(4, n_thr)))
+    try:
+        _config2_live_D_step_body(z, zc, N, F, T, H, HA, M, L, prng)
+    finally:
+        torch.set_num_threads(n_thr)
+
+
+def _config2_live_D_step_body(z, zc, N, F, T, H, HA, M, L, prng):
     G, D = RM.RefStackedBRNN(F, F, H, 4), RM.RefStackedBRNN(F, F, H, 4)
     A = RM.RefDeepSpeech(nn.GRU, LABELS, HA, 5, 11, 2, M, 2, nFreq=F)
     for m, seed, cs in ((G, 9001, None), (D, 9002, None), (A, 9003, 0.1)):
