@@ -544,3 +544,32 @@ def test_fused_lstm_forward_refuses_what_it_does_not_cover_and_consumes_nothing(
         finally:
             L.aas_set_debug_flags(0)
     assert rel_err(ys[0], ys[1]) < 4e-6 and not torch.equal(ys[0], ys[1])
+
+
+def test_config2_enhancement_network_runs_on_the_fused_forward_launch(gpu):
+    """A silent fall-back (aas_lstm_fwd_x_ex returning 3 for the headline's own shape) would cost 0.5 ms per step and nothing would
+    fail: E's four layers at config-2 size (N = 30, H = 500, whole chip) must each be ONE recurrent launch with no projection GEMM in
+    front, D's N = 60 pass on a 128-CU budget must keep the GEMM + launch form."""
+    from aas_enhancement_amd import ops
+    from aas_enhancement_amd.model import stackedBRNN
+    torch.manual_seed(0)
+    E = stackedBRNN(I=80, H=500, L=4).cuda()
+    x = torch.randn(30, 80, 200, device="cuda")
+    with torch.no_grad():
+        E(x)
+        torch.cuda.synchronize()
+        ops.Profiler.start(("rnn", "gemm"))
+        E(x)
+        torch.cuda.synchronize()
+        prof = ops.Profiler.stop()
+    assert prof["lstm_fwdx[N=30,H=500]"]["count"] == 4 and "lstm_fwd[N=30,H=500]" not in prof
+    assert prof["gemm_nt"]["count"] == 2                      # first_linear and final_linear only
+    with torch.no_grad():
+        st = ops.LaunchState()
+        st.rnn_cu_limit = 128
+        with ops.launch_state(st):
+            ops.Profiler.start(("rnn", "gemm"))
+            E(torch.randn(60, 80, 200, device="cuda"))
+            torch.cuda.synchronize()
+            prof = ops.Profiler.stop()
+    assert prof["lstm_fwd[N=60,H=500]"]["count"] == 4 and not any(k.startswith("lstm_fwdx") for k in prof)
